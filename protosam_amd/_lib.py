@@ -1,0 +1,62 @@
+"""ctypes binding of ``libprotosam_hip.so`` (the C-ABI declared in ``include/protosam_hip.h``).
+
+The product path has no CPU or eager-PyTorch fallback: if the shared library is missing, or a kernel
+launcher returns a non-zero status, this module raises. ``torch`` is imported first so that the HIP
+runtime bundled with PyTorch-ROCm (SONAME ``libamdhip64.so.7``) is the one the kernels run on; streams
+and device pointers handed across the boundary then belong to a single runtime.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede the CDLL below: loads PyTorch's libamdhip64)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libprotosam_hip.so")
+
+c_void_p, c_int, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+
+# name -> argtypes; every entry point returns int (0 = ok). Kept in the same order as the header.
+SIGNATURES = {
+    "psam_gemm_f16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p],
+    "psam_layernorm": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
+                       c_int, c_int, c_void_p],
+    "psam_attention_f16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
+                           c_int, c_int, c_int, c_int, c_void_p],
+    "psam_relpos": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p],
+}
+
+_lib = None
+
+
+class HipExtensionMissing(RuntimeError):
+    pass
+
+
+def _preload_torch_hip_runtime():
+    tl = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(tl):
+        ctypes.CDLL(tl, mode=ctypes.RTLD_GLOBAL)
+
+
+def lib():
+    """Return the loaded library, loading it on first use. Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipExtensionMissing(
+            f"{LIB_PATH} not found: build it with `make -C protosam_amd/csrc` (or __graft_entry__.build()). "
+            "protosam_amd has no CPU fallback.")
+    _preload_torch_hip_runtime()
+    L = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(L, name)  # AttributeError if the symbol is missing -> loud
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    _lib = L
+    return L
+
+
+def check(status, name):
+    if status != 0:
+        raise RuntimeError(f"{name} failed with status {status} (1 = bad argument, 2 = launch error)")

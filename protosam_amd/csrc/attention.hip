@@ -1,0 +1,443 @@
+// Fused multi-head self-attention (flash style, online softmax in fp32) on MFMA 16x16x32 f16.
+//
+// Replaces, per head, softmax((q*scale) k^T [+ decomposed rel-pos bias]) v of
+//   * DINOv2 `Attention` / `MemEffAttention` (global, N = 1 + (S/14)^2 tokens, no bias)  [external hub
+//     model; call site /root/reference/models/grid_proto_fewshot.py:90-91]
+//   * SAM `Attention.forward` (models/segment_anything/modeling/image_encoder.py:235-251) in both its
+//     global form (blocks in global_attn_indexes, 64x64 tokens) and its 14x14 windowed form
+//     (`window_partition` / `window_unpartition`, image_encoder.py:254-300) with
+//     `add_decomposed_rel_pos` (image_encoder.py:337-372).
+//
+// Input is the packed projection `qkv` fp16 [B, N, 3, H, hd] exactly as `self.qkv(x).reshape(B, N, 3, H, -1)`
+// lays it out, so no permute/contiguous copies exist. Output is fp16 [B, N, H*hd] (heads recombined).
+//
+// Work decomposition: one workgroup = 32*NW query rows of one (batch, head[, window]); each wave owns
+// 32 query rows. The product is computed "swapped": S^T = K Q^T and O^T = V^T P^T, so that every lane
+// owns one query column of the score tile: row max / row sum are in-lane plus two cross-lane shuffles,
+// the P registers are already the B operand of the second MFMA, and the online rescale of O^T is lane
+// local. K tiles (64 keys) are staged row-major in LDS, V tiles transposed ([hd][keys]) so both MFMA A
+// operands are 16-byte ds_read_b128; the next tile's global loads are issued before the current
+// tile's MFMAs.
+//
+// Window mode folds `window_partition` into index math: key j of window (wy,wx) is token
+// (wy*14 + j/14, wx*14 + j%14); positions outside the 64x64 map are the zero-padded tokens of the
+// reference (image_encoder.py:267-271) whose q/k/v equal the qkv bias -> read from `pad_row`.
+// Rel-pos bias uses the UNSCALED q (image_encoder.py:242-245): rel_h/rel_w are produced by
+// psam_relpos from the same fp16 q and added in fp32 after the scale.
+#include "common.h"
+
+struct AttnArgs {
+  const half_t* qkv;      // [B, N, 3, H, HD]
+  half_t* out;            // [B, N, H*HD]
+  const float* rel_h;     // mode1: [B,H,N,gw(64)]  mode2: [B,H,N,16]
+  const float* rel_w;
+  const half_t* pad_row;  // mode2: [3, H, HD] = fp16(qkv bias)
+  int B, N, H;
+  float scale;
+  int gh, gw, ws, nwx, nwin;  // token grid, window size, windows per row, windows per image
+};
+
+#define KT 64  // keys per tile
+
+template <int HD, int MODE, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
+  constexpr int NT = NW * 64;
+  constexpr int QB = NW * 32;
+  constexpr int HDP = (HD + 31) / 32 * 32;
+  constexpr int KS = HDP / 32;
+  constexpr int DT = HD / 16;
+  constexpr int CH = HD / 8;       // 16-byte chunks per row
+  constexpr int KLD = HDP + 8;     // Ks row stride (halfs)
+  constexpr int VLD = KT + 8;      // Vt row stride (halfs)
+  constexpr int NKL = (KT * CH + NT - 1) / NT;        // K chunk loads per thread
+  constexpr int NVL = ((KT / 2) * CH + NT - 1) / NT;  // V chunk-pair loads per thread
+  const float LOG2E = 1.4426950408889634f;
+
+  __shared__ __attribute__((aligned(16))) half_t Ks[KT * KLD];
+  __shared__ __attribute__((aligned(16))) half_t Vt[HD * VLD];
+  __shared__ float relh_s[MODE == 2 ? QB * 16 : 1];
+  __shared__ float relw_s[MODE == 2 ? QB * 16 : 1];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wv = t >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y;
+  int b, win = 0, wy = 0, wx = 0;
+  if (MODE == 2) {
+    b = blockIdx.z / p.nwin;
+    win = blockIdx.z % p.nwin;
+    wy = win / p.nwx;
+    wx = win % p.nwx;
+  } else {
+    b = blockIdx.z;
+  }
+  const int N = p.N, H = p.H;
+  const size_t rs = (size_t)3 * H * HD;  // qkv row stride (halfs)
+  const half_t* qkv_b = p.qkv + (size_t)b * N * rs;
+  const int nkeys = MODE == 2 ? p.ws * p.ws : N;
+  const int ntiles = (nkeys + KT - 1) / KT;
+
+  // ---- index helpers --------------------------------------------------------------------
+  // window-local index j -> token index, or -1 for a zero-padded position
+  auto win_token = [&](int j) -> int {
+    int y = wy * p.ws + j / p.ws, x = wx * p.ws + j % p.ws;
+    return (y < p.gh && x < p.gw) ? y * p.gw + x : -1;
+  };
+
+  // ---- query fragments (B operand of S^T = K Q^T), kept in registers -----------------------
+  const int qrow_blk = blockIdx.x * QB + wv * 32;  // first query row (global or window-local) of this wave
+  int qtok[2];
+  bool qvalid[2];
+  half8_t qf[2][KS];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    int q = qrow_blk + qt * 16 + li;
+    int tok;
+    if (MODE == 2) {
+      tok = q < nkeys ? win_token(q) : -1;
+    } else {
+      tok = q < N ? q : -1;
+    }
+    qvalid[qt] = tok >= 0;
+    qtok[qt] = tok >= 0 ? tok : 0;
+    const half_t* qp = qkv_b + (size_t)qtok[qt] * rs + (size_t)h * HD;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      int c0 = s * 32 + g * 8;
+      if (c0 < HD) {
+        qf[qt][s] = *reinterpret_cast<const half8_t*>(qp + c0);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[qt][s][e] = (half_t)0.f;
+      }
+    }
+  }
+
+  // ---- rel-pos bias state ------------------------------------------------------------------
+  float rwreg[2][4][4];  // MODE 1: rel_w[q][kw] for this lane's 32 key columns
+  const float* relh_q[2] = {nullptr, nullptr};
+  if (MODE == 1) {
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      size_t base = (((size_t)b * H + h) * N + qtok[qt]) * (size_t)p.gw;
+      relh_q[qt] = p.rel_h + base;
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        int kk = (tt >> 1) * 32 + g * 8 + (tt & 1) * 4;
+        float4 v = *reinterpret_cast<const float4*>(p.rel_w + base + kk);
+        rwreg[qt][tt][0] = v.x; rwreg[qt][tt][1] = v.y; rwreg[qt][tt][2] = v.z; rwreg[qt][tt][3] = v.w;
+      }
+    }
+  }
+  if (MODE == 2) {
+    for (int idx = t; idx < QB * 16; idx += NT) {
+      int qr = idx >> 4, k = idx & 15;
+      int q = blockIdx.x * QB + qr;
+      int tok = q < nkeys ? win_token(q) : -1;
+      float vh = 0.f, vw = 0.f;
+      if (tok >= 0) {
+        size_t base = (((size_t)b * H + h) * N + tok) * 16 + k;
+        vh = p.rel_h[base];
+        vw = p.rel_w[base];
+      }
+      relh_s[idx] = vh;
+      relw_s[idx] = vw;
+    }
+  }
+
+  // zero the K pad columns once (they are never overwritten)
+  if (HDP > HD) {
+    constexpr int PC = (HDP - HD) / 8;
+    for (int idx = t; idx < KT * PC; idx += NT) {
+      int key = idx / PC, c = idx % PC;
+      *reinterpret_cast<uint4*>(&Ks[key * KLD + HD + c * 8]) = make_uint4(0, 0, 0, 0);
+    }
+  }
+
+  // ---- K/V tile prefetch registers -----------------------------------------------------------
+  uint4 kreg[NKL];
+  uint4 vreg[NVL][2];
+
+  auto key_src = [&](int kidx, int which) -> const half_t* {
+    // pointer to the hd-vector of key `kidx` (tile-global index), or nullptr if masked
+    if (kidx >= nkeys) return nullptr;
+    if (MODE == 2) {
+      int tok = win_token(kidx);
+      if (tok < 0) return p.pad_row + ((size_t)which * H + h) * HD;
+      return qkv_b + (size_t)tok * rs + ((size_t)which * H + h) * HD;
+    }
+    return qkv_b + (size_t)kidx * rs + ((size_t)which * H + h) * HD;
+  };
+
+  auto load_tile = [&](int tile) {
+#pragma unroll
+    for (int i = 0; i < NKL; ++i) {
+      int idx = t + i * NT;
+      kreg[i] = make_uint4(0, 0, 0, 0);
+      if (idx < KT * CH) {
+        int key = idx / CH, c = idx % CH;
+        const half_t* src = key_src(tile * KT + key, 1);
+        if (src) kreg[i] = *reinterpret_cast<const uint4*>(src + c * 8);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NVL; ++i) {
+      int idx = t + i * NT;
+      vreg[i][0] = make_uint4(0, 0, 0, 0);
+      vreg[i][1] = make_uint4(0, 0, 0, 0);
+      if (idx < (KT / 2) * CH) {
+        int kp = idx / CH, c = idx % CH;
+        const half_t* s0 = key_src(tile * KT + 2 * kp, 2);
+        const half_t* s1 = key_src(tile * KT + 2 * kp + 1, 2);
+        if (s0) vreg[i][0] = *reinterpret_cast<const uint4*>(s0 + c * 8);
+        if (s1) vreg[i][1] = *reinterpret_cast<const uint4*>(s1 + c * 8);
+      }
+    }
+  };
+
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < NKL; ++i) {
+      int idx = t + i * NT;
+      if (idx < KT * CH) {
+        int key = idx / CH, c = idx % CH;
+        *reinterpret_cast<uint4*>(&Ks[key * KLD + c * 8]) = kreg[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NVL; ++i) {
+      int idx = t + i * NT;
+      if (idx < (KT / 2) * CH) {
+        int kp = idx / CH, c = idx % CH;
+        const uint32_t a[4] = {vreg[i][0].x, vreg[i][0].y, vreg[i][0].z, vreg[i][0].w};
+        const uint32_t bb[4] = {vreg[i][1].x, vreg[i][1].y, vreg[i][1].z, vreg[i][1].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          // elements 2e, 2e+1 of both keys -> Vt[c*8+2e][2kp..2kp+1], Vt[c*8+2e+1][2kp..2kp+1]
+          uint32_t lo = (a[e] & 0xffffu) | (bb[e] << 16);
+          uint32_t hi = (a[e] >> 16) | (bb[e] & 0xffff0000u);
+          *reinterpret_cast<uint32_t*>(&Vt[(c * 8 + 2 * e) * VLD + 2 * kp]) = lo;
+          *reinterpret_cast<uint32_t*>(&Vt[(c * 8 + 2 * e + 1) * VLD + 2 * kp]) = hi;
+        }
+      }
+    }
+  };
+
+  // ---- online-softmax state -------------------------------------------------------------------
+  f32x4 ot[DT][2];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ot[d][qt][r] = 0.f;
+  float mrun[2] = {-INFINITY, -INFINITY};
+  float lrun[2] = {0.f, 0.f};
+
+  load_tile(0);
+  __syncthreads();  // pad-column zeroing + rel tables visible
+  store_tile();
+  __syncthreads();
+
+  for (int tile = 0; tile < ntiles; ++tile) {
+    if (tile + 1 < ntiles) load_tile(tile + 1);
+
+    // S^T = K Q^T
+    f32x4 st[4][2];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st[tt][qt][r] = 0.f;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+      const int krow = (tt >> 1) * 32 + (li >> 2) * 8 + (tt & 1) * 4 + (li & 3);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        half8_t kf = *reinterpret_cast<const half8_t*>(&Ks[krow * KLD + s * 32 + g * 8]);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+          st[tt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qt][s], st[tt][qt], 0, 0, 0);
+      }
+    }
+
+    // scale + bias + mask, online softmax
+    half8_t pf[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      float bh = 0.f;
+      if (MODE == 1) bh = relh_q[qt][tile];
+      const int qr = wv * 32 + qt * 16 + li;  // block-local q row (MODE 2 tables)
+      float mx = -INFINITY;
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kk = (tt >> 1) * 32 + g * 8 + (tt & 1) * 4 + r;
+          const int kidx = tile * KT + kk;
+          float sv = st[tt][qt][r] * p.scale;
+          if (MODE == 1) sv += bh + rwreg[qt][tt][r];
+          if (MODE == 2) {
+            int kh = kidx / p.ws, kw = kidx - kh * p.ws;
+            if (kidx < nkeys) sv += relh_s[qr * 16 + kh] + relw_s[qr * 16 + kw];
+          }
+          if (kidx >= nkeys) sv = -INFINITY;
+          st[tt][qt][r] = sv;
+          mx = fmaxf(mx, sv);
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mnew = fmaxf(mrun[qt], mx);
+      const float alpha = exp2f((mrun[qt] - mnew) * LOG2E);
+      mrun[qt] = mnew;
+      float ps = 0.f;
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float pv = exp2f((st[tt][qt][r] - mnew) * LOG2E);
+          ps += pv;
+          pf[qt][tt >> 1][(tt & 1) * 4 + r] = (half_t)pv;
+        }
+      }
+      lrun[qt] = lrun[qt] * alpha + ps;
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ot[d][qt][r] *= alpha;
+    }
+
+    // O^T += V^T P^T
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        half8_t vf = *reinterpret_cast<const half8_t*>(&Vt[(d * 16 + li) * VLD + s2 * 32 + g * 8]);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+          ot[d][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qt][s2], ot[d][qt], 0, 0, 0);
+      }
+    }
+
+    __syncthreads();  // everyone done reading Ks/Vt
+    if (tile + 1 < ntiles) {
+      store_tile();
+      __syncthreads();
+    }
+  }
+
+  // ---- normalise and store: lane holds O^T[d = dt*16 + g*4 + r][q = li] ---------------------------
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    float l = lrun[qt];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    if (qvalid[qt]) {
+      half_t* op = p.out + ((size_t)b * N + qtok[qt]) * ((size_t)H * HD) + (size_t)h * HD;
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        half4_t o = {(half_t)(ot[d][qt][0] * inv), (half_t)(ot[d][qt][1] * inv), (half_t)(ot[d][qt][2] * inv),
+                     (half_t)(ot[d][qt][3] * inv)};
+        *reinterpret_cast<half4_t*>(op + d * 16 + g * 4) = o;
+      }
+    }
+  }
+}
+
+template <int HD>
+static int launch_attn(const AttnArgs& p, int mode, hipStream_t s) {
+  if (mode == 2) {
+    constexpr int NW = 7;
+    int nq = p.ws * p.ws;
+    dim3 grid((nq + NW * 32 - 1) / (NW * 32), p.H, p.B * p.nwin), block(NW * 64);
+    hipLaunchKernelGGL((attn_kernel<HD, 2, NW>), grid, block, 0, s, p);
+  } else {
+    constexpr int NW = 4;
+    dim3 grid((p.N + NW * 32 - 1) / (NW * 32), p.H, p.B), block(NW * 64);
+    if (mode == 1)
+      hipLaunchKernelGGL((attn_kernel<HD, 1, NW>), grid, block, 0, s, p);
+    else
+      hipLaunchKernelGGL((attn_kernel<HD, 0, NW>), grid, block, 0, s, p);
+  }
+  return psam_launch_status();
+}
+
+// mode 0: global, no bias.  mode 1: global + decomposed rel-pos (requires gw == 64, N == gh*gw).
+// mode 2: ws x ws windows over the gh x gw token map (zero-padded as the reference) + rel-pos.
+extern "C" int psam_attention_f16(const void* qkv, void* out, const float* rel_h, const float* rel_w,
+                                  const void* pad_row, int B, int N, int H, int hd, float scale, int mode, int gh,
+                                  int gw, int ws, void* stream) {
+  if (B <= 0 || N <= 0 || H <= 0 || mode < 0 || mode > 2) return PSAM_ERR_ARG;
+  AttnArgs p;
+  p.qkv = (const half_t*)qkv;
+  p.out = (half_t*)out;
+  p.rel_h = rel_h;
+  p.rel_w = rel_w;
+  p.pad_row = (const half_t*)pad_row;
+  p.B = B;
+  p.N = N;
+  p.H = H;
+  p.scale = scale;
+  p.gh = gh;
+  p.gw = gw;
+  p.ws = ws;
+  p.nwx = p.nwin = 0;
+  if (mode == 1) {
+    if (gw != KT || gh * gw != N || !rel_h || !rel_w) return PSAM_ERR_ARG;
+  }
+  if (mode == 2) {
+    if (ws <= 0 || ws > 16 || gh * gw != N || !rel_h || !rel_w || !pad_row) return PSAM_ERR_ARG;
+    p.nwx = (gw + ws - 1) / ws;
+    p.nwin = p.nwx * ((gh + ws - 1) / ws);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (hd == 64) return launch_attn<64>(p, mode, s);
+  if (hd == 80) return launch_attn<80>(p, mode, s);
+  return PSAM_ERR_ARG;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Decomposed relative-position terms (models/segment_anything/modeling/image_encoder.py:303-372):
+//   rel_h[b,h,n,kh] = q[b,n,h,:] . Rh[qy - kh + (K-1), :],   rel_w[b,h,n,kw] = q . Rw[qx - kw + (K-1), :]
+// with (qy,qx) the query's position inside its attention region (whole 64x64 map, or its 14x14
+// window) and K the region side. Rh/Rw are the (2K-1, hd) tables `rel_pos_h/w` (get_rel_pos is the
+// identity gather when the table length already equals 2K-1, the only case SAM's 1024 input hits).
+// q is the UNSCALED fp16 query from the packed qkv buffer. Output fp32 [B,H,N,KO] (KO = 64 or 16).
+__global__ void relpos_kernel(const half_t* __restrict__ qkv, const float* __restrict__ Rh,
+                              const float* __restrict__ Rw, float* __restrict__ rel_h, float* __restrict__ rel_w,
+                              int B, int N, int H, int hd, int gw, int K, int KO, int windowed) {
+  // one block per (token n, head h, batch b); 2*KO threads: [0,KO) -> rel_h, [KO,2KO) -> rel_w
+  extern __shared__ float qs[];
+  const int n = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const half_t* q = qkv + ((size_t)b * N + n) * ((size_t)3 * H * hd) + (size_t)h * hd;
+  for (int c = threadIdx.x; c < hd; c += blockDim.x) qs[c] = (float)q[c];
+  __syncthreads();
+  int y = n / gw, x = n % gw;
+  if (windowed) {
+    y %= K;
+    x %= K;
+  }
+  const int k = threadIdx.x % KO;
+  const bool is_w = threadIdx.x >= KO;
+  float acc = 0.f;
+  if (k < K) {
+    const float* R = is_w ? Rw + (size_t)(x - k + K - 1) * hd : Rh + (size_t)(y - k + K - 1) * hd;
+    for (int c = 0; c < hd; ++c) acc += qs[c] * R[c];
+  }
+  float* o = is_w ? rel_w : rel_h;
+  o[(((size_t)b * H + h) * N + n) * KO + k] = acc;
+}
+
+extern "C" int psam_relpos(const void* qkv, const float* Rh, const float* Rw, float* rel_h, float* rel_w, int B,
+                           int N, int H, int hd, int gw, int K, int windowed, void* stream) {
+  if (B <= 0 || N <= 0 || K <= 0 || K > 64) return PSAM_ERR_ARG;
+  const int KO = windowed ? 16 : 64;
+  if (K > KO) return PSAM_ERR_ARG;
+  dim3 grid(N, H, B), block(2 * KO);
+  hipLaunchKernelGGL(relpos_kernel, grid, block, hd * sizeof(float), (hipStream_t)stream, (const half_t*)qkv, Rh, Rw,
+                     rel_h, rel_w, B, N, H, hd, gw, K, KO, windowed);
+  return psam_launch_status();
+}

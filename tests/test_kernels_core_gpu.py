@@ -1,0 +1,164 @@
+"""GPU parity of the three core kernels (GEMM, LayerNorm, attention) against fp32 references.
+
+GEMM / attention take fp16 operands and accumulate in fp32, so the reference is the fp32 op evaluated
+on the SAME fp16-rounded operands; tolerances below are the fp16 output rounding (2^-11 relative) plus
+accumulation-order noise.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, dev, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dev)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1297, 768, 768), (300, 256, 640), (4096, 1280, 1280)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm(dev, M, N, K, epi):
+    from protosam_amd import ops
+    a = _rand((M, K), dev, 1.0, 1).half()
+    w = _rand((N, K), dev, 0.05, 2).half()  # asymmetric, transposition-detecting
+    bias = _rand((N,), dev, 0.5, 3)
+    ref = a.float() @ w.float().t() + bias
+    if epi == 0:
+        out = ops.gemm(a, w, bias, epilogue=ops.EPI_F16)
+        torch.testing.assert_close(out.float(), ref, rtol=2e-3, atol=2e-3)
+    elif epi == 1:
+        out = ops.gemm(a, w, bias, epilogue=ops.EPI_GELU_F16)
+        torch.testing.assert_close(out.float(), torch.nn.functional.gelu(ref), rtol=2e-3, atol=2e-3)
+    else:
+        resid = _rand((M, N), dev, 1.0, 4)
+        gamma = _rand((N,), dev, 1.0, 5)
+        out = ops.gemm(a, w, bias, epilogue=ops.EPI_F32, resid=resid, gamma=gamma)
+        torch.testing.assert_close(out, resid + gamma * ref, rtol=1e-4, atol=2e-4)
+
+
+def test_gemm_row_remap_and_resid_mod(dev):
+    """patch-embed style: rows of batch b land at b*stride + off + p, resid (pos-embed) indexed by p."""
+    from protosam_amd import ops
+    B, P, N, K = 3, 100, 128, 64
+    a = _rand((B * P, K), dev, 1.0, 1).half()
+    w = _rand((N, K), dev, 0.1, 2).half()
+    bias = _rand((N,), dev, 0.5, 3)
+    pos = _rand((P, N), dev, 1.0, 4)
+    out = torch.zeros((B, P + 1, N), device=dev)
+    ops.gemm(a, w, bias, out=out, epilogue=ops.EPI_F32, resid=pos, resid_mod=P, out_seg=P, out_seg_stride=P + 1,
+             out_seg_off=1)
+    ref = (a.float() @ w.float().t() + bias).view(B, P, N) + pos
+    torch.testing.assert_close(out[:, 1:], ref, rtol=1e-4, atol=2e-4)
+    assert float(out[:, 0].abs().max()) == 0.0
+
+
+def test_gemm_inplace_residual(dev):
+    from protosam_amd import ops
+    M, N, K = 257, 256, 128
+    a = _rand((M, K), dev, 1.0, 1).half()
+    w = _rand((N, K), dev, 0.1, 2).half()
+    x = _rand((M, N), dev, 1.0, 3)
+    ref = x + a.float() @ w.float().t()
+    ops.gemm(a, w, None, out=x, epilogue=ops.EPI_F32, resid=x)
+    torch.testing.assert_close(x, ref, rtol=1e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("M,D", [(5, 256), (1297, 768), (4096, 1280), (33, 1024)])
+@pytest.mark.parametrize("eps", [1e-6, 1e-5])
+def test_layernorm(dev, M, D, eps):
+    from protosam_amd import ops
+    x = _rand((M, D), dev, 3.0, 1) + 0.7
+    w = _rand((D,), dev, 1.0, 2)
+    b = _rand((D,), dev, 1.0, 3)
+    ref = torch.nn.functional.layer_norm(x, (D,), w, b, eps)
+    y32 = ops.layernorm(x, w, b, eps, out_dtype=torch.float32)
+    torch.testing.assert_close(y32, ref, rtol=1e-5, atol=1e-5)
+    y2 = torch.empty_like(x)
+    y16 = ops.layernorm(x, w, b, eps, out_dtype=torch.float16, out2=y2, zero_tail_rows=1)
+    assert y16.shape == (M + 1, D)
+    torch.testing.assert_close(y16[:M].float(), ref, rtol=1e-3, atol=2e-3)
+    torch.testing.assert_close(y2, ref, rtol=1e-5, atol=1e-5)
+    assert float(y16[M].abs().max()) == 0.0
+
+
+def _ref_attn_global(qkv, B, N, H, hd, scale, rel=None):
+    q, k, v = qkv.float().view(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    att = (q * scale) @ k.transpose(-2, -1)
+    if rel is not None:
+        att = att + rel
+    return (att.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(B, N, H * hd)
+
+
+@pytest.mark.parametrize("N,H,hd,B", [(1297, 12, 64, 2), (64, 2, 64, 1), (200, 3, 80, 1)])
+def test_attention_global(dev, N, H, hd, B):
+    from protosam_amd import ops
+    qkv = _rand((B, N, 3, H, hd), dev, 1.0, 7).half()
+    scale = hd ** -0.5
+    out = ops.attention(qkv, B, N, H, hd, scale)
+    ref = _ref_attn_global(qkv, B, N, H, hd, scale)
+    torch.testing.assert_close(out.float(), ref, rtol=2e-3, atol=2e-3)
+
+
+def test_attention_global_spiky_rows(dev):
+    """forces the online-softmax rescale path: one key dominates late in the sequence."""
+    from protosam_amd import ops
+    B, N, H, hd = 1, 512, 1, 64
+    qkv = _rand((B, N, 3, H, hd), dev, 0.3, 9)
+    qkv[0, 400, 1, 0] = qkv[0, 17, 0, 0] * 40.0  # key 400 aligned with query 17
+    qkv = qkv.half()
+    out = ops.attention(qkv, B, N, H, hd, hd ** -0.5)
+    ref = _ref_attn_global(qkv, B, N, H, hd, hd ** -0.5)
+    torch.testing.assert_close(out.float(), ref, rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("H,hd", [(2, 64), (2, 80)])
+def test_attention_global_relpos(dev, H, hd):
+    from oracle.sam_image_encoder import decomposed_rel_pos_terms
+    from protosam_amd import ops
+    B, g = 1, 64
+    N = g * g
+    qkv = _rand((B, N, 3, H, hd), dev, 1.0, 11).half()
+    Rh = _rand((2 * g - 1, hd), dev, 0.3, 12)
+    Rw = _rand((2 * g - 1, hd), dev, 0.3, 13)
+    scale = hd ** -0.5
+    rel_h, rel_w = ops.relpos(qkv, Rh, Rw, B, N, H, hd, g, g, False)
+    q = qkv.float().view(B, N, 3, H, hd)[:, :, 0].permute(0, 2, 1, 3).reshape(B * H, N, hd)
+    rh_ref, rw_ref = decomposed_rel_pos_terms(q.cpu(), Rh.cpu(), Rw.cpu(), (g, g))
+    torch.testing.assert_close(rel_h.cpu().view(B * H, g, g, g), rh_ref, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(rel_w.cpu().view(B * H, g, g, g), rw_ref, rtol=1e-4, atol=1e-4)
+    out = ops.attention(qkv, B, N, H, hd, scale, mode=1, rel_h=rel_h, rel_w=rel_w, gh=g, gw=g)
+    bias = (rh_ref[..., :, None] + rw_ref[..., None, :]).reshape(B, H, N, N).to(dev)
+    ref = _ref_attn_global(qkv, B, N, H, hd, scale, rel=bias)
+    torch.testing.assert_close(out.float(), ref, rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("H,hd", [(2, 64), (2, 80)])
+def test_attention_window_relpos(dev, H, hd):
+    """14x14 windows over a 64x64 map, zero-padded tokens carry the qkv bias (image_encoder.py:267-271)."""
+    from oracle.sam_image_encoder import decomposed_rel_pos_terms, window_partition, window_unpartition
+    from protosam_amd import ops
+    B, g, ws = 2, 64, 14
+    N, C = g * g, H * hd
+    qkv = _rand((B, N, 3, H, hd), dev, 1.0, 21).half()
+    pad = _rand((3, H, hd), dev, 1.0, 22).half()
+    Rh = _rand((2 * ws - 1, hd), dev, 0.3, 23)
+    Rw = _rand((2 * ws - 1, hd), dev, 0.3, 24)
+    scale = hd ** -0.5
+    rel_h, rel_w = ops.relpos(qkv, Rh, Rw, B, N, H, hd, g, ws, True)
+    out = ops.attention(qkv, B, N, H, hd, scale, mode=2, rel_h=rel_h, rel_w=rel_w, pad_row=pad, gh=g, gw=g, ws=ws)
+
+    # reference on CPU: pad the qkv map with the pad row, partition, attend per window, unpartition
+    m = qkv.float().cpu().view(B, g, g, 3 * C) - pad.float().cpu().view(1, 1, 1, 3 * C)
+    wins, pad_hw = window_partition(m, ws)          # zero padding == pad row after the shift below
+    wins = wins + pad.float().cpu().view(1, 1, 1, 3 * C)
+    nW = wins.shape[0]
+    qkv_w = wins.view(nW, ws * ws, 3, H, hd).permute(2, 0, 3, 1, 4).reshape(3, nW * H, ws * ws, hd)
+    q, k, v = qkv_w[0], qkv_w[1], qkv_w[2]
+    att = (q * scale) @ k.transpose(-2, -1)
+    rh, rw = decomposed_rel_pos_terms(q, Rh.cpu(), Rw.cpu(), (ws, ws))
+    att = (att.view(-1, ws, ws, ws, ws) + rh[..., :, None] + rw[..., None, :]).view(-1, ws * ws, ws * ws)
+    o = (att.softmax(-1) @ v).view(nW, H, ws, ws, hd).permute(0, 2, 3, 1, 4).reshape(nW, ws, ws, C)
+    ref = window_unpartition(o, ws, pad_hw, (g, g)).reshape(B, N, C)
+    torch.testing.assert_close(out.float().cpu(), ref, rtol=2e-3, atol=2e-3)
