@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the CDLL below: loads PyTorch's libamd
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libprotosam_hip.so")
 
-c_void_p, c_int, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+c_void_p, c_int, c_float, c_longlong = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong
 
 # name -> argtypes; every entry point returns int (0 = ok). Kept in the same order as the header.
 SIGNATURES = {
@@ -23,6 +23,17 @@ SIGNATURES = {
     "psam_attention_f16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                            c_int, c_int, c_int, c_int, c_void_p],
     "psam_relpos": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p],
+    "psam_alp_bank": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float,
+                      c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "psam_alp_sim": [c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_float, c_float,
+                     c_void_p, c_void_p, c_int, c_void_p],
+    "psam_patchify_bilinear": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "psam_bilinear_nchw": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "psam_prob_argmax": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "psam_broadcast_rows": [c_void_p, c_int, c_void_p, c_int, c_longlong, c_longlong, c_void_p],
+    "psam_minmax": [c_void_p, c_int, c_longlong, c_void_p, c_void_p],
+    "psam_sam_patchify": [c_void_p, c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_float), ctypes.POINTER(c_float),
+                          c_int, c_void_p, c_void_p, c_void_p],
 }
 
 _lib = None

@@ -1,0 +1,239 @@
+// HBM-bound resampling / packing kernels around the two ViTs.
+//
+//  psam_patchify_bilinear : F.interpolate(imgs, (S,S), 'bilinear') (models/grid_proto_fewshot.py:88-89)
+//                           fused with the im2col of DINOv2's PatchEmbed conv (k=14, s=14) -> fp16 rows.
+//  psam_bilinear_nchw     : F.interpolate(x, size, 'bilinear', align_corners=False) on fp32 NCHW
+//                           (grid_proto_fewshot.py:272-273; models/ProtoSAM.py:592-594).
+//  psam_prob_argmax       : [optional bilinear to (OH,OW)] -> softmax(dim=1) -> argmax for the 2-class
+//                           coarse logits (models/ProtoSAM.py:592-602), writing output_p and uint8 pred.
+//  psam_minmax / psam_sam_patchify : per-image min/max, then ((x-min)/(max-min)*255).astype(uint8)
+//                           (ProtoSAM.py:660) -> (u8 - pixel_mean)/pixel_std (modeling/sam.py:163-173)
+//                           -> im2col of SAM's PatchEmbed conv (k=16, s=16) -> fp16 rows.
+//  psam_broadcast_rows    : writes one fp32 row into out[b*stride + off] (cls token + pos_embed[0]).
+//
+// Bilinear source index math is ATen's area_pixel_compute_source_index (align_corners=False):
+//   src = max(scale*(dst+0.5)-0.5, 0), scale = in/out in fp32; i0 = (int)src, i1 = i0 + (i0 < in-1),
+//   l1 = src - i0, l0 = 1 - l1;  out = h0*(w0*p00 + w1*p01) + h1*(w0*p10 + w1*p11).
+#include "common.h"
+
+struct Lin {
+  int i0, i1;
+  float l0, l1;
+};
+__device__ __forceinline__ Lin lin_src(int dst, float scale, int in_size) {
+  float s = scale * ((float)dst + 0.5f) - 0.5f;
+  s = s < 0.f ? 0.f : s;
+  int i0 = (int)s;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  Lin r;
+  r.i0 = i0;
+  r.i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  float l1 = s - (float)i0;
+  l1 = l1 < 0.f ? 0.f : (l1 > 1.f ? 1.f : l1);
+  r.l1 = l1;
+  r.l0 = 1.f - l1;
+  return r;
+}
+__device__ __forceinline__ float bilerp(const float* __restrict__ p, int W, const Lin& y, const Lin& x) {
+  const float* r0 = p + (size_t)y.i0 * W;
+  const float* r1 = p + (size_t)y.i1 * W;
+  return y.l0 * (x.l0 * r0[x.i0] + x.l1 * r0[x.i1]) + y.l1 * (x.l0 * r1[x.i0] + x.l1 * r1[x.i1]);
+}
+
+// out[(b*np + py*npw + px)*Kpad + c*P*P + ky*P + kx] = resize(img)[b,c,py*P+ky,px*P+kx]; zero for k >= 3*P*P
+__global__ void patchify_bilinear_kernel(const float* __restrict__ img, int B, int C, int H, int W, int S, int P,
+                                         int Kpad, half_t* __restrict__ out) {
+  const int npw = S / P;
+  const int patch = blockIdx.x, b = blockIdx.y;
+  const int py = patch / npw, px = patch % npw;
+  const float sh = (float)H / (float)S, sw = (float)W / (float)S;
+  half_t* o = out + ((size_t)b * npw * npw + patch) * Kpad;
+  const int K = C * P * P;
+  const bool same = (H == S && W == S);
+  for (int k = threadIdx.x; k < Kpad; k += blockDim.x) {
+    float v = 0.f;
+    if (k < K) {
+      int c = k / (P * P), r = k % (P * P);
+      int y = py * P + r / P, x = px * P + r % P;
+      const float* pl = img + ((size_t)b * C + c) * H * W;
+      if (same) {
+        v = pl[(size_t)y * W + x];
+      } else {
+        Lin ly = lin_src(y, sh, H), lx = lin_src(x, sw, W);
+        v = bilerp(pl, W, ly, lx);
+      }
+    }
+    o[k] = (half_t)v;
+  }
+}
+
+extern "C" int psam_patchify_bilinear(const float* img, int B, int C, int H, int W, int S, int P, int Kpad, void* out,
+                                      void* stream) {
+  if (B <= 0 || S % P || Kpad < C * P * P) return PSAM_ERR_ARG;
+  const int np = (S / P) * (S / P);
+  hipLaunchKernelGGL(patchify_bilinear_kernel, dim3(np, B), dim3(256), 0, (hipStream_t)stream, img, B, C, H, W, S, P,
+                     Kpad, (half_t*)out);
+  return psam_launch_status();
+}
+
+__global__ void bilinear_nchw_kernel(const float* __restrict__ in, int planes, int IH, int IW, int OH, int OW,
+                                     float* __restrict__ out) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  const int pl = blockIdx.z;
+  if (x >= OW) return;
+  const float sh = (float)IH / (float)OH, sw = (float)IW / (float)OW;
+  Lin ly = lin_src(y, sh, IH), lx = lin_src(x, sw, IW);
+  out[((size_t)pl * OH + y) * OW + x] = bilerp(in + (size_t)pl * IH * IW, IW, ly, lx);
+}
+
+extern "C" int psam_bilinear_nchw(const float* in, int planes, int IH, int IW, int OH, int OW, float* out,
+                                  void* stream) {
+  if (planes <= 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0) return PSAM_ERR_ARG;
+  hipLaunchKernelGGL(bilinear_nchw_kernel, dim3((OW + 255) / 256, OH, planes), dim3(256), 0, (hipStream_t)stream, in,
+                     planes, IH, IW, OH, OW, out);
+  return psam_launch_status();
+}
+
+// logits [B,2,IH,IW] -> (bilinear to OH,OW unless equal) -> softmax -> prob [B,2,OH,OW], pred u8 [B,OH,OW]
+// fg_sum[b] (optional): number of foreground pixels (int32, atomically accumulated; caller zeroes it).
+__global__ void prob_argmax_kernel(const float* __restrict__ logits, int IH, int IW, int OH, int OW,
+                                   float* __restrict__ prob, uint8_t* __restrict__ pred, int* __restrict__ fg_sum) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y, b = blockIdx.z;
+  int fg = 0;
+  if (x < OW) {
+    const float* l0p = logits + ((size_t)b * 2 + 0) * IH * IW;
+    const float* l1p = l0p + (size_t)IH * IW;
+    float l0, l1;
+    if (IH == OH && IW == OW) {
+      l0 = l0p[(size_t)y * IW + x];
+      l1 = l1p[(size_t)y * IW + x];
+    } else {
+      const float sh = (float)IH / (float)OH, sw = (float)IW / (float)OW;
+      Lin ly = lin_src(y, sh, IH), lx = lin_src(x, sw, IW);
+      l0 = bilerp(l0p, IW, ly, lx);
+      l1 = bilerp(l1p, IW, ly, lx);
+    }
+    const float m = fmaxf(l0, l1);
+    const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+    const float s = e0 + e1;
+    const float p0 = e0 / s, p1 = e1 / s;
+    const size_t o = ((size_t)b * 2) * OH * OW + (size_t)y * OW + x;
+    prob[o] = p0;
+    prob[o + (size_t)OH * OW] = p1;
+    fg = p1 > p0 ? 1 : 0;  // argmax returns the first maximum on ties
+    pred[((size_t)b * OH + y) * OW + x] = (uint8_t)fg;
+  }
+  if (fg_sum) {
+    unsigned long long bal = __ballot(fg);
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&fg_sum[b], __popcll(bal));
+  }
+}
+
+extern "C" int psam_prob_argmax(const float* logits, int B, int IH, int IW, int OH, int OW, float* prob, void* pred,
+                                int* fg_sum, void* stream) {
+  if (B <= 0) return PSAM_ERR_ARG;
+  hipLaunchKernelGGL(prob_argmax_kernel, dim3((OW + 255) / 256, OH, B), dim3(256), 0, (hipStream_t)stream, logits, IH,
+                     IW, OH, OW, prob, (uint8_t*)pred, fg_sum);
+  return psam_launch_status();
+}
+
+__global__ void broadcast_rows_kernel(const float* __restrict__ row, int D, float* __restrict__ out, long long stride,
+                                      long long off) {
+  float* o = out + (size_t)blockIdx.x * stride + off;
+  for (int k = threadIdx.x; k < D; k += blockDim.x) o[k] = row[k];
+}
+extern "C" int psam_broadcast_rows(const float* row, int D, float* out, int B, long long stride, long long off,
+                                   void* stream) {
+  if (B <= 0 || D <= 0) return PSAM_ERR_ARG;
+  hipLaunchKernelGGL(broadcast_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, row, D, out, stride, off);
+  return psam_launch_status();
+}
+
+// ---- image hand-off to SAM ------------------------------------------------------------------------------
+// mm[2*b] = min, mm[2*b+1] = max over the whole [3,H,W] image b (ProtoSAM.py:660: min/max over all channels).
+// Encoded as order-preserving uint32 so atomicMin/Max work; caller initialises with psam_minmax_init.
+__device__ __forceinline__ uint32_t f2ord(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t u) {
+  return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+__global__ void minmax_init_kernel(uint32_t* mm, int B) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) {
+    mm[2 * i] = 0xffffffffu;
+    mm[2 * i + 1] = 0u;
+  }
+}
+__global__ __launch_bounds__(256) void minmax_kernel(const float* __restrict__ x, size_t n_per_img,
+                                                     uint32_t* __restrict__ mm) {
+  const int b = blockIdx.y;
+  const float* p = x + (size_t)b * n_per_img;
+  float lo = INFINITY, hi = -INFINITY;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_per_img; i += (size_t)gridDim.x * blockDim.x) {
+    float v = p[i];
+    lo = fminf(lo, v);
+    hi = fmaxf(hi, v);
+  }
+  lo = wave_min(lo);
+  hi = wave_max(hi);
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&mm[2 * b], f2ord(lo));
+    atomicMax(&mm[2 * b + 1], f2ord(hi));
+  }
+}
+
+// img fp32 [B,3,IH,IW] (the 1024^2 bilinear-upsampled query) -> u8 quantise -> normalise -> im2col fp16
+// If IH != S the image is first bilinearly resized to SxS (ProtoSAM.py:592-593) on the fly; min/max must then
+// have been taken over the RESIZED image (use psam_bilinear_nchw + psam_minmax, or pass resized input).
+__global__ void sam_patchify_kernel(const float* __restrict__ img, const uint32_t* __restrict__ mm, int S, int P,
+                                    float m0, float m1, float m2, float s0, float s1, float s2, int quantise,
+                                    half_t* __restrict__ out, uint8_t* __restrict__ u8out) {
+  const int npw = S / P;
+  const int patch = blockIdx.x, b = blockIdx.y;
+  const int py = patch / npw, px = patch % npw;
+  const float lo = ord2f(mm[2 * b]), hi = ord2f(mm[2 * b + 1]);
+  const float rng = hi - lo;
+  const int K = 3 * P * P;
+  half_t* o = out + ((size_t)b * npw * npw + patch) * K;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    int c = k / (P * P), r = k % (P * P);
+    int y = py * P + r / P, x = px * P + r % P;
+    float v = img[(((size_t)b * 3 + c) * S + y) * S + x];
+    float q = (v - lo) / rng;
+    if (quantise) {
+      q = q * 255.0f;
+      // numpy astype(uint8) of a float in [0,255]: truncation toward zero
+      q = (float)(int)q;
+      if (u8out) u8out[(((size_t)b * 3 + c) * S + y) * S + x] = (uint8_t)q;
+    }
+    const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2);
+    const float sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+    o[k] = (half_t)((q - mean) / sd);
+  }
+}
+
+extern "C" int psam_minmax(const float* x, int B, long long n_per_img, void* mm, void* stream) {
+  if (B <= 0 || n_per_img <= 0) return PSAM_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(minmax_init_kernel, dim3((B + 63) / 64), dim3(64), 0, s, (uint32_t*)mm, B);
+  int nb = (int)((n_per_img + 256 * 8 - 1) / (256 * 8));
+  if (nb > 512) nb = 512;
+  hipLaunchKernelGGL(minmax_kernel, dim3(nb, B), dim3(256), 0, s, x, (size_t)n_per_img, (uint32_t*)mm);
+  return psam_launch_status();
+}
+
+// quantise = 1: ProtoSAM (uint8 image, SAM pixel_mean/std). quantise = 0: ProtoMedSAM ([0,1] float image,
+// mean 0 / std 1, models/ProtoMedSAM.py:203-205).
+extern "C" int psam_sam_patchify(const float* img, const void* mm, int B, int S, int P, const float* mean3,
+                                 const float* std3, int quantise, void* out, void* u8out, void* stream) {
+  if (B <= 0 || S % P) return PSAM_ERR_ARG;
+  const int np = (S / P) * (S / P);
+  hipLaunchKernelGGL(sam_patchify_kernel, dim3(np, B), dim3(256), 0, (hipStream_t)stream, img, (const uint32_t*)mm, S,
+                     P, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], quantise, (half_t*)out,
+                     (uint8_t*)u8out);
+  return psam_launch_status();
+}

@@ -1,0 +1,147 @@
+"""ALPNet (`FewShotSeg`) on the HIP path: DINOv2 encoder + ALP prototype matching.
+
+Mirrors /root/reference/models/grid_proto_fewshot.py (FewShotSeg.__init__ :33-44, get_encoder :46-81,
+get_features :83-103, get_cls :105-121, forward :150-290) for inference. Differences that do not change
+results:
+  * the encoder is our `DinoVisionTransformer` (hub key names) instead of `torch.hub.load`;
+  * features stay token-major; `supp_fts` / `qry_fts` in the returned 7-tuple are zero-copy permuted views with
+    the reference's shapes;
+  * the support image's features and prototype bank are cached across calls while the support tensors are
+    unchanged (the reference re-encodes the support on every slice, :181-184; same values).
+    `cache_support=False` reproduces the reference's per-call cost.
+Out of scope here (training only): alignLoss, dino losses, LoRA injection (`lora` must be 0).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .alpmodule import MultiProtoAsConv
+from .dinov2 import DinoVisionTransformer
+
+DEFAULT_FEATURE_SIZE = 32  # util/consts.py
+FG_PROT_MODE = "gridconv+"
+BG_PROT_MODE = "gridconv"
+FG_THRESH = 0.95
+BG_THRESH = 0.95
+
+_HUB_NAME = {"dinov2_b14": "dinov2_vitb14", "dinov2_l14": "dinov2_vitl14", "dinov2_l14_reg": "dinov2_vitl14_reg"}
+
+
+class FewShotSeg(nn.Module):
+    def __init__(self, image_size, pretrained_path=None, cfg=None, cache_support=True):
+        super().__init__()
+        self.image_size = image_size
+        self.pretrained_path = pretrained_path
+        self.config = cfg or {"align": False, "debug": False}
+        self.cache_support = cache_support
+        self.get_encoder()
+        self.get_cls()
+        self._sup_key = None
+        self._sup_bank = None
+        self._sup_tokens = None
+        if self.pretrained_path:
+            self.load_state_dict(torch.load(self.pretrained_path), strict=True)
+            print(f"###### Pre-trained model f{self.pretrained_path} has been loaded ######")
+
+    def get_encoder(self):
+        which = self.config["which_model"]
+        if which in _HUB_NAME:
+            self.encoder = DinoVisionTransformer(_HUB_NAME[which], depth=self.config.get("encoder_depth"))
+            s = max(self.image_size // 14, DEFAULT_FEATURE_SIZE)
+            self.config["feature_hw"] = [s, s]
+        elif which in ("dlfcn_res101", "default"):
+            raise NotImplementedError(
+                "dlfcn_res101 (torchvision DeepLabV3-ResNet101, models/backbone/torchvision_backbones.py) is the "
+                "reference's CPU-only baseline backbone and is not part of the MI355X hot path")
+        else:
+            raise NotImplementedError(f"Backbone network {which} not implemented")
+        if self.config.get("lora", 0) > 0:
+            raise NotImplementedError("LoRA injection is a fine-tuning feature (util/lora.py); inference uses lora=0")
+
+    def get_cls(self):
+        proto_hw = self.config["proto_grid_size"]
+        if self.config["cls_name"] != "grid_proto":
+            raise NotImplementedError(f'Classifier {self.config["cls_name"]} not implemented')
+        self.cls_unit = MultiProtoAsConv(proto_grid=[proto_hw, proto_hw], feature_hw=self.config["feature_hw"],
+                                         embed_dim=self.encoder.embed_dim)
+
+    # ---- features ------------------------------------------------------------------------------------------------
+    def _grid(self):
+        S = self.image_size // 14 * 14
+        g = S // 14
+        if g * g < DEFAULT_FEATURE_SIZE ** 2:
+            raise NotImplementedError("image_size < 448 needs the 32x32 feature upsample (grid_proto_fewshot.py:96-98)")
+        return S, g
+
+    def get_features(self, imgs_concat):
+        """-> [B, C, h, w] as the reference (a permuted view of the token-major buffer)."""
+        S, g = self._grid()
+        t = self.encoder.forward_tokens(imgs_concat.float(), S)
+        R = self.encoder.num_register_tokens
+        B, _, C = t.shape
+        return t[:, 1 + R:].reshape(B, g, g, C).permute(0, 3, 1, 2)
+
+    def _support_bank(self, supp, fg, bg, pool_w):
+        """Support features + prototype bank, cached while the support is unchanged. The cache holds references to
+        the tensors it was built from (so their storage cannot be recycled under the same address); a different
+        tensor object with identical content (the reference caller re-uploads the support every slice,
+        validation_protosam.py:374-385) is recognised by an on-device equality test instead of a re-encode."""
+        if self.cache_support and self._sup_key is not None:
+            k_supp, k_fg, k_bg, k_pool, k_ver = self._sup_key
+            if k_pool == pool_w and k_supp.shape == supp.shape and k_fg.shape == fg.shape:
+                same_obj = (k_supp is supp and k_fg is fg and k_bg is bg and k_ver == (supp._version, fg._version))
+                if same_obj or (torch.equal(k_supp, supp) and torch.equal(k_fg, fg)
+                                and (k_bg is bg or (k_bg is not None and bg is not None and torch.equal(k_bg, bg)))):
+                    return self._sup_bank, self._sup_tokens
+        S, g = self._grid()
+        C = self.encoder.embed_dim
+        R = self.encoder.num_register_tokens
+        t = self.encoder.forward_tokens(supp.float(), S)          # workspace buffer [1, N, C]
+        tok = t[0, 1 + R:].clone()                                # [g*g, C] kept for the cache / returned tuple
+        fg2 = fg.reshape(fg.shape[-2], fg.shape[-1]).float().contiguous()
+        bg2 = None
+        if bg is not None and not bool(torch.equal(bg.float(), 1 - fg.float())):   # ProtoSAM.py:63 builds 1 - fg
+            bg2 = bg.reshape(bg.shape[-2], bg.shape[-1]).float().contiguous()
+        bank = self.cls_unit.build_bank(tok, C, g, g, fg2, pool_w, FG_THRESH, force_mode=-1, bank=None, bg_mask=bg2)
+        self._sup_key = (supp, fg, bg, pool_w, (supp._version, fg._version))
+        self._sup_bank, self._sup_tokens = bank, tok
+        return bank, tok
+
+    def forward(self, supp_imgs, fore_mask, back_mask, qry_imgs, isval, val_wsize, show_viz=False, supp_fts=None):
+        n_ways, n_shots, n_queries = len(supp_imgs), len(supp_imgs[0]), len(qry_imgs)
+        assert n_ways == 1, "Multi-shot has not been implemented yet"
+        assert n_queries == 1
+        if n_shots != 1 or supp_imgs[0][0].shape[0] != 1:
+            raise NotImplementedError("one support shot per call (validation_protosam.py:346-362)")
+        if supp_fts is not None:
+            raise NotImplementedError("supp_fts is unusable in the reference as well (SURVEY Q18)")
+        supp, fg, bg, qry = supp_imgs[0][0], fore_mask[0][0], back_mask[0][0], qry_imgs[0]
+        img_size = supp.shape[-2:]
+        S, g = self._grid()
+        C = self.encoder.embed_dim
+        R = self.encoder.num_register_tokens
+        pool_w = val_wsize if (isval and val_wsize is not None) else self.cls_unit.kernel_size[0]
+        bank, sup_tok = self._support_bank(supp, fg, bg, pool_w)
+        qt = self.encoder.forward_tokens(qry.float(), S)          # [B, N, C]
+        B, N, _ = qt.shape
+        qry_tok = qt[:, 1 + R:]
+        pred = self.cls_unit.scores_token_major(qry_tok, N * C, C, B, g * g, bank)   # [B, 2, g*g]
+        self._check_bank(bank)
+        output = ops.bilinear_nchw(pred.view(B, 2, g, g), img_size[0], img_size[1])   # :272-273
+        supp_view = sup_tok.reshape(1, 1, 1, g, g, C).permute(0, 1, 2, 5, 3, 4)
+        qry_view = qry_tok.reshape(1, B, g, g, C).permute(0, 1, 4, 2, 3)
+        return output, 0.0, [None, None], None, None, supp_view, qry_view
+
+    def _check_bank(self, bank):
+        """The reference raises inside F.conv2d when a bank is empty (alpmodule.py:193-196). One 8-int D2H read."""
+        if self.config.get("skip_bank_check", False):
+            return
+        if bank.__dict__.get("_checked"):
+            return
+        m = bank.meta.cpu()
+        if int(m[ops.META_NBG]) == 0:
+            print("failed to find prototypes")
+            raise RuntimeError("no background prototype passed the 0.95 coverage threshold")
+        bank._checked = True

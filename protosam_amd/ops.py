@@ -95,3 +95,123 @@ def relpos(qkv, Rh, Rw, B, N, H, hd, gw, K, windowed, rel_h=None, rel_w=None):
                                1 if windowed else 0, _stream())
     _lib.check(st, "psam_relpos")
     return rel_h, rel_w
+
+
+# ---- ALP -----------------------------------------------------------------------------------------------
+META_NBG, META_NFG, META_FGMODE, META_NCELL_FG = 0, 1, 2, 3
+
+
+class AlpBank:
+    """Fixed-capacity prototype bank + device-side counts (see csrc/alp.hip)."""
+
+    def __init__(self, ncell, C, device):
+        self.cap = ncell + 1
+        self.C = C
+        self.bank = torch.zeros((2 * self.cap, C), dtype=torch.float32, device=device)
+        self.meta = torch.zeros(8, dtype=torch.int32, device=device)
+        self.slot_bg = torch.empty(ncell, dtype=torch.int32, device=device)
+        self.slot_fg = torch.empty(ncell, dtype=torch.int32, device=device)
+        self.mres = None
+
+
+def alp_bank(sup, ld, h, w, C, mask, pool_w, kernel_size, thresh=0.95, eps=1e-4, bank=None, force_mode=-1, bmask=None):
+    """sup: fp32 token-major support features (row stride ld); mask fp32 [MH,MW] foreground mask."""
+    _req(sup, torch.float32, "sup"); _req(mask, torch.float32, "mask")
+    assert mask.dim() == 2 and mask.is_contiguous()
+    ncell = (h // pool_w) * (w // pool_w)
+    if bank is None:
+        bank = AlpBank(ncell, C, sup.device)
+    if bank.mres is None or bank.mres.numel() != 2 * h * w:
+        bank.mres = torch.empty(2 * h * w, dtype=torch.float32, device=sup.device)
+    if bmask is not None:
+        _req(bmask, torch.float32, "bmask")
+        assert bmask.shape == mask.shape and bmask.is_contiguous()
+    st = _lib.lib().psam_alp_bank(_ptr(sup), ld, h, w, C, _ptr(mask), _ptr(bmask), mask.shape[0], mask.shape[1], pool_w,
+                                 kernel_size,
+                                 float(thresh), float(eps), _ptr(bank.bank), bank.cap, _ptr(bank.meta),
+                                 _ptr(bank.slot_bg), _ptr(bank.slot_fg), _ptr(bank.mres), force_mode, _stream())
+    _lib.check(st, "psam_alp_bank")
+    return bank
+
+
+def alp_sim(qry, q_bstride, ld, B, npix, C, bank, pred=None, part=None, eps=1e-4, sim_scale=20.0, which_only=-1):
+    """qry fp32 token-major [B][npix, C] -> pred fp32 [B, 2, npix] (bg, fg)."""
+    _req(qry, torch.float32, "qry")
+    npt = (bank.cap + 63) // 64
+    npix_pad = (npix + 63) // 64 * 64
+    if part is None:
+        part = torch.empty(2 * B * npt * npix_pad * 3, dtype=torch.float32, device=qry.device)
+    if pred is None:
+        pred = torch.empty((B, 2, npix), dtype=torch.float32, device=qry.device)
+    st = _lib.lib().psam_alp_sim(_ptr(qry), q_bstride, ld, B, npix, C, _ptr(bank.bank), bank.cap, _ptr(bank.meta),
+                                float(eps), float(sim_scale), _ptr(part), _ptr(pred), which_only, _stream())
+    _lib.check(st, "psam_alp_sim")
+    return pred
+
+
+# ---- resampling / packing ---------------------------------------------------------------------------------
+def patchify_bilinear(img, S, P, Kpad, out=None):
+    _req(img, torch.float32, "img")
+    assert img.is_contiguous() and img.dim() == 4
+    B, C, H, W = img.shape
+    if out is None:
+        out = torch.empty((B * (S // P) ** 2, Kpad), dtype=torch.float16, device=img.device)
+    st = _lib.lib().psam_patchify_bilinear(_ptr(img), B, C, H, W, S, P, Kpad, _ptr(out), _stream())
+    _lib.check(st, "psam_patchify_bilinear")
+    return out
+
+
+def bilinear_nchw(x, OH, OW, out=None):
+    _req(x, torch.float32, "x")
+    assert x.is_contiguous()
+    planes = x.numel() // (x.shape[-1] * x.shape[-2])
+    if out is None:
+        out = torch.empty(tuple(x.shape[:-2]) + (OH, OW), dtype=torch.float32, device=x.device)
+    st = _lib.lib().psam_bilinear_nchw(_ptr(x), planes, x.shape[-2], x.shape[-1], OH, OW, _ptr(out), _stream())
+    _lib.check(st, "psam_bilinear_nchw")
+    return out
+
+
+def prob_argmax(logits, OH, OW, prob=None, pred=None, fg_sum=None):
+    _req(logits, torch.float32, "logits")
+    assert logits.is_contiguous() and logits.dim() == 4 and logits.shape[1] == 2
+    B = logits.shape[0]
+    if prob is None:
+        prob = torch.empty((B, 2, OH, OW), dtype=torch.float32, device=logits.device)
+    if pred is None:
+        pred = torch.empty((B, OH, OW), dtype=torch.uint8, device=logits.device)
+    st = _lib.lib().psam_prob_argmax(_ptr(logits), B, logits.shape[2], logits.shape[3], OH, OW, _ptr(prob), _ptr(pred),
+                                    _ptr(fg_sum), _stream())
+    _lib.check(st, "psam_prob_argmax")
+    return prob, pred
+
+
+def broadcast_rows(row, out, B, stride, off):
+    _req(row, torch.float32, "row"); _req(out, torch.float32, "out")
+    st = _lib.lib().psam_broadcast_rows(_ptr(row), row.numel(), _ptr(out), B, stride, off, _stream())
+    _lib.check(st, "psam_broadcast_rows")
+
+
+def minmax(x, B, mm=None):
+    _req(x, torch.float32, "x")
+    assert x.is_contiguous()
+    if mm is None:
+        mm = torch.empty(2 * B, dtype=torch.int32, device=x.device)
+    st = _lib.lib().psam_minmax(_ptr(x), B, x.numel() // B, _ptr(mm), _stream())
+    _lib.check(st, "psam_minmax")
+    return mm
+
+
+def sam_patchify(img, mm, S, P, mean3, std3, quantise=True, out=None, u8out=None):
+    import ctypes
+    _req(img, torch.float32, "img")
+    assert img.is_contiguous() and img.shape[-1] == S and img.shape[-2] == S
+    B = img.shape[0]
+    if out is None:
+        out = torch.empty((B * (S // P) ** 2, 3 * P * P), dtype=torch.float16, device=img.device)
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean3])
+    s = (ctypes.c_float * 3)(*[float(v) for v in std3])
+    st = _lib.lib().psam_sam_patchify(_ptr(img), _ptr(mm), B, S, P, m, s, 1 if quantise else 0, _ptr(out), _ptr(u8out),
+                                     _stream())
+    _lib.check(st, "psam_sam_patchify")
+    return out

@@ -1,0 +1,114 @@
+"""Seeded synthetic weights and inputs (no checkpoints or datasets exist offline).
+
+Weights: every parameter/buffer is filled from a CPU generator seeded by (seed, crc32(name)) so the same
+state dict is reproduced on any machine and in any construction order, then handed both to the product
+modules (`load_state_dict`) and to the oracle. Scales are chosen so every term of the arithmetic is
+exercised (non-zero rel-pos tables, pos-embeds, biases, LayerScale) with O(1) activations.
+"""
+import math
+import zlib
+
+import numpy as np
+import torch
+
+
+_EMBEDDING_TABLES = ("iou_token", "mask_tokens", "point_embeddings", "not_a_point_embed", "no_mask_embed")
+
+
+def _gen(seed, name):
+    g = torch.Generator()
+    g.manual_seed((int(seed) * 1000003 + zlib.crc32(name.encode())) % (2 ** 63 - 1))
+    return g
+
+
+def synth_tensor(name, shape, seed):
+    g = _gen(seed, name)
+    shape = tuple(shape)
+    last = name.rsplit(".", 1)[-1]
+    n = lambda s: torch.randn(shape, generator=g) * s  # noqa: E731
+    if "rel_pos" in last:
+        return n(0.1)
+    if last in ("pos_embed", "cls_token", "register_tokens"):
+        return n(0.5)
+    if last == "mask_token":
+        return n(0.02)
+    if last == "gamma":
+        return torch.rand(shape, generator=g) * 0.5 + 0.5
+    if last == "positional_encoding_gaussian_matrix":
+        return n(1.0)
+    if last == "bias":
+        return n(0.1)
+    if last == "weight":
+        if len(shape) == 1:
+            return 1.0 + n(0.1)  # norm scales
+        if any(k in name for k in _EMBEDDING_TABLES):
+            return n(1.0)  # nn.Embedding default init
+        fan_in = int(np.prod(shape[1:]))
+        if "output_upscaling" in name:  # ConvTranspose2d weight is [in, out, kh, kw]
+            fan_in = shape[0]
+        return n(1.0 / math.sqrt(fan_in))
+    return n(0.1)
+
+
+def synth_state_dict(module, seed=1234):
+    """A full state dict for `module` (parameters and persistent buffers), fp32 on CPU."""
+    sd = {}
+    for k, v in module.state_dict().items():
+        sd[k] = synth_tensor(k, v.shape, seed).to(torch.float32)
+    return sd
+
+
+# ---- synthetic slices / volumes ---------------------------------------------------------------
+def _smooth_field(size, seed, n_blobs=12):
+    rng = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float32) / size
+    f = np.zeros((size, size), np.float32)
+    for _ in range(n_blobs):
+        cy, cx = rng.uniform(0.1, 0.9, 2)
+        s = rng.uniform(0.05, 0.25)
+        a = rng.uniform(-1.0, 1.0)
+        f += a * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * s * s))
+    return f
+
+
+def ellipse_mask(size, cy, cx, ry, rx):
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float32) / size
+    return (((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0).astype(np.float32)
+
+
+def synth_pair(size=512, seed=0):
+    """One support/query pair: smooth background field + a bright elliptical 'organ' (slightly moved in the
+    query), tiled x3 and z-scored like MR_normalize (dataloaders/dataset_utils.py:101-102,
+    ManualAnnoDatasetv2.py:326-327). Returns support [1,3,S,S], fg mask [1,S,S], query [1,3,S,S], query gt."""
+    rng = np.random.RandomState(seed + 77)
+    out = []
+    for j in range(2):
+        cy, cx = 0.5 + 0.04 * j, 0.47 + 0.05 * j
+        ry, rx = 0.17 - 0.01 * j, 0.22 + 0.01 * j
+        m = ellipse_mask(size, cy, cx, ry, rx)
+        img = 0.6 * _smooth_field(size, seed + j) + 1.5 * m + 0.05 * rng.randn(size, size).astype(np.float32)
+        img = (img - img.mean()) / img.std()
+        out.append((torch.from_numpy(np.repeat(img[None, None], 3, axis=1).astype(np.float32)),
+                    torch.from_numpy(m[None])))
+    (s_img, s_m), (q_img, q_m) = out
+    return s_img, s_m, q_img, q_m
+
+
+def synth_volume(n_slices=32, size=512, seed=0, kind="mri"):
+    """[n,S,S] volume with an ellipsoid organ whose cross-section varies with z, + labels [n,S,S]."""
+    rng = np.random.RandomState(seed + 991)
+    base = _smooth_field(size, seed)
+    vol = np.zeros((n_slices, size, size), np.float32)
+    lab = np.zeros((n_slices, size, size), np.float32)
+    for z in range(n_slices):
+        t = (z + 0.5) / n_slices
+        r = math.sqrt(max(1e-3, 1.0 - (2 * t - 1) ** 2 * 0.8))
+        m = ellipse_mask(size, 0.5 + 0.03 * math.sin(6.0 * t), 0.48 + 0.04 * t, 0.16 * r, 0.21 * r)
+        noise = rng.randn(size, size).astype(np.float32)
+        if kind == "ct":
+            img = -300.0 + 400.0 * base + 350.0 * m + 20.0 * noise
+        else:
+            img = np.abs(0.6 * base + 1.5 * m + 0.05 * noise + 0.8)
+        vol[z], lab[z] = img, m
+    vol = (vol - vol.mean()) / vol.std()
+    return torch.from_numpy(vol), torch.from_numpy(lab)

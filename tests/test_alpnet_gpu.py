@@ -1,0 +1,128 @@
+"""GPU parity of the coarse segmenter (DINOv2 encoder + ALP prototype matching) against the CPU oracle."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CFG = {"which_model": "dinov2_b14", "cls_name": "grid_proto", "proto_grid_size": 8, "lora": 0, "align": False,
+       "debug": False}
+
+
+def _model(dev, depth=None, size=512, seed=1234):
+    from protosam_amd.grid_proto_fewshot import FewShotSeg
+    from protosam_amd.synth import synth_state_dict
+    cfg = dict(CFG)
+    if depth is not None:
+        cfg["encoder_depth"] = depth
+    m = FewShotSeg(size, None, cfg)
+    sd = synth_state_dict(m, seed)
+    m.load_state_dict(sd, strict=True)
+    return m.to(dev).eval(), sd
+
+
+@pytest.mark.parametrize("depth", [1, 12])
+def test_dinov2_patch_tokens(dev, depth):
+    from oracle import dinov2 as odino
+    from protosam_amd.synth import synth_pair
+    m, sd = _model(dev, depth)
+    s_img, _, q_img, _ = synth_pair(504, seed=3)
+    x = torch.cat([s_img, q_img], 0)
+    enc_sd = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+    ref = odino.forward_features(x, enc_sd, "dinov2_b14", depth=depth)["x_norm_patchtokens"]
+    out = m.encoder.forward_features(x.to(dev))["x_norm_patchtokens"].cpu()
+    err = (out - ref).abs()
+    print(f"dinov2 depth={depth}: max abs err {err.max():.3e}, mean {err.mean():.3e}, ref rms {ref.pow(2).mean().sqrt():.3f}")
+    assert err.max() < 3e-2 and err.mean() < 2e-3
+
+
+@pytest.mark.parametrize("hw,cover", [(36, "big"), (36, "small"), (36, "tiny"), (73, "big")])
+def test_alp_bank_and_scores(dev, hw, cover):
+    """fp32 stage: bank rows, counts, fg mode and the score maps against oracle/alp.py."""
+    from oracle import alp as oalp
+    from protosam_amd.alpmodule import MultiProtoAsConv
+    from protosam_amd import ops
+    from protosam_amd.synth import ellipse_mask
+    C, S = 768, 512
+    g = torch.Generator().manual_seed(hw)
+    sup = torch.randn((hw * hw, C), generator=g)
+    qry = torch.randn((2, hw * hw, C), generator=g) + 0.3 * sup[None]
+    r = {"big": (0.25, 0.3), "small": (0.09, 0.1), "tiny": (0.03, 0.03)}[cover]
+    fg = torch.from_numpy(ellipse_mask(S, 0.5, 0.45, *r))[None]  # [1,S,S]
+    ks = hw // 8
+    unit = MultiProtoAsConv([8, 8], [hw, hw], embed_dim=C)
+    bank = unit.build_bank(sup.to(dev), C, hw, hw, fg[0].to(dev).contiguous(), 2)
+    pred = unit.scores_token_major(qry.to(dev), hw * hw * C, C, 2, hw * hw, bank).cpu()
+    meta = bank.meta.cpu()
+    sup_map = sup.t().reshape(1, C, hw, hw)
+    for b in range(2):
+        taps = {}
+        ref = oalp.fewshot_scores(qry[b].t().reshape(1, C, hw, hw), sup_map, fg, ks, 2, taps)
+        if b == 0:
+            assert int(meta[ops.META_NBG]) == taps["bg_protos"].shape[0]
+            assert int(meta[ops.META_NFG]) == taps["fg_protos"].shape[0]
+            assert int(meta[ops.META_FGMODE]) == (1 if taps["fg_mode"] == "gridconv+" else 0)
+            nb, nf = taps["bg_protos"].shape[0], taps["fg_protos"].shape[0]
+            torch.testing.assert_close(bank.bank[:nb].cpu(), taps["bg_protos"], rtol=1e-5, atol=1e-6)
+            fgp = taps["fg_protos"] if taps["fg_mode"] == "gridconv+" else oalp.safe_norm(taps["fg_protos"])
+            torch.testing.assert_close(bank.bank[bank.cap:bank.cap + nf].cpu(), fgp, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(pred[b].view(1, 2, hw, hw), ref, rtol=1e-4, atol=2e-4)
+
+
+def test_alp_module_reference_api(dev):
+    """MultiProtoAsConv.forward with the reference's NCHW arguments, all three modes + the bad-mode error."""
+    from oracle import alp as oalp
+    from protosam_amd.alpmodule import MultiProtoAsConv
+    C, hw = 256, 32
+    g = torch.Generator().manual_seed(5)
+    qry = torch.randn((1, 1, C, hw, hw), generator=g)
+    sup = torch.randn((1, 1, 1, C, hw, hw), generator=g)
+    msk = torch.zeros((1, 1, 1, hw, hw))
+    msk[..., 8:20, 6:22] = 1
+    unit = MultiProtoAsConv([8, 8], [hw, hw], embed_dim=C)
+    for mode in ("mask", "gridconv", "gridconv+"):
+        out = unit(qry.to(dev), sup.to(dev), msk.to(dev), mode, 0.95, isval=True, val_wsize=2)[0].cpu()
+        ref, _ = oalp.cls_unit(qry[0], sup[0, 0], msk[0], mode, 0.95, 2)
+        torch.testing.assert_close(out, ref, rtol=1e-4, atol=2e-4)
+    with pytest.raises(ValueError):
+        unit(qry.to(dev), sup.to(dev), msk.to(dev), "grid", 0.95, isval=True, val_wsize=2)
+
+
+def test_bilinear_and_prob_argmax(dev):
+    from protosam_amd import ops
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn((1, 2, 36, 36), generator=g) * 5
+    up = ops.bilinear_nchw(x.to(dev), 512, 512)
+    ref = F.interpolate(x, size=(512, 512), mode="bilinear")
+    torch.testing.assert_close(up.cpu(), ref, rtol=1e-5, atol=1e-5)
+    fg_sum = torch.zeros(1, dtype=torch.int32, device=dev)
+    prob, pred = ops.prob_argmax(up, 1024, 1024, fg_sum=fg_sum)
+    ref2 = F.interpolate(ref, size=(1024, 1024), mode="bilinear").softmax(dim=1)
+    torch.testing.assert_close(prob.cpu(), ref2, rtol=1e-5, atol=1e-6)
+    rp = ref2.argmax(dim=1)
+    mism = (pred.cpu().long() != rp).sum().item()
+    assert mism <= 4, mism  # only exact ties / 1-ulp flips may differ
+    assert abs(int(fg_sum.item()) - int(rp.sum())) <= 4
+
+
+@pytest.mark.parametrize("depth", [12])
+def test_fewshot_forward_probability_map(dev, depth):
+    """North-star tolerance: coarse probability map within 1e-3 of the fp32 reference path."""
+    from oracle import alp as oalp, dinov2 as odino
+    from protosam_amd.synth import synth_pair
+    m, sd = _model(dev, depth)
+    s_img, s_m, q_img, _ = synth_pair(512, seed=0)
+    enc_sd = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+    enc = lambda im: odino.forward_features(im, enc_sd, "dinov2_b14", depth=depth)["x_norm_patchtokens"]  # noqa: E731
+    ref = oalp.fewshot_forward(enc, s_img, s_m, q_img, 512)
+    out = m([[s_img.to(dev)]], [[s_m.to(dev)]], [[(1 - s_m).to(dev)]], [q_img.to(dev)], True, 2)
+    logits = out[0].cpu()
+    assert logits.shape == (1, 2, 512, 512)
+    assert out[5].shape == (1, 1, 1, 768, 36, 36) and out[6].shape == (1, 1, 768, 36, 36)
+    perr = (logits.softmax(1) - ref.softmax(1)).abs().max().item()
+    lerr = (logits - ref).abs().max().item()
+    print(f"fewshot depth={depth}: max |dlogit| {lerr:.3e}, max |dprob| {perr:.3e}, fg frac {ref.argmax(1).float().mean():.3f}")
+    assert perr < 1e-3
+    # second call hits the support cache and must give the same answer
+    out2 = m([[s_img.to(dev)]], [[s_m.to(dev)]], [[(1 - s_m).to(dev)]], [q_img.to(dev)], True, 2)
+    assert torch.equal(out2[0].cpu(), logits)
