@@ -1,0 +1,280 @@
+"""Pins the oracle against the real reference (runs ONLY in the build container, where /root/reference exists).
+
+  python oracle/validate_against_reference.py [--write-golden]
+
+1. imports the reference's own modules from /root/reference behind four small shims: stub
+   `torchvision` / `cv2` / `kneed`, put `/root/reference/models` on sys.path so `import segment_anything`
+   resolves to the vendored copy, make `Tensor.cuda()` the identity, and route `torch.hub.load` to an adapter
+   around oracle/dinov2.py (DINOv2 itself is not in the reference tree);
+2. runs reference and oracle on the same seeded inputs and asserts agreement (<= 1e-5 unless noted);
+3. with --write-golden, stores the REFERENCE outputs (never oracle outputs) as small fixtures under
+   tests/golden/, which `tests/test_oracle_golden.py` replays on any machine without the reference.
+
+Nothing here is imported by the product or by the GPU tests.
+"""
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+GOLD = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+
+def install_shims():
+    import transformers  # noqa: F401  (must be imported before the torchvision stub exists)
+    from transformers import Dinov2Config, Dinov2Model  # noqa: F401
+
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    tv = stub("torchvision")
+    tv.models = stub("torchvision.models")
+    tv.models.segmentation = stub("torchvision.models.segmentation")
+    tv.transforms = stub("torchvision.transforms")
+    tv.transforms.functional = stub("torchvision.transforms.functional", resize=None, to_pil_image=None, rotate=None,
+                                    InterpolationMode=types.SimpleNamespace(BILINEAR=2, NEAREST=0))
+    tv.ops = stub("torchvision.ops")
+    tv.ops.boxes = stub("torchvision.ops.boxes", batched_nms=None, box_area=None)
+    stub("cv2")
+    stub("kneed")
+    sys.path.insert(0, os.path.join(REF, "models"))
+    sys.path.insert(0, REF)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+
+
+def close(a, b, tol, what):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    err = (a - b).abs().max().item() if a.numel() else 0.0
+    status = "ok" if err <= tol else "FAIL"
+    print(f"  [{status}] {what}: max abs diff {err:.3e} (tol {tol:.0e})")
+    if err > tol:
+        raise SystemExit(f"oracle disagrees with the reference at: {what}")
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def check_alp(gold):
+    from models.alpmodule import MultiProtoAsConv  # reference
+    from oracle import alp as oalp
+    print("ALP module (models/alpmodule.py)")
+    from oracle import golden_inputs as gi
+    qry, sup, msk = gi.alp_case()
+    C, hw = qry.shape[2], qry.shape[-1]
+    ref_unit = MultiProtoAsConv(proto_grid=[8, 8], feature_hw=[hw, hw], embed_dim=C)
+    for mode in ("mask", "gridconv", "gridconv+"):
+        ref = ref_unit(qry, sup, msk, mode, 0.95, isval=True, val_wsize=2)[0]
+        out, _ = oalp.cls_unit(qry[0], sup[0, 0], msk[0], mode, 0.95, 2)
+        close(out, ref, 1e-5, f"mode={mode}")
+        gold[f"alp_{mode}"] = ref.numpy()
+
+
+class _HubAdapter(torch.nn.Module):
+    """What `torch.hub.load('facebookresearch/dinov2', ...)` is replaced with: oracle DINOv2 over a seeded state dict."""
+
+    def __init__(self, which, sd, depth):
+        super().__init__()
+        self.which, self.sd, self.depth = which, sd, depth
+
+    def forward_features(self, x):
+        from oracle import dinov2 as odino
+        return odino.forward_features(x, self.sd, self.which, depth=self.depth)
+
+
+def check_fewshot(gold):
+    from oracle import alp as oalp, dinov2 as odino
+    from oracle import golden_inputs as gi
+    print("FewShotSeg.forward (models/grid_proto_fewshot.py) with the hub encoder replaced by oracle/dinov2.py")
+    depth = gi.FEWSHOT_DEPTH
+    enc_sd = gi.fewshot_encoder_sd()
+    torch.hub.load = lambda repo, name, **k: _HubAdapter("dinov2_b14", enc_sd, depth)
+    from models.grid_proto_fewshot import FewShotSeg  # reference
+    for size in gi.FEWSHOT_SIZES:
+        cfg = {"which_model": "dinov2_b14", "cls_name": "grid_proto", "proto_grid_size": 8, "lora": 0, "align": False,
+               "debug": False, "use_coco_init": False}
+        ref_model = FewShotSeg(size, None, cfg).eval()
+        s_img, s_m, q_img, _ = gi.fewshot_pair(size)
+        with torch.no_grad():
+            ref = ref_model([[s_img]], [[s_m]], [[1 - s_m]], [q_img], True, 2)[0]
+        enc = lambda im: odino.forward_features(im, enc_sd, "dinov2_b14", depth=depth)["x_norm_patchtokens"]  # noqa
+        out = oalp.fewshot_forward(enc, s_img, s_m, q_img, size)
+        close(out, ref, 1e-4, f"logits image_size={size} (|logit| <= 20)")
+        gold[f"fewshot_logits_{size}"] = ref.numpy().astype(np.float32)
+
+
+def check_dinov2_vs_transformers():
+    """Independent implementation cross-check (the hub code itself is unavailable => 'parity unpinned')."""
+    from transformers import Dinov2Config, Dinov2Model
+    from oracle import dinov2 as odino
+    from protosam_amd.dinov2 import DinoVisionTransformer
+    from protosam_amd.synth import synth_state_dict
+    print("DINOv2 restatement vs transformers.Dinov2Model (518x518: no pos-embed interpolation)")
+    depth = 2
+    sd = synth_state_dict(DinoVisionTransformer("dinov2_vitb14", depth=depth), 7)
+    cfg = Dinov2Config(hidden_size=768, num_hidden_layers=depth, num_attention_heads=12, mlp_ratio=4, image_size=518,
+                       patch_size=14, layer_norm_eps=1e-6, layerscale_value=1.0, use_swiglu_ffn=False, qkv_bias=True,
+                       attention_probs_dropout_prob=0.0, hidden_dropout_prob=0.0, hidden_act="gelu")
+    hf = Dinov2Model(cfg).eval()
+    m = {}
+    m["embeddings.cls_token"] = sd["cls_token"]
+    m["embeddings.mask_token"] = sd["mask_token"]
+    m["embeddings.position_embeddings"] = sd["pos_embed"]
+    m["embeddings.patch_embeddings.projection.weight"] = sd["patch_embed.proj.weight"]
+    m["embeddings.patch_embeddings.projection.bias"] = sd["patch_embed.proj.bias"]
+    D = 768
+    for i in range(depth):
+        p, q = f"blocks.{i}.", f"encoder.layer.{i}."
+        W, b = sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"]
+        for j, nm in enumerate(("query", "key", "value")):
+            m[q + f"attention.attention.{nm}.weight"] = W[j * D:(j + 1) * D]
+            m[q + f"attention.attention.{nm}.bias"] = b[j * D:(j + 1) * D]
+        m[q + "attention.output.dense.weight"] = sd[p + "attn.proj.weight"]
+        m[q + "attention.output.dense.bias"] = sd[p + "attn.proj.bias"]
+        m[q + "norm1.weight"], m[q + "norm1.bias"] = sd[p + "norm1.weight"], sd[p + "norm1.bias"]
+        m[q + "norm2.weight"], m[q + "norm2.bias"] = sd[p + "norm2.weight"], sd[p + "norm2.bias"]
+        m[q + "layer_scale1.lambda1"] = sd[p + "ls1.gamma"]
+        m[q + "layer_scale2.lambda1"] = sd[p + "ls2.gamma"]
+        m[q + "mlp.fc1.weight"], m[q + "mlp.fc1.bias"] = sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"]
+        m[q + "mlp.fc2.weight"], m[q + "mlp.fc2.bias"] = sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"]
+    m["layernorm.weight"], m["layernorm.bias"] = sd["norm.weight"], sd["norm.bias"]
+    missing, unexpected = hf.load_state_dict(m, strict=False)
+    assert not unexpected, unexpected
+    assert all("mask_token" in k for k in missing), missing
+    x = torch.randn((1, 3, 518, 518), generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        ref = hf(pixel_values=x).last_hidden_state
+    out = odino.forward_features(x, sd, "dinov2_b14", depth=depth)
+    close(out["x_norm_patchtokens"], ref[:, 1:], 2e-5, "x_norm_patchtokens")
+    close(out["x_norm_clstoken"], ref[:, 0], 2e-5, "x_norm_clstoken")
+
+
+def _small_encoder_kwargs():
+    from functools import partial
+    from oracle import golden_inputs as gi
+    c = gi.SMALL_ENCODER
+    return dict(depth=c["depth"], embed_dim=c["embed_dim"], img_size=1024, mlp_ratio=4,
+                norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), num_heads=c["num_heads"], patch_size=16,
+                qkv_bias=True, use_rel_pos=True, global_attn_indexes=c["global_attn_indexes"], window_size=14,
+                out_chans=c["out_chans"])
+
+
+def check_sam_encoder(gold):
+    from segment_anything.modeling import ImageEncoderViT  # vendored reference
+    from oracle import sam_image_encoder as oenc
+    from protosam_amd.synth import synth_state_dict
+    print("SAM ImageEncoderViT (reduced width: 3 blocks [window, global, window], dim 64, 2 heads)")
+    ref = ImageEncoderViT(**_small_encoder_kwargs()).eval()
+    from oracle import golden_inputs as gi
+    sd = synth_state_dict(ref, gi.SMALL_ENCODER_SEED)
+    ref.load_state_dict(sd)
+    x = gi.small_encoder_input()
+    with torch.no_grad():
+        r = ref(x)
+    oenc.VIT_CFGS["tiny_test"] = {k: v for k, v in gi.SMALL_ENCODER.items() if k != "out_chans"}
+    o = oenc.image_encoder(x, sd, pre="", model_type="tiny_test")
+    close(o, r, 2e-5, "image embedding [1,32,64,64]")
+    gold["sam_encoder_small_out"] = r.numpy().astype(np.float32)
+
+
+def check_sam_decoder(gold):
+    from segment_anything import sam_model_registry  # vendored
+    from segment_anything.modeling import Sam
+    from oracle import sam_prompt_decoder as odec
+    from protosam_amd.synth import synth_state_dict
+    print("SAM PromptEncoder + MaskDecoder + postprocess (full-size decoder, vendored reference)")
+    sam = sam_model_registry["vit_b"]()  # random init, SamBatched
+    from oracle import golden_inputs as gi
+    sd_full = synth_state_dict(sam, gi.DECODER_SEED)
+    sd = {k: v for k, v in sd_full.items() if not k.startswith("image_encoder.")}
+    sam.load_state_dict(sd, strict=False)
+    feats = gi.decoder_features()
+    cases = gi.decoder_cases()
+    with torch.no_grad():
+        pe_ref = sam.prompt_encoder.get_dense_pe()
+        close(odec.dense_pe(sd), pe_ref, 1e-5, "get_dense_pe")
+        for name, (pc, pl, bx) in cases.items():
+            pts = (pc, pl) if pc is not None else None
+            sp_r, de_r = sam.prompt_encoder(points=pts, boxes=bx, masks=None)
+            sp_o, de_o = odec.prompt_encoder(sd, pts, bx)
+            close(sp_o, sp_r, 1e-5, f"{name}: sparse embeddings")
+            close(de_o, de_r, 1e-6, f"{name}: dense embeddings")
+            for mm in (True, False):
+                low_r, iou_r = sam.mask_decoder(image_embeddings=feats, image_pe=pe_ref, sparse_prompt_embeddings=sp_r,
+                                                dense_prompt_embeddings=de_r, multimask_output=mm)
+                low_o, iou_o = odec.mask_decoder(sd, feats, odec.dense_pe(sd), sp_o, de_o, mm)
+                close(low_o, low_r, 2e-4, f"{name}: low_res_masks multimask={mm}")
+                close(iou_o, iou_r, 2e-5, f"{name}: iou_predictions multimask={mm}")
+                if mm:
+                    gold[f"dec_{name}_low_res"] = low_r.numpy().astype(np.float32)
+                    gold[f"dec_{name}_iou"] = iou_r.numpy().astype(np.float32)
+        low = low_r
+        r_b = sam.postprocess_masks(low, (1024, 1024), (1024, 1024))           # SamBatched: align_corners=True
+        close(odec.postprocess_masks(low, (1024, 1024), (1024, 1024), "batched"), r_b, 1e-5, "postprocess SamBatched")
+        r_n = Sam.postprocess_masks(sam, low, (1024, 1024), (512, 512))        # vendored Sam: nearest
+        close(odec.postprocess_masks(low, (1024, 1024), (512, 512), "nearest"), r_n, 0, "postprocess Sam(nearest)")
+        gold["post_batched_row"] = r_b[0, 0, 511].numpy().astype(np.float32)
+    # ResizeLongestSide coordinate maps
+    from segment_anything.utils.transforms import ResizeLongestSide
+    tr = ResizeLongestSide(1024)
+    pts = np.array([[10.0, 20.0], [511.0, 300.5]])
+    close(odec.apply_coords(pts, (512, 512)), tr.apply_coords(pts, (512, 512)), 0, "ResizeLongestSide.apply_coords")
+    close(odec.apply_coords(pts, (600, 900)), tr.apply_coords(pts, (600, 900)), 0, "apply_coords non-square")
+
+
+def check_glue(gold):
+    from oracle import glue
+    import scipy.ndimage as ndi
+    print("connected components / prompt extraction (cv2 absent: cross-check against scipy.ndimage)")
+    rng = np.random.RandomState(5)
+    for trial in range(4):
+        img = (ndi.gaussian_filter(rng.randn(96, 128), 3 + trial) > 0.02).astype(np.uint8)
+        n, labels, stats, cent = glue.connected_components_with_stats(img)
+        lab2, n2 = ndi.label(img, structure=np.ones((3, 3)))
+        assert n == n2 + 1, (n, n2)
+        # same partition (label numbering may differ): map through first pixel
+        for j in range(1, n):
+            ys, xs = np.nonzero(labels == j)
+            l2 = lab2[ys[0], xs[0]]
+            assert np.array_equal(labels == j, lab2 == l2)
+            com = ndi.center_of_mass(img, lab2, l2)
+            close(cent[j], np.array([com[1], com[0]]), 1e-9, f"trial {trial} centroid {j}") if j == 1 else None
+            assert stats[j, 4] == (lab2 == l2).sum()
+    # reference util functions that do not need cv2
+    from util.utils import get_confidence_from_logits
+    lg = torch.randn((1, 2, 40, 40), generator=torch.Generator().manual_seed(2)) * 3
+    close(glue.confidence_from_logits(lg), get_confidence_from_logits(lg), 1e-6, "get_confidence_from_logits")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--write-golden", action="store_true")
+    args = ap.parse_args()
+    if not os.path.isdir(REF):
+        raise SystemExit("/root/reference not present: this script only runs in the build container")
+    install_shims()
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    gold = {}
+    check_alp(gold)
+    check_fewshot(gold)
+    check_dinov2_vs_transformers()
+    check_sam_encoder(gold)
+    check_sam_decoder(gold)
+    check_glue(gold)
+    if args.write_golden:
+        os.makedirs(GOLD, exist_ok=True)
+        path = os.path.join(GOLD, "reference_outputs.npz")
+        np.savez_compressed(path, **gold)
+        print(f"wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB, {len(gold)} arrays)")
+    print("ALL CHECKS PASSED")
+
+
+if __name__ == "__main__":
+    main()

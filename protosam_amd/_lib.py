@@ -32,6 +32,19 @@ SIGNATURES = {
     "psam_prob_argmax": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "psam_broadcast_rows": [c_void_p, c_int, c_void_p, c_int, c_longlong, c_longlong, c_void_p],
     "psam_minmax": [c_void_p, c_int, c_longlong, c_void_p, c_void_p],
+    "psam_im2col3x3": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "psam_cast_f16": [c_void_p, c_void_p, c_longlong, c_void_p],
+    "psam_small_linear": [c_void_p] * 6 + [c_int] * 4 + [c_longlong] * 4 + [c_int] * 3 + [c_void_p],
+    "psam_small_attention": [c_void_p] * 4 + [c_int] * 10 + [c_void_p],
+    "psam_t2i_attention": [c_void_p] * 4 + [c_int] * 4 + [c_void_p],
+    "psam_ln_pe": [c_void_p] * 8 + [c_int, c_int, c_int, c_float, c_int, c_void_p],
+    "psam_dense_pe": [c_void_p, c_int, c_int, c_void_p, c_void_p],
+    "psam_prompt_tokens": [c_void_p] * 5 + [c_int, c_int, c_float, c_void_p, c_void_p],
+    "psam_upscale_tail": [c_void_p] * 7 + [c_int, c_int, c_void_p],
+    "psam_mask_upsample": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "psam_mask_union": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p],
+    "psam_normalize_chw": [c_void_p, c_int, c_int, c_longlong, ctypes.POINTER(c_float), ctypes.POINTER(c_float),
+                           c_void_p, c_void_p],
     "psam_sam_patchify": [c_void_p, c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_float), ctypes.POINTER(c_float),
                           c_int, c_void_p, c_void_p, c_void_p],
 }

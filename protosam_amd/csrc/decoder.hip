@@ -1,0 +1,510 @@
+// SAM prompt encoder + two-way mask decoder kernels (token side in fp32; the 4096-token image side uses the
+// fp16/fp32-acc GEMM of gemm.hip for its projections and the kernels below for everything else).
+//
+// Replaces models/segment_anything/modeling/prompt_encoder.py (PositionEmbeddingRandom :171-214, _embed_points
+// :73-92, _embed_boxes :94-101, get_dense_pe :62-71), modeling/transformer.py (Attention :185-240,
+// TwoWayAttentionBlock :109-182, TwoWayTransformer :16-106), modeling/mask_decoder.py (predict_masks :112-149,
+// MLP :154-176) and the mask post-processing of modeling/sam.py (:133-161, :292-321) / models/ProtoSAM.py:669-676.
+#include "common.h"
+
+// =====================================================================================================
+// small_linear: y[g,m,n] = act(sum_k (x[g,m,k] [+ x2[g,m,k]]) W[g,n,k] + b[g,n]) (+ resid[g,m,n]);  fp32, few rows.
+// One wave per output column n: its W row sits in registers (KV = K/64 values per lane, coalesced), every x row
+// is streamed from L1/L2 and reduced with a 64-lane butterfly.
+template <int KV>
+__global__ __launch_bounds__(256) void small_linear_kernel(const float* __restrict__ x, const float* __restrict__ x2,
+                                                           const float* __restrict__ W,
+                                                           const float* __restrict__ b, const float* __restrict__ resid,
+                                                           float* __restrict__ y, int M, int N, long long xg, long long wg,
+                                                           long long bg, long long yg, int ldx, int ldy, int act) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int g = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  if (n >= N) return;
+  const float* wr = W + (size_t)g * wg + (size_t)n * (KV * 64);
+  float w[KV];
+#pragma unroll
+  for (int i = 0; i < KV; ++i) w[i] = wr[lane + 64 * i];
+  const float bias = b ? b[(size_t)g * bg + n] : 0.f;
+  for (int m = 0; m < M; ++m) {
+    const float* xr = x + (size_t)g * xg + (size_t)m * ldx;
+    float s = 0.f;
+    if (x2) {  // fused `queries + query_pe` (transformer.py:157,163,177,98)
+      const float* x2r = x2 + (size_t)g * xg + (size_t)m * ldx;
+#pragma unroll
+      for (int i = 0; i < KV; ++i) s += (xr[lane + 64 * i] + x2r[lane + 64 * i]) * w[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < KV; ++i) s += xr[lane + 64 * i] * w[i];
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+      s += bias;
+      if (act == 1) s = fmaxf(s, 0.f);
+      const size_t o = (size_t)g * yg + (size_t)m * ldy + n;
+      if (resid) s += resid[o];
+      y[o] = s;
+    }
+  }
+}
+
+extern "C" int psam_small_linear(const float* x, const float* x2, const float* W, const float* b, const float* resid,
+                                 float* y, int G,
+                                 int M, int N, int K, long long xg, long long wg, long long bg, long long yg, int ldx,
+                                 int ldy, int act, void* stream) {
+  if (G <= 0 || M <= 0 || N <= 0 || (K % 64) != 0) return PSAM_ERR_ARG;
+  dim3 grid((N + 3) / 4, G), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define SL(KV) hipLaunchKernelGGL(small_linear_kernel<KV>, grid, block, 0, s, x, x2, W, b, resid, y, M, N, xg, wg, bg, yg, ldx, ldy, act)
+  switch (K / 64) {
+    case 1: SL(1); break;
+    case 2: SL(2); break;
+    case 4: SL(4); break;
+    case 32: SL(32); break;
+    default: return PSAM_ERR_ARG;
+  }
+#undef SL
+  return psam_launch_status();
+}
+
+// =====================================================================================================
+// small_attention: softmax(q k^T / sqrt(hd)) v with <= 16 keys; one thread per (batch, query row, head).
+// Used for the token self-attention (Tq = Tk = T, hd 32) and for image->token cross attention
+// (Tq = 4096 image tokens, q fp16 from the GEMM, hd 16; transformer.py:176-180).
+template <int HD, typename QT, typename OT>
+__global__ void small_attention_kernel(const QT* __restrict__ q, const float* __restrict__ k,
+                                       const float* __restrict__ v, OT* __restrict__ out, int B, int Tq, int Tk, int NH,
+                                       int ldq, int ldk, int ldv, int ldo) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)B * Tq * NH;
+  if (idx >= total) return;
+  const int h = (int)(idx % NH);
+  const long long row = idx / NH;  // b*Tq + qi
+  const int b = (int)(row / Tq);
+  const QT* qp = q + (size_t)row * ldq + h * HD;
+  float qv[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) qv[d] = (float)qp[d];
+  const float inv = 1.0f / sqrtf((float)HD);
+  float s[16];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    s[j] = -INFINITY;
+    if (j < Tk) {
+      const float* kp = k + ((size_t)b * Tk + j) * ldk + h * HD;
+      float a = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) a += qv[d] * kp[d];
+      s[j] = a * inv;
+      mx = fmaxf(mx, s[j]);
+    }
+  }
+  float l = 0.f;
+  float o[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) o[d] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    if (j < Tk) {
+      const float p = expf(s[j] - mx);
+      l += p;
+      const float* vp = v + ((size_t)b * Tk + j) * ldv + h * HD;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) o[d] += p * vp[d];
+    }
+  }
+  OT* op = out + (size_t)row * ldo + h * HD;
+#pragma unroll
+  for (int d = 0; d < HD; ++d) op[d] = (OT)(o[d] / l);
+}
+
+// q_f16 = 1: q and out are fp16 (image side); 0: fp32.
+extern "C" int psam_small_attention(const void* q, const float* k, const float* v, void* out, int B, int Tq, int Tk,
+                                    int NH, int hd, int ldq, int ldk, int ldv, int ldo, int q_f16, void* stream) {
+  if (B <= 0 || Tq <= 0 || Tk <= 0 || Tk > 16) return PSAM_ERR_ARG;
+  const long long total = (long long)B * Tq * NH;
+  dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (hd == 16 && q_f16)
+    hipLaunchKernelGGL((small_attention_kernel<16, half_t, half_t>), grid, block, 0, s, (const half_t*)q, k, v,
+                       (half_t*)out, B, Tq, Tk, NH, ldq, ldk, ldv, ldo);
+  else if (hd == 16)
+    hipLaunchKernelGGL((small_attention_kernel<16, float, float>), grid, block, 0, s, (const float*)q, k, v,
+                       (float*)out, B, Tq, Tk, NH, ldq, ldk, ldv, ldo);
+  else if (hd == 32 && !q_f16)
+    hipLaunchKernelGGL((small_attention_kernel<32, float, float>), grid, block, 0, s, (const float*)q, k, v,
+                       (float*)out, B, Tq, Tk, NH, ldq, ldk, ldv, ldo);
+  else
+    return PSAM_ERR_ARG;
+  return psam_launch_status();
+}
+
+// =====================================================================================================
+// t2i_attention: token -> image cross attention (transformer.py:163-167, 98-103). q fp32 [B,T,NH*16];
+// K, V fp16 [B*Nk, NH*16] (outputs of the k_proj / v_proj GEMMs); out fp32 [B,T,NH*16].
+// One block per (t, head, b); 256 threads x up to 16 keys each; two passes over register-resident scores.
+__global__ __launch_bounds__(256) void t2i_attention_kernel(const float* __restrict__ q, const half_t* __restrict__ K,
+                                                            const half_t* __restrict__ V, float* __restrict__ out, int T,
+                                                            int Nk, int NH) {
+  constexpr int HD = 16;
+  const int t = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  __shared__ float red[4][HD + 1];
+  __shared__ float bmax;
+  const int C = NH * HD;
+  const float* qp = q + ((size_t)b * T + t) * C + h * HD;
+  float qv[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) qv[d] = qp[d];
+  const float inv = 1.0f / sqrtf((float)HD);
+  float s[16];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int key = tid + 256 * j;
+    s[j] = -INFINITY;
+    if (key < Nk) {
+      const half8_t* kp = reinterpret_cast<const half8_t*>(K + ((size_t)b * Nk + key) * C + h * HD);
+      half8_t k0 = kp[0], k1 = kp[1];
+      float a = 0.f;
+#pragma unroll
+      for (int d = 0; d < 8; ++d) a += qv[d] * (float)k0[d] + qv[8 + d] * (float)k1[d];
+      s[j] = a * inv;
+      mx = fmaxf(mx, s[j]);
+    }
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[wv][0] = mx;
+  __syncthreads();
+  if (tid == 0) bmax = fmaxf(fmaxf(red[0][0], red[1][0]), fmaxf(red[2][0], red[3][0]));
+  __syncthreads();
+  const float M = bmax;
+  float l = 0.f, o[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) o[d] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int key = tid + 256 * j;
+    if (key < Nk) {
+      const float p = expf(s[j] - M);
+      l += p;
+      const half8_t* vp = reinterpret_cast<const half8_t*>(V + ((size_t)b * Nk + key) * C + h * HD);
+      half8_t v0 = vp[0], v1 = vp[1];
+#pragma unroll
+      for (int d = 0; d < 8; ++d) {
+        o[d] += p * (float)v0[d];
+        o[8 + d] += p * (float)v1[d];
+      }
+    }
+  }
+  l = wave_sum(l);
+#pragma unroll
+  for (int d = 0; d < HD; ++d) o[d] = wave_sum(o[d]);
+  __syncthreads();
+  if (lane == 0) {
+    red[wv][HD] = l;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) red[wv][d] = o[d];
+  }
+  __syncthreads();
+  if (tid < HD) {
+    const float lt = red[0][HD] + red[1][HD] + red[2][HD] + red[3][HD];
+    const float ot = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    out[((size_t)b * T + t) * C + h * HD + tid] = ot / lt;
+  }
+}
+
+extern "C" int psam_t2i_attention(const float* q, const void* K, const void* V, float* out, int B, int T, int Nk, int NH,
+                                  void* stream) {
+  if (B <= 0 || T <= 0 || Nk <= 0 || Nk > 4096) return PSAM_ERR_ARG;
+  hipLaunchKernelGGL(t2i_attention_kernel, dim3(T, NH, B), dim3(256), 0, (hipStream_t)stream, q, (const half_t*)K,
+                     (const half_t*)V, out, T, Nk, NH);
+  return psam_launch_status();
+}
+
+// =====================================================================================================
+// ln_pe: image-token row op (C = 256, one wave per row):  y = [LayerNorm](x[row % in_mod] + add_vec)
+//   y32 (fp32, may alias x), y16 = fp16(y), ype16 = fp16(y + pe[row % pe_mod])
+// Serves `src = image_embeddings + dense` (mask_decoder.py:126-127), `keys + key_pe` (transformer.py:164,178,99)
+// and norm4 (transformer.py:180).
+__global__ __launch_bounds__(256) void ln_pe_kernel(const float* __restrict__ x, const float* __restrict__ add_vec,
+                                                    const float* __restrict__ w, const float* __restrict__ b,
+                                                    const float* __restrict__ pe, float* __restrict__ y32,
+                                                    half_t* __restrict__ y16, half_t* __restrict__ ype16, int M,
+                                                    int in_mod, int pe_mod, float eps, int do_ln) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const int irow = in_mod ? row % in_mod : row;
+  float4 v = reinterpret_cast<const float4*>(x + (size_t)irow * 256)[lane];
+  if (add_vec) {
+    float4 a = reinterpret_cast<const float4*>(add_vec)[lane];
+    v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+  }
+  if (do_ln) {
+    const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) / 256.f;
+    const float a0 = v.x - mean, a1 = v.y - mean, a2 = v.z - mean, a3 = v.w - mean;
+    const float var = wave_sum((a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3)) / 256.f;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const float4 ww = reinterpret_cast<const float4*>(w)[lane], bb = reinterpret_cast<const float4*>(b)[lane];
+    v.x = a0 * rstd * ww.x + bb.x;
+    v.y = a1 * rstd * ww.y + bb.y;
+    v.z = a2 * rstd * ww.z + bb.z;
+    v.w = a3 * rstd * ww.w + bb.w;
+  }
+  if (y32) reinterpret_cast<float4*>(y32 + (size_t)row * 256)[lane] = v;
+  if (y16) {
+    half4_t hh = {(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
+    reinterpret_cast<half4_t*>(y16 + (size_t)row * 256)[lane] = hh;
+  }
+  if (ype16) {
+    const float4 p = reinterpret_cast<const float4*>(pe + (size_t)(row % pe_mod) * 256)[lane];
+    half4_t hh = {(half_t)(v.x + p.x), (half_t)(v.y + p.y), (half_t)(v.z + p.z), (half_t)(v.w + p.w)};
+    reinterpret_cast<half4_t*>(ype16 + (size_t)row * 256)[lane] = hh;
+  }
+}
+
+extern "C" int psam_ln_pe(const float* x, const float* add_vec, const float* w, const float* b, const float* pe,
+                          float* y32, void* y16, void* ype16, int M, int in_mod, int pe_mod, float eps, int do_ln,
+                          void* stream) {
+  if (M <= 0 || pe_mod <= 0) return PSAM_ERR_ARG;
+  hipLaunchKernelGGL(ln_pe_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, add_vec, w, b, pe, y32,
+                     (half_t*)y16, (half_t*)ype16, M, in_mod, pe_mod, eps, do_ln);
+  return psam_launch_status();
+}
+
+// =====================================================================================================
+// Random-Fourier positional encoding (prompt_encoder.py:186-193): c in [0,1]^2 -> [sin | cos](2*pi*((2c-1) @ G))
+__device__ __forceinline__ void pe_pair(float cx, float cy, const float* __restrict__ G, int k, float* sn, float* cs) {
+  const float a = (2.f * cx - 1.f) * G[k] + (2.f * cy - 1.f) * G[128 + k];
+  const float arg = 6.283185307179586f * a;
+  *sn = sinf(arg);
+  *cs = cosf(arg);
+}
+
+// dense PE of the 64x64 grid, token-major [gh*gw, 256] (get_dense_pe, prompt_encoder.py:62-71,195-206)
+__global__ void dense_pe_kernel(const float* __restrict__ G, int gh, int gw, float* __restrict__ pe) {
+  const int pix = blockIdx.x, k = threadIdx.x;  // 128 threads
+  const float cy = ((float)(pix / gw) + 0.5f) / (float)gh, cx = ((float)(pix % gw) + 0.5f) / (float)gw;
+  float sn, cs;
+  pe_pair(cx, cy, G, k, &sn, &cs);
+  pe[(size_t)pix * 256 + k] = sn;
+  pe[(size_t)pix * 256 + 128 + k] = cs;
+}
+extern "C" int psam_dense_pe(const float* G, int gh, int gw, float* pe, void* stream) {
+  hipLaunchKernelGGL(dense_pe_kernel, dim3(gh * gw), dim3(128), 0, (hipStream_t)stream, G, gh, gw, pe);
+  return psam_launch_status();
+}
+
+// tokens[b, 0:5] = out_tok (iou_token ++ mask_tokens); tokens[b, 5+j] = PE((coords[b,j] + 0.5)/img) + type_emb
+// labels: -1 not-a-point (PE zeroed), 0 negative, 1 positive, 2 / 3 box corners; type table row = label + 1
+// (prompt_encoder.py:73-101). coords are in the 1024-frame (predictor.apply_coords already applied).
+__global__ void prompt_tokens_kernel(const float* __restrict__ coords, const int* __restrict__ labels,
+                                     const float* __restrict__ G, const float* __restrict__ type_emb,
+                                     const float* __restrict__ out_tok, int Ns, float img_size,
+                                     float* __restrict__ tokens) {
+  const int j = blockIdx.x, b = blockIdx.y, k = threadIdx.x;  // 128 threads
+  const int T = 5 + Ns;
+  float* o = tokens + ((size_t)b * T + j) * 256;
+  if (j < 5) {
+    o[k] = out_tok[j * 256 + k];
+    o[128 + k] = out_tok[j * 256 + 128 + k];
+    return;
+  }
+  const int sj = j - 5;
+  const int lab = labels[b * Ns + sj];
+  float sn = 0.f, cs = 0.f;
+  if (lab >= 0) {
+    const float cx = (coords[((size_t)b * Ns + sj) * 2 + 0] + 0.5f) / img_size;
+    const float cy = (coords[((size_t)b * Ns + sj) * 2 + 1] + 0.5f) / img_size;
+    pe_pair(cx, cy, G, k, &sn, &cs);
+  }
+  const float* te = type_emb + (size_t)(lab + 1) * 256;
+  o[k] = sn + te[k];
+  o[128 + k] = cs + te[128 + k];
+}
+extern "C" int psam_prompt_tokens(const float* coords, const int* labels, const float* G, const float* type_emb,
+                                  const float* out_tok, int B, int Ns, float img_size, float* tokens, void* stream) {
+  if (B <= 0 || Ns < 0) return PSAM_ERR_ARG;
+  hipLaunchKernelGGL(prompt_tokens_kernel, dim3(5 + Ns, B), dim3(128), 0, (hipStream_t)stream, coords, labels, G,
+                     type_emb, out_tok, Ns, img_size, tokens);
+  return psam_launch_status();
+}
+
+// =====================================================================================================
+// upscale_tail (mask_decoder.py:53-59,137-144): u1 = ConvT(256->64,2,2)(keys) as a GEMM [B*4096, 4*64] (+bias);
+// per mid pixel (token, dy, dx): LayerNorm2d(64) -> GELU -> ConvT(64->32,2,2) -> GELU -> dot with the 4
+// hyper-network vectors -> masks[b, 0:4, 4*ty+2*dy+dy2, 4*tx+2*dx+dx2]. `upscaled_embedding` is never written.
+__global__ __launch_bounds__(256) void upscale_tail_kernel(const float* __restrict__ u1, const float* __restrict__ lnw,
+                                                           const float* __restrict__ lnb, const float* __restrict__ W2r,
+                                                           const float* __restrict__ b2, const float* __restrict__ hyper,
+                                                           float* __restrict__ masks, int g) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* w2s = sm;                 // [64][128]
+  float* hs = w2s + 64 * 128;      // [4][32]
+  float* b2s = hs + 128;           // [32]
+  float* mids = b2s + 32;          // [256][65]
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < 64 * 128; i += 256) w2s[i] = W2r[i];
+  if (threadIdx.x < 128) hs[threadIdx.x] = hyper[(size_t)b * 128 + threadIdx.x];
+  if (threadIdx.x < 32) b2s[threadIdx.x] = b2[threadIdx.x];
+  const int tok = blockIdx.x * 64 + (threadIdx.x >> 2);
+  const int dd = threadIdx.x & 3, dy = dd >> 1, dx = dd & 1;
+  const int ty = tok / g, tx = tok % g;
+  const float4* up = reinterpret_cast<const float4*>(u1 + ((size_t)b * g * g + tok) * 256 + dd * 64);
+  float* mymid = mids + threadIdx.x * 65;
+  {
+    float mid[64];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float4 v = up[i];
+      mid[4 * i] = v.x; mid[4 * i + 1] = v.y; mid[4 * i + 2] = v.z; mid[4 * i + 3] = v.w;
+      s += (v.x + v.y) + (v.z + v.w);
+    }
+    const float mean = s / 64.f;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < 64; ++c) {
+      mid[c] -= mean;
+      q += mid[c] * mid[c];
+    }
+    const float rstd = 1.0f / sqrtf(q / 64.f + 1e-6f);
+#pragma unroll
+    for (int c = 0; c < 64; ++c) mymid[c] = gelu_erf(mid[c] * rstd * lnw[c] + lnb[c]);
+  }
+  __syncthreads();
+  const int W = 4 * g;
+#pragma unroll 1
+  for (int d2 = 0; d2 < 4; ++d2) {
+    float acc[32];
+#pragma unroll
+    for (int c2 = 0; c2 < 32; ++c2) acc[c2] = b2s[c2];
+#pragma unroll 2
+    for (int c = 0; c < 64; ++c) {
+      const float m = mymid[c];
+      const float4* wr = reinterpret_cast<const float4*>(&w2s[c * 128 + d2 * 32]);
+#pragma unroll
+      for (int c4 = 0; c4 < 8; ++c4) {
+        const float4 wv = wr[c4];
+        acc[4 * c4] += m * wv.x;
+        acc[4 * c4 + 1] += m * wv.y;
+        acc[4 * c4 + 2] += m * wv.z;
+        acc[4 * c4 + 3] += m * wv.w;
+      }
+    }
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+#pragma unroll
+    for (int c2 = 0; c2 < 32; ++c2) {
+      const float a = gelu_erf(acc[c2]);
+      o0 += hs[c2] * a;
+      o1 += hs[32 + c2] * a;
+      o2 += hs[64 + c2] * a;
+      o3 += hs[96 + c2] * a;
+    }
+    const int y = 4 * ty + 2 * dy + (d2 >> 1), x = 4 * tx + 2 * dx + (d2 & 1);
+    float* mp = masks + (size_t)b * 4 * W * W + (size_t)y * W + x;
+    mp[0] = o0;
+    mp[(size_t)W * W] = o1;
+    mp[(size_t)2 * W * W] = o2;
+    mp[(size_t)3 * W * W] = o3;
+  }
+}
+
+#define UPS_LDS ((64 * 128 + 128 + 32 + 256 * 65) * 4)
+extern "C" int psam_upscale_tail(const float* u1, const float* lnw, const float* lnb, const float* W2r, const float* b2,
+                                 const float* hyper, float* masks, int B, int g, void* stream) {
+  if (B <= 0 || (g * g) % 64) return PSAM_ERR_ARG;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)upscale_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, UPS_LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(upscale_tail_kernel, dim3(g * g / 64, B), dim3(256), UPS_LDS, (hipStream_t)stream, u1, lnw, lnb, W2r, b2,
+                     hyper, masks, g);
+  return psam_launch_status();
+}
+
+// =====================================================================================================
+// Mask post-processing. variant 0: bilinear align_corners=False (pip segment_anything 1.0 `Sam`),
+// 1: bilinear align_corners=True (vendored `SamBatched`, sam.py:313-320), 2: nearest (vendored `Sam`, sam.py:154-160).
+struct Lin2 {
+  int i0, i1;
+  float l0, l1;
+};
+__device__ __forceinline__ Lin2 lin2(int dst, int in_size, int out_size, int align) {
+  float s;
+  if (align) {
+    const float sc = out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
+    s = sc * (float)dst;
+  } else {
+    const float sc = (float)in_size / (float)out_size;
+    s = sc * ((float)dst + 0.5f) - 0.5f;
+    s = s < 0.f ? 0.f : s;
+  }
+  int i0 = (int)s;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  Lin2 r;
+  r.i0 = i0;
+  r.i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  float l1 = s - (float)i0;
+  l1 = l1 < 0.f ? 0.f : (l1 > 1.f ? 1.f : l1);
+  r.l1 = l1;
+  r.l0 = 1.f - l1;
+  return r;
+}
+__device__ __forceinline__ float up_sample(const float* __restrict__ p, int IN, int MID, int y, int x, int variant) {
+  // value of interpolate(p[IN,IN] -> [MID,MID]) at (y, x)
+  if (variant == 2) {
+    const float sc = (float)IN / (float)MID;
+    int sy = (int)floorf((float)y * sc), sx = (int)floorf((float)x * sc);
+    sy = sy < IN - 1 ? sy : IN - 1;
+    sx = sx < IN - 1 ? sx : IN - 1;
+    return p[(size_t)sy * IN + sx];
+  }
+  Lin2 ly = lin2(y, IN, MID, variant == 1), lx = lin2(x, IN, MID, variant == 1);
+  const float* r0 = p + (size_t)ly.i0 * IN;
+  const float* r1 = p + (size_t)ly.i1 * IN;
+  return ly.l0 * (lx.l0 * r0[lx.i0] + lx.l1 * r0[lx.i1]) + ly.l1 * (lx.l0 * r1[lx.i0] + lx.l1 * r1[lx.i1]);
+}
+
+// masks [B, C, IN, IN] logits -> logits at [B, C, MID, MID] (the predictor's `masks` before thresholding when the image
+// handed to SAM is MID x MID, so the second interpolate of postprocess_masks is the identity)
+__global__ void mask_upsample_kernel(const float* __restrict__ low, int IN, int MID, int variant,
+                                     float* __restrict__ out) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, pl = blockIdx.z;
+  if (x >= MID) return;
+  out[((size_t)pl * MID + y) * MID + x] = up_sample(low + (size_t)pl * IN * IN, IN, MID, y, x, variant);
+}
+extern "C" int psam_mask_upsample(const float* low, int planes, int IN, int MID, int variant, float* out, void* stream) {
+  if (planes <= 0 || variant < 0 || variant > 2) return PSAM_ERR_ARG;
+  hipLaunchKernelGGL(mask_upsample_kernel, dim3((MID + 255) / 256, MID, planes), dim3(256), 0, (hipStream_t)stream, low,
+                     IN, MID, variant, out);
+  return psam_launch_status();
+}
+
+// pred[y, x] (fp32 {0,1}, [OUT, OUT]) = OR_b ( upsample(low[b, sel])[ny(y), nx(x)] > thr ) with the final
+// F.interpolate(mode='nearest') MID -> OUT folded in (models/ProtoSAM.py:669-676).
+__global__ void mask_union_kernel(const float* __restrict__ low, int B, int C, int sel, int IN, int MID, int OUT,
+                                  int variant, float thr, float* __restrict__ pred) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= OUT) return;
+  const float sc = (float)MID / (float)OUT;
+  int sy = (int)floorf((float)y * sc), sx = (int)floorf((float)x * sc);
+  sy = sy < MID - 1 ? sy : MID - 1;
+  sx = sx < MID - 1 ? sx : MID - 1;
+  int any = 0;
+  for (int b = 0; b < B; ++b) {
+    const float v = up_sample(low + ((size_t)b * C + sel) * IN * IN, IN, MID, sy, sx, variant);
+    any |= (v > thr);
+  }
+  pred[(size_t)y * OUT + x] = any ? 1.f : 0.f;
+}
+extern "C" int psam_mask_union(const float* low, int B, int C, int sel, int IN, int MID, int OUT, int variant, float thr,
+                               float* pred, void* stream) {
+  if (B <= 0 || sel < 0 || sel >= C || variant < 0 || variant > 2) return PSAM_ERR_ARG;
+  hipLaunchKernelGGL(mask_union_kernel, dim3((OUT + 255) / 256, OUT), dim3(256), 0, (hipStream_t)stream, low, B, C, sel,
+                     IN, MID, OUT, variant, thr, pred);
+  return psam_launch_status();
+}

@@ -237,3 +237,64 @@ extern "C" int psam_sam_patchify(const float* img, const void* mm, int B, int S,
                      (uint8_t*)u8out);
   return psam_launch_status();
 }
+
+// ---- SAM neck: im2col for the 3x3 / pad 1 conv on a token-major map --------------------------------------------
+// in fp16 [B, H*W, C] -> out fp16 [B*H*W, 9*C], column (ky*3+kx)*C + c = in[b, (y+ky-1)*W + (x+kx-1), c] or 0.
+// (models/segment_anything/modeling/image_encoder.py:98-104: Conv2d(out_chans, out_chans, 3, padding=1, bias=False))
+__global__ void im2col3x3_kernel(const half_t* __restrict__ in, int H, int W, int C, half_t* __restrict__ out) {
+  const int pix = blockIdx.x, b = blockIdx.y;
+  const int y = pix / W, x = pix % W;
+  const int cv = C / 8;  // 16-byte chunks per tap
+  uint4* o = reinterpret_cast<uint4*>(out + ((size_t)b * H * W + pix) * 9 * C);
+  for (int i = threadIdx.x; i < 9 * cv; i += blockDim.x) {
+    int tap = i / cv, c = i % cv;
+    int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+      v = reinterpret_cast<const uint4*>(in + ((size_t)b * H * W + (size_t)yy * W + xx) * C)[c];
+    o[i] = v;
+  }
+}
+extern "C" int psam_im2col3x3(const void* in, int B, int H, int W, int C, void* out, void* stream) {
+  if (B <= 0 || (C % 8) != 0) return PSAM_ERR_ARG;
+  hipLaunchKernelGGL(im2col3x3_kernel, dim3(H * W, B), dim3(256), 0, (hipStream_t)stream, (const half_t*)in, H, W, C,
+                     (half_t*)out);
+  return psam_launch_status();
+}
+
+// fp32 -> fp16 cast (residual stream into the neck's 1x1-conv GEMM operand), 8 elements per thread
+__global__ void cast_f16_kernel(const float* __restrict__ x, half_t* __restrict__ y, size_t n8) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const float4 a = reinterpret_cast<const float4*>(x)[2 * i], b = reinterpret_cast<const float4*>(x)[2 * i + 1];
+  half8_t h = {(half_t)a.x, (half_t)a.y, (half_t)a.z, (half_t)a.w, (half_t)b.x, (half_t)b.y, (half_t)b.z, (half_t)b.w};
+  reinterpret_cast<half8_t*>(y)[i] = h;
+}
+extern "C" int psam_cast_f16(const float* x, void* y, long long n, void* stream) {
+  if (n <= 0 || (n & 7)) return PSAM_ERR_ARG;
+  size_t n8 = (size_t)n / 8;
+  hipLaunchKernelGGL(cast_f16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     (half_t*)y, n8);
+  return psam_launch_status();
+}
+
+// Sam.preprocess normalisation (modeling/sam.py:163-168): y[b,c,:,:] = (x[b,c,:,:] - mean[c]) / std[c].
+// in_u8 = 1: x is uint8 (the predictor's image tensor, predictor.py:57-58), else fp32. 3 channels.
+__global__ void normalize_chw_kernel(const void* __restrict__ x, int in_u8, size_t plane, float m0, float m1, float m2,
+                                     float s0, float s1, float s2, float* __restrict__ y, size_t total) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)((i / plane) % 3);
+  const float v = in_u8 ? (float)reinterpret_cast<const uint8_t*>(x)[i] : reinterpret_cast<const float*>(x)[i];
+  const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2);
+  const float sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+  y[i] = (v - mean) / sd;
+}
+extern "C" int psam_normalize_chw(const void* x, int in_u8, int B, long long plane, const float* mean3,
+                                  const float* std3, float* y, void* stream) {
+  if (B <= 0 || plane <= 0) return PSAM_ERR_ARG;
+  const size_t total = (size_t)B * 3 * (size_t)plane;
+  hipLaunchKernelGGL(normalize_chw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     in_u8, (size_t)plane, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], y, total);
+  return psam_launch_status();
+}

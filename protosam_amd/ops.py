@@ -215,3 +215,138 @@ def sam_patchify(img, mm, S, P, mean3, std3, quantise=True, out=None, u8out=None
                                      _stream())
     _lib.check(st, "psam_sam_patchify")
     return out
+
+
+def im2col3x3(x, B, H, W, C, out=None):
+    _req(x, torch.float16, "x")
+    assert x.is_contiguous()
+    if out is None:
+        out = torch.empty((B * H * W, 9 * C), dtype=torch.float16, device=x.device)
+    st = _lib.lib().psam_im2col3x3(_ptr(x), B, H, W, C, _ptr(out), _stream())
+    _lib.check(st, "psam_im2col3x3")
+    return out
+
+
+def cast_f16(x, out=None):
+    _req(x, torch.float32, "x")
+    assert x.is_contiguous()
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    st = _lib.lib().psam_cast_f16(_ptr(x), _ptr(out), x.numel(), _stream())
+    _lib.check(st, "psam_cast_f16")
+    return out
+
+
+# ---- SAM prompt encoder / mask decoder -----------------------------------------------------------------------
+def small_linear(x, W, b=None, out=None, act=0, resid=None, x2=None, G=1, M=None, N=None, K=None, xg=0, wg=0, bg=0, yg=0,
+                 ldx=None, ldy=None):
+    """Grouped fp32 y[g,m,:] = act(x[g,m,:] @ W[g]^T + b[g]) (+ resid). Defaults: one group, x [M,K], W [N,K]."""
+    _req(x, torch.float32, "x"); _req(W, torch.float32, "W"); _req(b, torch.float32, "b")
+    _req(resid, torch.float32, "resid")
+    if M is None:
+        M = x.shape[-2]
+    if K is None:
+        K = x.shape[-1]
+    if N is None:
+        N = W.shape[-2]
+    if ldx is None:
+        ldx = x.stride(-2)
+    if out is None:
+        out = torch.empty(tuple(x.shape[:-1]) + (N,), dtype=torch.float32, device=x.device)
+    if ldy is None:
+        ldy = out.stride(-2)
+    _req(x2, torch.float32, "x2")
+    st = _lib.lib().psam_small_linear(_ptr(x), _ptr(x2), _ptr(W), _ptr(b), _ptr(resid), _ptr(out), G, M, N, K, xg, wg, bg, yg,
+                                     ldx, ldy, act, _stream())
+    _lib.check(st, "psam_small_linear")
+    return out
+
+
+def small_attention(q, k, v, out, B, Tq, Tk, NH, hd, ldq, ldk, ldv, ldo):
+    q16 = q.dtype == torch.float16
+    _req(k, torch.float32, "k"); _req(v, torch.float32, "v")
+    assert out.dtype == q.dtype
+    st = _lib.lib().psam_small_attention(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, Tq, Tk, NH, hd, ldq, ldk, ldv, ldo,
+                                        1 if q16 else 0, _stream())
+    _lib.check(st, "psam_small_attention")
+    return out
+
+
+def t2i_attention(q, K, V, out, B, T, Nk, NH):
+    _req(q, torch.float32, "q"); _req(K, torch.float16, "K"); _req(V, torch.float16, "V"); _req(out, torch.float32, "out")
+    st = _lib.lib().psam_t2i_attention(_ptr(q), _ptr(K), _ptr(V), _ptr(out), B, T, Nk, NH, _stream())
+    _lib.check(st, "psam_t2i_attention")
+    return out
+
+
+def ln_pe(x, pe, M, y32=None, y16=None, ype16=None, add_vec=None, w=None, b=None, in_mod=0, pe_mod=4096, eps=1e-5):
+    _req(x, torch.float32, "x"); _req(pe, torch.float32, "pe")
+    st = _lib.lib().psam_ln_pe(_ptr(x), _ptr(add_vec), _ptr(w), _ptr(b), _ptr(pe), _ptr(y32), _ptr(y16), _ptr(ype16), M,
+                              in_mod, pe_mod, float(eps), 1 if w is not None else 0, _stream())
+    _lib.check(st, "psam_ln_pe")
+
+
+def dense_pe(G, gh, gw):
+    _req(G, torch.float32, "G")
+    pe = torch.empty((gh * gw, 256), dtype=torch.float32, device=G.device)
+    st = _lib.lib().psam_dense_pe(_ptr(G), gh, gw, _ptr(pe), _stream())
+    _lib.check(st, "psam_dense_pe")
+    return pe
+
+
+def prompt_tokens(coords, labels, G, type_emb, out_tok, B, Ns, img_size, tokens=None):
+    _req(coords, torch.float32, "coords"); _req(labels, torch.int32, "labels")
+    if tokens is None:
+        tokens = torch.empty((B, 5 + Ns, 256), dtype=torch.float32, device=G.device)
+    st = _lib.lib().psam_prompt_tokens(_ptr(coords), _ptr(labels), _ptr(G), _ptr(type_emb), _ptr(out_tok), B, Ns,
+                                      float(img_size), _ptr(tokens), _stream())
+    _lib.check(st, "psam_prompt_tokens")
+    return tokens
+
+
+def upscale_tail(u1, lnw, lnb, W2r, b2, hyper, B, g, masks=None):
+    _req(u1, torch.float32, "u1"); _req(hyper, torch.float32, "hyper")
+    if masks is None:
+        masks = torch.empty((B, 4, 4 * g, 4 * g), dtype=torch.float32, device=u1.device)
+    st = _lib.lib().psam_upscale_tail(_ptr(u1), _ptr(lnw), _ptr(lnb), _ptr(W2r), _ptr(b2), _ptr(hyper), _ptr(masks), B, g,
+                                     _stream())
+    _lib.check(st, "psam_upscale_tail")
+    return masks
+
+
+def mask_upsample(low, MID, variant, out=None):
+    _req(low, torch.float32, "low")
+    assert low.is_contiguous()
+    IN = low.shape[-1]
+    planes = low.numel() // (IN * IN)
+    if out is None:
+        out = torch.empty(tuple(low.shape[:-2]) + (MID, MID), dtype=torch.float32, device=low.device)
+    st = _lib.lib().psam_mask_upsample(_ptr(low), planes, IN, MID, variant, _ptr(out), _stream())
+    _lib.check(st, "psam_mask_upsample")
+    return out
+
+
+def mask_union(low, sel, MID, OUT, variant, thr=0.0, pred=None):
+    _req(low, torch.float32, "low")
+    assert low.is_contiguous() and low.dim() == 4
+    B, C, IN, _ = low.shape
+    if pred is None:
+        pred = torch.empty((OUT, OUT), dtype=torch.float32, device=low.device)
+    st = _lib.lib().psam_mask_union(_ptr(low), B, C, sel, IN, MID, OUT, variant, float(thr), _ptr(pred), _stream())
+    _lib.check(st, "psam_mask_union")
+    return pred
+
+
+def normalize_chw(x, mean3, std3, out=None):
+    """(x - mean[c]) / std[c] on [B,3,H,W]; x uint8 or fp32."""
+    import ctypes
+    assert x.is_cuda and x.is_contiguous() and x.dim() == 4 and x.shape[1] == 3
+    assert x.dtype in (torch.uint8, torch.float32)
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean3])
+    s = (ctypes.c_float * 3)(*[float(v) for v in std3])
+    st = _lib.lib().psam_normalize_chw(_ptr(x), 1 if x.dtype == torch.uint8 else 0, x.shape[0],
+                                      x.shape[2] * x.shape[3], m, s, _ptr(out), _stream())
+    _lib.check(st, "psam_normalize_chw")
+    return out

@@ -1,0 +1,172 @@
+"""SAM ViTDet image encoder on the HIP kernels (state-dict names of the vendored reference module).
+
+Mirrors /root/reference/models/segment_anything/modeling/image_encoder.py: `ImageEncoderViT` (:17-122), `Block`
+(:125-193), `Attention` (:196-251), windowing (:254-300), decomposed rel-pos (:303-372), `PatchEmbed` (:375-406).
+Per block: LN -> QKV GEMM -> psam_relpos (from the unscaled fp16 q) -> fused attention (14x14 windows folded into
+index math, or global with a 64-key tile = one key row) -> proj GEMM (+residual) -> LN -> lin1 GEMM (+GELU) ->
+lin2 GEMM (+residual). Neck: 1x1 conv = GEMM, LayerNorm2d = row LN (token-major), 3x3 conv = im2col + GEMM, LN.
+The 64x64x256 embedding is kept token-major; `forward` returns the reference's NCHW shape as a permuted view.
+"""
+import torch
+import torch.nn as nn
+
+from ... import ops
+from .common import LayerNorm2d, MLPBlock, f16, f32
+
+LN_EPS = 1e-6  # build_sam.py:72
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, kernel_size=(16, 16), stride=(16, 16), padding=(0, 0), in_chans=3, embed_dim=768):
+        super().__init__()
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=kernel_size, stride=stride, padding=padding)
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads=8, qkv_bias=True, use_rel_pos=False, rel_pos_zero_init=True, input_size=None):
+        super().__init__()
+        self.num_heads = num_heads
+        head_dim = dim // num_heads
+        self.scale = head_dim ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+        self.use_rel_pos = use_rel_pos
+        if use_rel_pos:
+            assert input_size is not None, "Input size must be provided if using relative positional encoding."
+            self.rel_pos_h = nn.Parameter(torch.zeros(2 * input_size[0] - 1, head_dim))
+            self.rel_pos_w = nn.Parameter(torch.zeros(2 * input_size[1] - 1, head_dim))
+
+
+class Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=True, norm_layer=nn.LayerNorm, act_layer=nn.GELU,
+                 use_rel_pos=False, rel_pos_zero_init=True, window_size=0, input_size=None):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, use_rel_pos=use_rel_pos,
+                              rel_pos_zero_init=rel_pos_zero_init,
+                              input_size=input_size if window_size == 0 else (window_size, window_size))
+        self.norm2 = norm_layer(dim)
+        self.mlp = MLPBlock(embedding_dim=dim, mlp_dim=int(dim * mlp_ratio), act=act_layer)
+        self.window_size = window_size
+
+
+class ImageEncoderViT(nn.Module):
+    def __init__(self, img_size=1024, patch_size=16, in_chans=3, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.0,
+                 out_chans=256, qkv_bias=True, norm_layer=nn.LayerNorm, act_layer=nn.GELU, use_abs_pos=True,
+                 use_rel_pos=False, rel_pos_zero_init=True, window_size=0, global_attn_indexes=(),
+                 use_grad_checkpointing=False):
+        super().__init__()
+        self.img_size = img_size
+        self.patch_size = patch_size
+        self.embed_dim = embed_dim
+        self.num_heads = num_heads
+        self.out_chans = out_chans
+        self.grid = img_size // patch_size
+        if not (use_abs_pos and use_rel_pos and qkv_bias):
+            raise NotImplementedError("only SAM's configuration (abs pos + rel pos + qkv bias, build_sam.py:66-81)")
+        if self.grid != 64 or (embed_dim // num_heads) not in (64, 80):
+            raise NotImplementedError("HIP attention is built for the 64x64 token map and head dims 64 / 80")
+        self.patch_embed = PatchEmbed((patch_size, patch_size), (patch_size, patch_size), in_chans=in_chans,
+                                      embed_dim=embed_dim)
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.grid, self.grid, embed_dim))
+        self.blocks = nn.ModuleList([
+            Block(embed_dim, num_heads, mlp_ratio, qkv_bias, norm_layer, act_layer, use_rel_pos, rel_pos_zero_init,
+                  window_size if i not in global_attn_indexes else 0, (self.grid, self.grid)) for i in range(depth)])
+        self.neck = nn.Sequential(nn.Conv2d(embed_dim, out_chans, kernel_size=1, bias=False), LayerNorm2d(out_chans),
+                                  nn.Conv2d(out_chans, out_chans, kernel_size=3, padding=1, bias=False),
+                                  LayerNorm2d(out_chans))
+        self._packed = None
+        self._ws = {}
+
+    def _apply(self, fn, *a, **k):
+        self._packed, self._ws = None, {}
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._packed = None
+        return super().load_state_dict(*a, **k)
+
+    def _pack(self):
+        if self._packed is not None:
+            return self._packed
+        D, oc = self.embed_dim, self.out_chans
+        pk = dict(patch_w=f16(self.patch_embed.proj.weight.reshape(D, -1)), patch_b=f32(self.patch_embed.proj.bias),
+                  pos=f32(self.pos_embed.reshape(self.grid * self.grid, D)), blocks=[])
+        for blk in self.blocks:
+            a = blk.attn
+            pk["blocks"].append(dict(
+                ws=blk.window_size, n1w=f32(blk.norm1.weight), n1b=f32(blk.norm1.bias), n2w=f32(blk.norm2.weight),
+                n2b=f32(blk.norm2.bias), qkv_w=f16(a.qkv.weight), qkv_b=f32(a.qkv.bias), pad_row=f16(a.qkv.bias),
+                proj_w=f16(a.proj.weight), proj_b=f32(a.proj.bias), rh=f32(a.rel_pos_h), rw=f32(a.rel_pos_w),
+                l1w=f16(blk.mlp.lin1.weight), l1b=f32(blk.mlp.lin1.bias), l2w=f16(blk.mlp.lin2.weight),
+                l2b=f32(blk.mlp.lin2.bias)))
+            K = blk.window_size if blk.window_size > 0 else self.grid
+            if a.rel_pos_h.shape[0] != 2 * K - 1:
+                raise NotImplementedError("rel-pos table length != 2K-1 needs get_rel_pos' linear resize")
+        pk["neck0"] = f16(self.neck[0].weight.reshape(oc, D))
+        pk["neck1w"], pk["neck1b"] = f32(self.neck[1].weight), f32(self.neck[1].bias)
+        pk["neck2"] = f16(self.neck[2].weight.permute(0, 2, 3, 1).reshape(oc, 9 * oc))  # [out, (ky,kx,cin)]
+        pk["neck3w"], pk["neck3b"] = f32(self.neck[3].weight), f32(self.neck[3].bias)
+        self._packed = pk
+        return pk
+
+    def _workspace(self, B):
+        if B not in self._ws:
+            D, oc, N, H = self.embed_dim, self.out_chans, self.grid * self.grid, self.num_heads
+            dev = self.pos_embed.device
+            M = B * N
+            e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)  # noqa: E731
+            self._ws[B] = dict(x=e((M, D), torch.float32), ln=e((M, D), torch.float16), qkv=e((M, 3 * D), torch.float16),
+                               att=e((M, D), torch.float16), hid=e((M, 4 * D), torch.float16),
+                               relh=e((B, H, N, 64), torch.float32), relw=e((B, H, N, 64), torch.float32),
+                               n0=e((M, oc), torch.float32), n1=e((M, oc), torch.float16),
+                               col=e((M, 9 * oc), torch.float16), n2=e((M, oc), torch.float32),
+                               out=e((B, N, oc), torch.float32))
+        return self._ws[B]
+
+    def encode_patches(self, patches, B):
+        """patches fp16 [B*4096, 3*16*16] (im2col of the normalised image) -> token-major embedding fp32 [B,4096,out]."""
+        pk = self._pack()
+        ws = self._workspace(B)
+        D, H, N, g = self.embed_dim, self.num_heads, self.grid * self.grid, self.grid
+        hd = D // H
+        x = ws["x"]
+        ops.gemm(patches, pk["patch_w"], pk["patch_b"], out=x, epilogue=ops.EPI_F32, resid=pk["pos"], resid_mod=N)
+        for bp in pk["blocks"]:
+            ops.layernorm(x, bp["n1w"], bp["n1b"], LN_EPS, out=ws["ln"])
+            ops.gemm(ws["ln"], bp["qkv_w"], bp["qkv_b"], out=ws["qkv"], epilogue=ops.EPI_F16)
+            if bp["ws"] > 0:
+                ops.relpos(ws["qkv"], bp["rh"], bp["rw"], B, N, H, hd, g, bp["ws"], True, ws["relh"], ws["relw"])
+                ops.attention(ws["qkv"], B, N, H, hd, hd ** -0.5, out=ws["att"], mode=2, rel_h=ws["relh"],
+                              rel_w=ws["relw"], pad_row=bp["pad_row"], gh=g, gw=g, ws=bp["ws"])
+            else:
+                ops.relpos(ws["qkv"], bp["rh"], bp["rw"], B, N, H, hd, g, g, False, ws["relh"], ws["relw"])
+                ops.attention(ws["qkv"], B, N, H, hd, hd ** -0.5, out=ws["att"], mode=1, rel_h=ws["relh"],
+                              rel_w=ws["relw"], gh=g, gw=g)
+            ops.gemm(ws["att"], bp["proj_w"], bp["proj_b"], out=x, epilogue=ops.EPI_F32, resid=x)
+            ops.layernorm(x, bp["n2w"], bp["n2b"], LN_EPS, out=ws["ln"])
+            ops.gemm(ws["ln"], bp["l1w"], bp["l1b"], out=ws["hid"], epilogue=ops.EPI_GELU_F16)
+            ops.gemm(ws["hid"], bp["l2w"], bp["l2b"], out=x, epilogue=ops.EPI_F32, resid=x)
+        # neck (image_encoder.py:90-106): the residual stream is cast once to fp16 for the 1x1-conv GEMM
+        xh = ws["ln"]
+        ops.cast_f16(x, xh)
+        ops.gemm(xh, pk["neck0"], None, out=ws["n0"], epilogue=ops.EPI_F32)
+        ops.layernorm(ws["n0"], pk["neck1w"], pk["neck1b"], LN_EPS, out=ws["n1"])
+        ops.im2col3x3(ws["n1"], B, g, g, self.out_chans, out=ws["col"])
+        ops.gemm(ws["col"], pk["neck2"], None, out=ws["n2"], epilogue=ops.EPI_F32)
+        ops.layernorm(ws["n2"], pk["neck3w"], pk["neck3b"], LN_EPS, out=ws["out"].view(B * N, self.out_chans),
+                      out_dtype=torch.float32)
+        return ws["out"]
+
+    def forward_tokens(self, x):
+        """x fp32 [B,3,1024,1024] (already normalised / padded) -> token-major [B, 4096, out_chans]."""
+        B = x.shape[0]
+        assert tuple(x.shape[1:]) == (3, self.img_size, self.img_size)
+        P = self.patch_size
+        patches = ops.patchify_bilinear(x.float().contiguous(), self.img_size, P, 3 * P * P)
+        return self.encode_patches(patches, B)
+
+    def forward(self, x):
+        t = self.forward_tokens(x)
+        B = t.shape[0]
+        return t.view(B, self.grid, self.grid, self.out_chans).permute(0, 3, 1, 2)

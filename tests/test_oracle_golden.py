@@ -1,0 +1,121 @@
+"""CPU: the oracle reproduces the REFERENCE's recorded outputs (tests/golden/reference_outputs.npz, written by
+oracle/validate_against_reference.py from the real /root/reference modules) on the shared seeded inputs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_outputs.npz")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+def _close(a, b, tol):
+    err = (torch.as_tensor(a).double() - torch.as_tensor(b).double()).abs().max().item()
+    assert err <= tol, err
+
+
+def test_alp_modes(gold):
+    from oracle import alp as oalp, golden_inputs as gi
+    qry, sup, msk = gi.alp_case()
+    for mode in ("mask", "gridconv", "gridconv+"):
+        out, _ = oalp.cls_unit(qry[0], sup[0, 0], msk[0], mode, 0.95, 2)
+        _close(out, gold[f"alp_{mode}"], 1e-5)
+
+
+def test_alp_edge_cases():
+    """Edge cases the reference defines: bad mode -> ValueError; no prototype -> failure; 1-pixel mask -> 'mask' mode;
+    odd maps (73x73) pool to 36x36 cells."""
+    from oracle import alp as oalp
+    g = torch.Generator().manual_seed(0)
+    q = torch.randn((1, 16, 8, 8), generator=g)
+    s = torch.randn((1, 16, 8, 8), generator=g)
+    with pytest.raises(ValueError):
+        oalp.cls_unit(q, s, torch.ones((1, 1, 8, 8)), "grid", 0.95, 2)
+    with pytest.raises(RuntimeError):
+        oalp.cls_unit(q, s, torch.zeros((1, 1, 8, 8)), "gridconv", 0.95, 2)
+    one = torch.zeros((1, 1, 8, 8))
+    one[0, 0, 3, 3] = 1
+    assert oalp.fg_mode_for(one, 1) == "gridconv+" and oalp.fg_mode_for(one, 2) == "mask"
+    q73 = torch.randn((1, 8, 73, 73), generator=g)
+    protos = oalp.get_prototypes(q73, torch.ones((1, 1, 73, 73)), "gridconv", 2, 0.95)
+    assert protos.shape == (36 * 36, 8)
+
+
+@pytest.mark.parametrize("size", [252, 448])
+def test_fewshot_forward(gold, size):
+    from oracle import alp as oalp, dinov2 as odino, golden_inputs as gi
+    sd = gi.fewshot_encoder_sd()
+    s_img, s_m, q_img, _ = gi.fewshot_pair(size)
+    enc = lambda im: odino.forward_features(im, sd, "dinov2_b14", depth=gi.FEWSHOT_DEPTH)["x_norm_patchtokens"]  # noqa
+    out = oalp.fewshot_forward(enc, s_img, s_m, q_img, size)
+    _close(out, gold[f"fewshot_logits_{size}"], 1e-4)
+
+
+def test_sam_image_encoder_small(gold):
+    from oracle import golden_inputs as gi, sam_image_encoder as oenc
+    from protosam_amd.synth import synth_tensor
+    c = gi.SMALL_ENCODER
+    oenc.VIT_CFGS["tiny_test"] = {k: v for k, v in c.items() if k != "out_chans"}
+    D, oc, hd = c["embed_dim"], c["out_chans"], c["embed_dim"] // c["num_heads"]
+    shapes = {"pos_embed": (1, 64, 64, D), "patch_embed.proj.weight": (D, 3, 16, 16), "patch_embed.proj.bias": (D,),
+              "neck.0.weight": (oc, D, 1, 1), "neck.1.weight": (oc,), "neck.1.bias": (oc,),
+              "neck.2.weight": (oc, oc, 3, 3), "neck.3.weight": (oc,), "neck.3.bias": (oc,)}
+    for i in range(c["depth"]):
+        K = 64 if i in c["global_attn_indexes"] else 14
+        p = f"blocks.{i}."
+        shapes.update({p + "norm1.weight": (D,), p + "norm1.bias": (D,), p + "norm2.weight": (D,), p + "norm2.bias": (D,),
+                       p + "attn.qkv.weight": (3 * D, D), p + "attn.qkv.bias": (3 * D,),
+                       p + "attn.proj.weight": (D, D), p + "attn.proj.bias": (D,),
+                       p + "attn.rel_pos_h": (2 * K - 1, hd), p + "attn.rel_pos_w": (2 * K - 1, hd),
+                       p + "mlp.lin1.weight": (4 * D, D), p + "mlp.lin1.bias": (4 * D,),
+                       p + "mlp.lin2.weight": (D, 4 * D), p + "mlp.lin2.bias": (D,)})
+    sd = {k: synth_tensor(k, s, gi.SMALL_ENCODER_SEED) for k, s in shapes.items()}
+    out = oenc.image_encoder(gi.small_encoder_input(), sd, pre="", model_type="tiny_test")
+    _close(out, gold["sam_encoder_small_out"], 2e-5)
+
+
+def test_sam_prompt_encoder_and_mask_decoder(gold):
+    from oracle import golden_inputs as gi, sam_prompt_decoder as odec
+    from protosam_amd.segment_anything import sam_model_registry
+    from protosam_amd.synth import synth_state_dict
+    sam = sam_model_registry["vit_b"](encoder_depth=0)
+    sd = {k: v for k, v in synth_state_dict(sam, gi.DECODER_SEED).items() if not k.startswith("image_encoder.")}
+    feats = gi.decoder_features()
+    pe = odec.dense_pe(sd)
+    for name, (pc, pl, bx) in gi.decoder_cases().items():
+        pts = (pc, pl) if pc is not None else None
+        sp, de = odec.prompt_encoder(sd, pts, bx)
+        low, iou = odec.mask_decoder(sd, feats, pe, sp, de, True)
+        _close(low, gold[f"dec_{name}_low_res"], 2e-4)
+        _close(iou, gold[f"dec_{name}_iou"], 2e-5)
+        if name == "box_only":
+            post = odec.postprocess_masks(odec.mask_decoder(sd, feats, pe, sp, de, False)[0], (1024, 1024),
+                                          (1024, 1024), "batched")
+            _close(post[0, 0, 511], gold["post_batched_row"], 1e-5)
+
+
+def test_connected_components_properties():
+    """Label-invariance properties (cv2 is absent; scipy is the independent check where available)."""
+    from oracle import glue
+    rng = np.random.RandomState(3)
+    img = (rng.rand(64, 80) > 0.55).astype(np.uint8)
+    n, labels, stats, cent = glue.connected_components_with_stats(img)
+    assert labels.shape == img.shape and (labels > 0).sum() == img.sum()
+    assert stats[1:, 4].sum() == img.sum()
+    firsts = [np.flatnonzero(labels.ravel() == j)[0] for j in range(1, n)]
+    assert firsts == sorted(firsts)  # numbered by raster order of the first pixel
+    # idempotence under relabelling and 8-connectivity: diagonal neighbours share a label
+    ys, xs = np.nonzero(img[:-1, :-1] & img[1:, 1:])
+    assert np.all(labels[ys, xs] == labels[ys + 1, xs + 1])
+    try:
+        import scipy.ndimage as ndi
+        lab2, n2 = ndi.label(img, structure=np.ones((3, 3)))
+        assert n2 + 1 == n
+    except ImportError:
+        pass
+    assert glue.connected_components_with_stats(np.zeros((5, 7), np.uint8))[0] == 1

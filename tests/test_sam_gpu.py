@@ -1,0 +1,113 @@
+"""GPU parity of the SAM stage (image encoder, prompt encoder, mask decoder, post-processing, predictor API)
+against the CPU oracle (which is pinned to the vendored reference modules, see tests/test_oracle_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _sam(dev, model_type, depth, seed=1234):
+    from protosam_amd.segment_anything import sam_model_registry
+    from protosam_amd.synth import synth_state_dict
+    sam = sam_model_registry[model_type](encoder_depth=depth)
+    sd = synth_state_dict(sam, seed)
+    sam.load_state_dict(sd, strict=True)
+    return sam.to(dev).eval(), sd
+
+
+def _image(seed=0):
+    from protosam_amd.synth import synth_pair
+    _, _, q, _ = synth_pair(1024, seed=seed)
+    q = (q - q.min()) / (q.max() - q.min()) * 255
+    return q.to(torch.uint8)  # [1,3,1024,1024]
+
+
+@pytest.mark.parametrize("model_type,depth", [("vit_b", 3), ("vit_h", 8)])
+def test_image_encoder(dev, model_type, depth):
+    from oracle import sam_image_encoder as oenc
+    sam, sd = _sam(dev, model_type, depth)
+    img = _image(1)
+    x = (img.float() - torch.tensor([123.675, 116.28, 103.53]).view(1, 3, 1, 1)) / torch.tensor(
+        [58.395, 57.12, 57.375]).view(1, 3, 1, 1)
+    ref = oenc.image_encoder(x, sd, model_type=model_type, depth=depth)
+    xin = sam.preprocess(img.to(dev))
+    torch.testing.assert_close(xin.cpu(), x, rtol=1e-6, atol=1e-6)
+    out = sam.image_encoder(xin)
+    assert out.shape == (1, 256, 64, 64)
+    err = (out.cpu() - ref).abs()
+    print(f"{model_type} depth {depth}: max abs err {err.max():.3e} mean {err.mean():.3e} ref rms {ref.pow(2).mean().sqrt():.3f}")
+    assert err.max() < 5e-2 and err.mean() < 3e-3
+
+
+def _cases():
+    from oracle import golden_inputs as gi
+    return gi.decoder_cases()
+
+
+@pytest.mark.parametrize("name", ["pts_box", "pts_only", "box_only"])
+def test_prompt_encoder_and_mask_decoder(dev, name):
+    from oracle import golden_inputs as gi, sam_prompt_decoder as odec
+    sam, sd = _sam(dev, "vit_b", 0)
+    feats = gi.decoder_features()
+    pc, pl, bx = _cases()[name]
+    pts = (pc, pl) if pc is not None else None
+    sp_r, de_r = odec.prompt_encoder(sd, pts, bx)
+    pe_r = odec.dense_pe(sd)
+    dpts = (pc.to(dev), pl.to(dev)) if pc is not None else None
+    sp, de = sam.prompt_encoder(points=dpts, boxes=None if bx is None else bx.to(dev), masks=None)
+    torch.testing.assert_close(sp.cpu(), sp_r, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(de.cpu(), de_r, rtol=0, atol=0)
+    pe = sam.prompt_encoder.get_dense_pe()
+    torch.testing.assert_close(pe.cpu(), pe_r, rtol=1e-4, atol=2e-5)
+    for mm in (True, False):
+        taps = {}
+        low_r, iou_r = odec.mask_decoder(sd, feats, pe_r, sp_r, de_r, mm, taps=taps)
+        low, iou = sam.mask_decoder(image_embeddings=feats.to(dev), image_pe=pe, sparse_prompt_embeddings=sp,
+                                    dense_prompt_embeddings=de, multimask_output=mm)
+        assert low.shape == low_r.shape and iou.shape == iou_r.shape
+        lerr = (low.cpu() - low_r).abs().max().item()
+        perr = (torch.sigmoid(low.cpu()) - torch.sigmoid(low_r)).abs().max().item()
+        ierr = (iou.cpu() - iou_r).abs().max().item()
+        print(f"{name} multimask={mm}: |dlogit| {lerr:.3e} (|logit| max {low_r.abs().max():.2f}), |dprob| {perr:.3e}, |diou| {ierr:.3e}")
+        # fp16 GEMM operands on the 4096-token side: measured 0.8e-3 .. 1.2e-3 on sigmoid(low_res) (precision)
+        assert perr < 2e-3 and ierr < 2e-3
+
+
+@pytest.mark.parametrize("variant", ["upstream", "batched", "nearest"])
+def test_postprocess_variants(dev, variant):
+    from oracle import sam_prompt_decoder as odec
+    from protosam_amd import ops
+    sam, _ = _sam(dev, "vit_b", 0)
+    sam.postprocess_variant = variant
+    g = torch.Generator().manual_seed(4)
+    low = torch.randn((2, 3, 256, 256), generator=g) * 4
+    ref = odec.postprocess_masks(low, (1024, 1024), (1024, 1024), variant)
+    out = sam.postprocess_masks(low.to(dev), (1024, 1024), (1024, 1024))
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-5)
+    # fused union + nearest to 512 (ProtoSAM.py:669-676)
+    pred = ops.mask_union(low.to(dev), 1, 1024, 512, sam.variant_id())
+    refu = ((ref[:, 1] > 0).sum(0) > 0).float()
+    refu = torch.nn.functional.interpolate(refu[None, None], size=512, mode="nearest")[0, 0]
+    assert (pred.cpu() != refu).sum().item() <= 2
+
+
+def test_predictor_api(dev):
+    from oracle import glue, sam_image_encoder as oenc, sam_prompt_decoder as odec
+    from protosam_amd.segment_anything import SamPredictor
+    sam, sd = _sam(dev, "vit_b", 2)
+    pred = SamPredictor(sam)
+    with pytest.raises(RuntimeError):
+        pred.predict(point_coords=np.array([[1.0, 2.0]]), point_labels=np.array([1]))
+    img = _image(2)[0].permute(1, 2, 0).numpy()  # HWC uint8
+    pred.set_image(img)
+    feats_ref = oenc.image_encoder(glue.sam_preprocess(img), sd, model_type="vit_b", depth=2)
+    emb = pred.get_image_embedding()
+    assert (emb.cpu() - feats_ref).abs().max() < 5e-2
+    pts, lbl, box = np.array([[400.0, 500.0], [520.5, 480.0]]), np.array([1, 1]), np.array([300, 350, 700, 800])
+    masks, iou, low = pred.predict(point_coords=pts, point_labels=lbl, box=box, multimask_output=True)
+    m_r, iou_r, low_r = odec.predict(sd, emb.cpu().contiguous(), pts, lbl, box, True, (1024, 1024))
+    assert masks.shape == (3, 1024, 1024) and masks.dtype == np.bool_ and low.shape == (3, 256, 256)
+    assert (torch.sigmoid(torch.from_numpy(low)) - torch.sigmoid(low_r)).abs().max() < 2e-3
+    assert np.abs(iou - iou_r.numpy()).max() < 2e-3
+    assert (masks != m_r.numpy()).mean() < 1e-3  # sign flips of near-zero logits only
