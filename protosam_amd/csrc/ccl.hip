@@ -1,0 +1,252 @@
+// 8-connected component labelling + per-component statistics on the device.
+//
+// Replaces the host round trip of models/ProtoSAM.py:602-635: `cv2.connectedComponentsWithStats(pred, connectivity=8)`
+// inside util/utils.py:474-494 `get_connected_components` (labels, area, centroids, per-label confidence
+// sum(p_fg * [label == j]) / (sum(pred) + 1e-6)), `get_bbox_per_cc` (ProtoSAM.py:242-264: XYXY min/max per label) and
+// `get_most_conf_points` with k = 1 (ProtoSAM.py:266-289: arg-max of p_fg inside the component).
+//
+// Algorithm: lock-free union-find over pixels (link larger root -> smaller with atomicMin, so a component's root is its
+// first pixel in raster order), flatten, collect the roots, rank them (labels are numbered by raster order of the first
+// pixel; cv2's numbering is an implementation detail and every downstream use is order-invariant, ProtoSAM.py:669),
+// then one pass that accumulates the statistics with wave-level pre-aggregation (a 64-pixel row segment almost always
+// holds a single label) before the atomics. Integer work throughout, except the confidence sum (fp64 atomics).
+//
+// Output table (fp64, one D2H): tab[0] = n components found, tab[1] = n kept (<= cap), tab[2] = sum(pred),
+// tab[3] = index (0-based) of the most confident component, then per component k at tab[8 + 12*k ..]:
+//   {area, sum_x, sum_y, min_x, min_y, max_x, max_y, conf, best_x, best_y, best_p, 0}
+#include "common.h"
+
+#define CC_STRIDE 12
+#define CC_HDR 8
+
+__device__ __forceinline__ int uf_find(const int* parent, int a) {
+  int p = parent[a];
+  while (p != a) {
+    a = p;
+    p = parent[a];
+  }
+  return a;
+}
+
+__device__ __forceinline__ void uf_union(int* parent, int a, int b) {
+  for (;;) {
+    a = uf_find(parent, a);
+    b = uf_find(parent, b);
+    if (a == b) return;
+    if (a < b) {
+      int t = a;
+      a = b;
+      b = t;
+    }
+    // a > b: hang a under b if a is still a root
+    int old = atomicMin(&parent[a], b);
+    if (old == a) return;
+    a = old;  // somebody re-parented a concurrently; retry from its new parent
+  }
+}
+
+__global__ void ccl_init_kernel(const uint8_t* __restrict__ pred, int n, int* __restrict__ parent, int* counters) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) {
+    counters[0] = 0;
+    counters[1] = 0;
+  }
+  if (i < n) parent[i] = pred[i] ? i : -1;
+}
+
+__global__ void ccl_merge_kernel(const uint8_t* __restrict__ pred, int H, int W, int* __restrict__ parent) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= W) return;
+  const int p = y * W + x;
+  if (!pred[p]) return;
+  if (x + 1 < W && pred[p + 1]) uf_union(parent, p, p + 1);
+  if (y + 1 < H) {
+    const int q = p + W;
+    if (x > 0 && pred[q - 1]) uf_union(parent, p, q - 1);
+    if (pred[q]) uf_union(parent, p, q);
+    if (x + 1 < W && pred[q + 1]) uf_union(parent, p, q + 1);
+  }
+}
+
+__global__ void ccl_flatten_kernel(int n, int* __restrict__ parent, int* __restrict__ roots, int cap, int* counters) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (parent[i] < 0) return;
+  const int r = uf_find(parent, i);
+  if (r == i) {
+    int k = atomicAdd(&counters[0], 1);
+    if (k < cap) roots[k] = i;
+  }
+}
+// second flatten pass (after all roots are final) so that parent[i] is the root itself
+__global__ void ccl_compress_kernel(int n, int* __restrict__ parent) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || parent[i] < 0) return;
+  parent[i] = uf_find(parent, i);
+}
+
+// one block: rank the (<= cap) collected roots ascending, label them 1..n, clear the accumulators
+__global__ __launch_bounds__(256) void ccl_rank_kernel(int* __restrict__ roots, int cap, const int* counters,
+                                                       int* __restrict__ labels, int* __restrict__ acc_i,
+                                                       unsigned long long* __restrict__ acc_u, double* __restrict__ acc_d) {
+  extern __shared__ int sroots[];
+  const int nall = counters[0];
+  const int n = nall < cap ? nall : cap;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) sroots[i] = roots[i];
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int r = sroots[i];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) rank += (sroots[j] < r);
+    labels[r] = rank + 1;
+    roots[rank] = r;  // sorted in place is unsafe in general; ranks are a permutation and sroots holds the originals
+  }
+  for (int k = threadIdx.x; k < cap; k += blockDim.x) {
+    acc_i[k * 5 + 0] = 0;            // area
+    acc_i[k * 5 + 1] = 0x7fffffff;   // min_x
+    acc_i[k * 5 + 2] = 0x7fffffff;   // min_y
+    acc_i[k * 5 + 3] = -1;           // max_x
+    acc_i[k * 5 + 4] = -1;           // max_y
+    acc_u[k * 3 + 0] = 0ull;         // sum_x
+    acc_u[k * 3 + 1] = 0ull;         // sum_y
+    acc_u[k * 3 + 2] = 0ull;         // best (ordered value << 32 | ~index)
+    acc_d[k] = 0.0;                  // conf sum
+  }
+}
+
+__device__ __forceinline__ uint32_t f2ord32(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f32(uint32_t u) {
+  return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+__global__ __launch_bounds__(256) void ccl_stats_kernel(const int* __restrict__ parent, int H, int W,
+                                                        const float* __restrict__ pfg, int* __restrict__ labels,
+                                                        int* __restrict__ acc_i, unsigned long long* __restrict__ acc_u,
+                                                        double* __restrict__ acc_d) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  int lab = 0;
+  float pv = 0.f;
+  int p = 0;
+  if (x < W) {
+    p = y * W + x;
+    const int r = parent[p];
+    if (r >= 0) {
+      lab = (r == p) ? labels[p] : labels[r];  // roots were labelled by ccl_rank_kernel (0 if beyond capacity)
+      pv = pfg[p];
+    }
+    if (r != p) labels[p] = lab;               // never rewrites a root's label (read by other threads)
+  }
+  unsigned long long todo = __ballot(lab != 0);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int L = __shfl(lab, leader, 64);
+    const bool in = (lab == L);
+    const unsigned long long mask = __ballot(in);
+    todo &= ~mask;
+    const int cnt = __popcll(mask);
+    float ps = wave_sum(in ? pv : 0.f);
+    int sx = in ? x : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sx += __shfl_xor(sx, o, 64);
+    unsigned long long key = in ? (((unsigned long long)f2ord32(pv) << 32) | (0xffffffffu - (uint32_t)p)) : 0ull;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      unsigned long long other = __shfl_xor(key, o, 64);
+      key = other > key ? other : key;
+    }
+    if (lane == leader) {
+      const int k = L - 1;
+      const int x0 = x - lane;
+      const int mnx = x0 + (__ffsll((long long)mask) - 1), mxx = x0 + 63 - __clzll((long long)mask);
+      atomicAdd(&acc_i[k * 5 + 0], cnt);
+      atomicMin(&acc_i[k * 5 + 1], mnx);
+      atomicMin(&acc_i[k * 5 + 2], y);
+      atomicMax(&acc_i[k * 5 + 3], mxx);
+      atomicMax(&acc_i[k * 5 + 4], y);
+      atomicAdd(&acc_u[k * 3 + 0], (unsigned long long)sx);
+      atomicAdd(&acc_u[k * 3 + 1], (unsigned long long)y * (unsigned long long)cnt);
+      atomicMax(&acc_u[k * 3 + 2], key);
+      atomicAdd(&acc_d[k], (double)ps);
+    }
+  }
+}
+
+__global__ void ccl_finalize_kernel(const int* counters, int cap, int W, const int* __restrict__ acc_i,
+                                    const unsigned long long* __restrict__ acc_u, const double* __restrict__ acc_d,
+                                    const int* __restrict__ fg_sum, double* __restrict__ tab) {
+  const int nall = counters[0];
+  const int n = nall < cap ? nall : cap;
+  __shared__ double total_s;
+  if (threadIdx.x == 0) {
+    long long tot = 0;
+    if (fg_sum) {
+      tot = fg_sum[0];
+    } else {
+      for (int k = 0; k < n; ++k) tot += acc_i[k * 5];
+    }
+    total_s = (double)tot;
+    tab[0] = (double)nall;
+    tab[1] = (double)n;
+    tab[2] = (double)tot;
+  }
+  __syncthreads();
+  // util/utils.py:490: conf = sum(p * [label == j]) / (sum(pred) + 1e-6), evaluated in fp32 by numpy
+  const float den = (float)total_s + 1e-6f;
+  for (int k = threadIdx.x; k < n; k += blockDim.x) {
+    double* t = tab + CC_HDR + (size_t)k * CC_STRIDE;
+    const unsigned long long key = acc_u[k * 3 + 2];
+    const int bidx = (int)(0xffffffffu - (uint32_t)(key & 0xffffffffull));
+    t[0] = (double)acc_i[k * 5 + 0];
+    t[1] = (double)acc_u[k * 3 + 0];
+    t[2] = (double)acc_u[k * 3 + 1];
+    t[3] = (double)acc_i[k * 5 + 1];
+    t[4] = (double)acc_i[k * 5 + 2];
+    t[5] = (double)acc_i[k * 5 + 3];
+    t[6] = (double)acc_i[k * 5 + 4];
+    t[7] = (double)((float)acc_d[k] / den);
+    t[8] = (double)(bidx % W);
+    t[9] = (double)(bidx / W);
+    t[10] = (double)ord2f32((uint32_t)(key >> 32));
+    t[11] = 0.0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // util/utils.py:510-515: first component with strictly larger confidence wins
+    int best = 0;
+    double bc = -1.0;
+    for (int k = 0; k < n; ++k) {
+      double c = tab[CC_HDR + (size_t)k * CC_STRIDE + 7];
+      if (c > bc) {
+        bc = c;
+        best = k;
+      }
+    }
+    tab[3] = (double)best;
+  }
+}
+
+// pred u8 [H,W]; pfg fp32 [H,W]; labels int32 [H,W] (out); parent int32 [H*W] scratch; scratch: int32 area of
+// 2 + cap + 5*cap ints, then 8-byte aligned 3*cap u64 + cap doubles (see protosam_amd/ops.py: CclWorkspace).
+extern "C" int psam_ccl(const void* pred, const float* pfg, int H, int W, int cap, int* labels, int* parent, int* counters,
+                        int* roots, int* acc_i, void* acc_u, double* acc_d, const int* fg_sum, double* tab, void* stream) {
+  if (H <= 0 || W <= 0 || cap <= 0 || cap > 4096) return PSAM_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int n = H * W;
+  const uint8_t* pr = (const uint8_t*)pred;
+  (void)hipMemsetAsync(labels, 0, (size_t)n * sizeof(int), s);
+  hipLaunchKernelGGL(ccl_init_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pr, n, parent, counters);
+  hipLaunchKernelGGL(ccl_merge_kernel, dim3((W + 255) / 256, H), dim3(256), 0, s, pr, H, W, parent);
+  hipLaunchKernelGGL(ccl_flatten_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, parent, roots, cap, counters);
+  hipLaunchKernelGGL(ccl_compress_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, parent);
+  hipLaunchKernelGGL(ccl_rank_kernel, dim3(1), dim3(256), cap * sizeof(int), s, roots, cap, counters, labels, acc_i,
+                     (unsigned long long*)acc_u, acc_d);
+  hipLaunchKernelGGL(ccl_stats_kernel, dim3((W + 255) / 256, H), dim3(256), 0, s, parent, H, W, pfg, labels, acc_i,
+                     (unsigned long long*)acc_u, acc_d);
+  hipLaunchKernelGGL(ccl_finalize_kernel, dim3(1), dim3(256), 0, s, counters, cap, W, acc_i,
+                     (const unsigned long long*)acc_u, acc_d, fg_sum, tab);
+  return psam_launch_status();
+}

@@ -350,3 +350,30 @@ def normalize_chw(x, mean3, std3, out=None):
                                       x.shape[2] * x.shape[3], m, s, _ptr(out), _stream())
     _lib.check(st, "psam_normalize_chw")
     return out
+
+
+# ---- connected components --------------------------------------------------------------------------------------
+CC_HDR, CC_STRIDE = 8, 12
+
+
+class CclWorkspace:
+    def __init__(self, H, W, cap, device):
+        n = H * W
+        self.H, self.W, self.cap = H, W, cap
+        i32 = lambda k: torch.empty(k, dtype=torch.int32, device=device)  # noqa: E731
+        self.parent, self.labels, self.counters, self.roots, self.acc_i = i32(n), i32(n), i32(2), i32(cap), i32(5 * cap)
+        self.acc_u = torch.empty(3 * cap, dtype=torch.int64, device=device)
+        self.acc_d = torch.empty(cap, dtype=torch.float64, device=device)
+        self.tab = torch.zeros(CC_HDR + CC_STRIDE * cap, dtype=torch.float64, device=device)
+        self.tab_host = torch.empty(CC_HDR + CC_STRIDE * cap, dtype=torch.float64).pin_memory()
+
+
+def ccl(pred_u8, pfg, ws, fg_sum=None):
+    """pred uint8 [H,W], pfg fp32 [H,W] -> ws.labels (int32 [H*W]) and ws.tab (fp64 table, see csrc/ccl.hip)."""
+    assert pred_u8.dtype == torch.uint8 and pred_u8.is_cuda and pred_u8.is_contiguous()
+    _req(pfg, torch.float32, "pfg")
+    st = _lib.lib().psam_ccl(_ptr(pred_u8), _ptr(pfg), ws.H, ws.W, ws.cap, _ptr(ws.labels), _ptr(ws.parent),
+                            _ptr(ws.counters), _ptr(ws.roots), _ptr(ws.acc_i), _ptr(ws.acc_u), _ptr(ws.acc_d),
+                            _ptr(fg_sum), _ptr(ws.tab), _stream())
+    _lib.check(st, "psam_ccl")
+    return ws

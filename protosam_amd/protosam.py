@@ -1,0 +1,325 @@
+"""`ProtoSAM` pipeline on the HIP path, with the reference's class API.
+
+Mirrors /root/reference/models/ProtoSAM.py: `ALPNetInput` (:59-79), `ALPNetOutput` (:81-92), `InputFactory` (:112-130),
+`ModelWrapper` / `ALPNetWrapper` (:133-168) and `ProtoSAM` (:184-678) with the same constructor arguments, the same
+`forward(query_image, coarse_model_input, degrees_rotate=0) -> (pred [H,W] float {0,1} on device, scores list)`
+contract, the same ValueError / AssertionError conditions.
+
+What changes is where the work happens. The reference leaves the GPU four times per slice (argmax -> numpy -> cv2
+connected components -> per-component python loops -> uint8 image -> `predictor.set_image` -> one `predict` per
+component -> numpy -> tensor; ProtoSAM.py:602-676). Here every stage stays on the device:
+
+  coarse logits --prob_argmax--> output_p, pred(u8) --ccl--> labels + per-component table (area, bbox, centroid sums,
+  confidence, most-confident pixel) --async D2H of the table only-->           (host: number of components, prompts)
+  query --bilinear 1024--> minmax --quantise+normalise+im2col--> SAM image encoder        (enqueued BEFORE the host waits
+  for the table, so the wait overlaps the encoder)  --> prompt tokens --> batched two-way decoder over all components
+  --> fused upsample / threshold / union / nearest-resize --> pred.
+
+Unsupported (outside SURVEY §8's hot path, raise NotImplementedError): `use_mask=True` (mask prompts), `use_neg_points`,
+`degrees_rotate != 0`, `debug` plotting, training mode.
+"""
+import os
+from abc import ABC, abstractmethod
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .grid_proto_fewshot import FewShotSeg
+from .segment_anything import SamPredictor, sam_model_registry
+from .segment_anything.utils.transforms import ResizeLongestSide
+
+CONF_MODE = "conf"
+CENTROID_MODE = "centroid"
+BOTH_MODE = "both"
+POINT_MODES = (CONF_MODE, CENTROID_MODE, BOTH_MODE)
+
+TYPE_ALPNET = "alpnet"
+TYPE_SAM = "sam"
+
+MAX_COMPONENTS = 256
+
+
+class SegmentationInput(ABC):
+    @abstractmethod
+    def set_query_images(self, query_images):
+        pass
+
+    def to(self, device):
+        pass
+
+
+class SegmentationOutput(ABC):
+    @abstractmethod
+    def get_prediction(self):
+        pass
+
+
+class ALPNetInput(SegmentationInput):
+    def __init__(self, support_images, support_labels, query_images, isval, val_wsize, show_viz=False, supp_fts=None):
+        self.supp_imgs = [support_images]
+        self.fore_mask = [support_labels]
+        self.back_mask = [[1 - sup_labels for sup_labels in support_labels]]
+        self.qry_imgs = [query_images]
+        self.isval = isval
+        self.val_wsize = val_wsize
+        self.show_viz = show_viz
+        self.supp_fts = supp_fts
+
+    def set_query_images(self, query_images):
+        self.qry_imgs = [query_images]
+
+    def to(self, device):
+        self.supp_imgs = [[supp_img.to(device) for way in self.supp_imgs for supp_img in way]]
+        self.fore_mask = [[fore_mask.to(device) for way in self.fore_mask for fore_mask in way]]
+        self.back_mask = [[back_mask.to(device) for way in self.back_mask for back_mask in way]]
+        self.qry_imgs = [qry_img.to(device) for qry_img in self.qry_imgs]
+        if self.supp_fts is not None:
+            self.supp_fts = self.supp_fts.to(device)
+
+
+class ALPNetOutput(SegmentationOutput):
+    def __init__(self, pred, align_loss, sim_maps, assign_maps, proto_grid, supp_fts, qry_fts):
+        self.pred = pred
+        self.align_loss = align_loss
+        self.sim_maps = sim_maps
+        self.assign_maps = assign_maps
+        self.proto_grid = proto_grid
+        self.supp_fts = supp_fts
+        self.qry_fts = qry_fts
+
+    def get_prediction(self):
+        return self.pred
+
+
+class InputFactory(ABC):
+    @staticmethod
+    def create_input(input_type, query_image, support_images=None, support_labels=None, isval=False, val_wsize=None,
+                     show_viz=False, supp_fts=None, original_sz=None, img_sz=None, gts=None):
+        if input_type == TYPE_ALPNET:
+            return ALPNetInput(support_images, support_labels, query_image, isval, val_wsize, show_viz, supp_fts)
+        elif input_type == TYPE_SAM:
+            raise NotImplementedError("TYPE_SAM inputs feed SamWrapperWrapper, which validation_protosam.get_model "
+                                      "cannot reach (validation_protosam.py:208-213)")
+        else:
+            raise ValueError("input_type not supported")
+
+
+class ModelWrapper(ABC):
+    def __init__(self, model):
+        self.model = model
+
+    def __call__(self, input_data):
+        pass
+
+    def state_dict(self):
+        return self.model.state_dict()
+
+    def load_state_dict(self, state_dict):
+        self.model.load_state_dict(state_dict)
+
+    def eval(self):
+        self.model.eval()
+
+    def train(self):
+        self.model.train()
+
+    def parameters(self):
+        pass
+
+
+class ALPNetWrapper(ModelWrapper):
+    def __init__(self, model: FewShotSeg):
+        super().__init__(model)
+
+    def __call__(self, input_data: ALPNetInput):
+        output = self.model(**input_data.__dict__)
+        output = ALPNetOutput(*output)
+        return output.pred
+
+    def parameters(self):
+        return self.model.encoder.parameters()
+
+    def train(self):
+        self.model.encoder.train()
+
+
+class ProtoSAM(nn.Module):
+    def __init__(self, image_size, coarse_segmentation_model: ModelWrapper,
+                 sam_pretrained_path="pretrained_model/sam_default.pth", num_points_for_sam=1, use_points=True,
+                 use_bbox=False, use_mask=False, debug=False, use_cca=False, point_mode=CONF_MODE, use_sam_trans=True,
+                 coarse_pred_only=False, alpnet_image_size=None, use_neg_points=False):
+        super().__init__()
+        if isinstance(image_size, int):
+            image_size = (image_size, image_size)
+        self.image_size = image_size
+        self.coarse_segmentation_model = coarse_segmentation_model
+        self.get_sam(sam_pretrained_path, use_sam_trans)
+        self.num_points_for_sam = num_points_for_sam
+        self.use_points = use_points
+        self.use_bbox = use_bbox
+        self.use_mask = use_mask
+        self.use_neg_points = use_neg_points
+        assert self.use_bbox or self.use_points or self.use_mask, "must use at least one of bbox, points, or mask"
+        self.use_cca = use_cca
+        self.point_mode = point_mode
+        if self.point_mode not in POINT_MODES:
+            raise ValueError(f"point mode must be one of {POINT_MODES}")
+        self.debug = debug
+        self.coarse_pred_only = coarse_pred_only
+        if use_mask or use_neg_points or debug or num_points_for_sam != 1:
+            raise NotImplementedError("use_mask / use_neg_points / debug / num_points_for_sam != 1 are outside the hot path")
+        if tuple(self.image_size) != (1024, 1024):
+            raise NotImplementedError("image_size must be (1024, 1024) as in validation_protosam.py:220")
+        self._ccl = None
+        self._bufs = {}
+        self.last_stats = {}
+
+    def get_sam(self, checkpoint_path, use_sam_trans):
+        """ProtoSAM.py:205-220. `random:<vit_b|vit_l|vit_h>[:seed[:depth]]` builds seeded synthetic weights instead of reading a
+        checkpoint (none exist offline)."""
+        model_type = "vit_b"
+        if checkpoint_path is not None and "vit_h" in checkpoint_path:
+            model_type = "vit_h"
+        if checkpoint_path is not None and checkpoint_path.startswith("random:"):
+            from .synth import synth_state_dict
+            parts = checkpoint_path.split(":")
+            model_type = parts[1]
+            seed = int(parts[2]) if len(parts) > 2 else 1234
+            depth = int(parts[3]) if len(parts) > 3 else None   # test hook: truncated block stack
+            self.sam = sam_model_registry[model_type](encoder_depth=depth)
+            self.sam.load_state_dict(synth_state_dict(self.sam, seed))
+            self.sam.eval()
+        else:
+            self.sam = sam_model_registry[model_type](checkpoint=checkpoint_path).eval()
+        self.predictor = SamPredictor(self.sam)
+        self.sam.requires_grad_(False)
+        if use_sam_trans:
+            sam_trans = ResizeLongestSide(self.sam.image_encoder.img_size)
+            sam_trans.pixel_mean = torch.tensor([0, 0, 0]).view(3, 1, 1)
+            sam_trans.pixel_std = torch.tensor([1, 1, 1]).view(3, 1, 1)
+        else:
+            sam_trans = None
+        self.sam_trans = sam_trans
+
+    # ---- host-side prompt assembly from the component table -----------------------------------------------------------
+    def _prompts_from_table(self, tab):
+        """tab: fp64 numpy table of csrc/ccl.hip. Returns coords fp32 [n, Ns, 2], labels int32 [n, Ns] in the prompt
+        kernel's convention (1 = positive point, 2/3 = box corners, -1 = padding point) following
+        get_sam_input_points (:349-450), get_bbox_per_cc (:242-264) and PromptEncoder's padding rule."""
+        n = int(tab[1])
+        rows = tab[ops.CC_HDR:ops.CC_HDR + ops.CC_STRIDE * n].reshape(n, ops.CC_STRIDE)
+        if self.use_cca:  # util/utils.py:496-541: keep the most confident component only
+            rows = rows[int(tab[3]):int(tab[3]) + 1]
+        coords, labels = [], []
+        for r in rows:
+            c, lab = [], []
+            if self.use_points:
+                if self.point_mode in (CONF_MODE, BOTH_MODE):
+                    c.append([r[8], r[9]])
+                    lab.append(1)
+                if self.point_mode in (CENTROID_MODE, BOTH_MODE):
+                    c.append([r[1] / r[0], r[2] / r[0]])  # cv2 centroid: float64 mean of x, mean of y
+                    lab.append(1)
+                if not self.use_bbox:
+                    c.append([0.0, 0.0])
+                    lab.append(-1)
+            if self.use_bbox:
+                c += [[r[3], r[4]], [r[5], r[6]]]
+                lab += [2, 3]
+            coords.append(c)
+            labels.append(lab)
+        # predictor.predict: apply_coords with original_size == 1024 is the identity; torch.as_tensor(dtype=float)
+        return np.asarray(coords, dtype=np.float64).astype(np.float32), np.asarray(labels, dtype=np.int32), rows
+
+    def _work_buffers(self, dev, H):
+        key = (str(dev), H)
+        if key not in self._bufs:
+            self._bufs[key] = dict(
+                fg_sum=torch.zeros(1, dtype=torch.int32, device=dev),
+                prob=torch.empty((1, 2, 1024, 1024), dtype=torch.float32, device=dev),
+                pred=torch.empty((1, 1024, 1024), dtype=torch.uint8, device=dev),
+                q1024=torch.empty((1, 3, 1024, 1024), dtype=torch.float32, device=dev),
+                mm=torch.empty(2, dtype=torch.int32, device=dev),
+                patches=torch.empty((4096, 768), dtype=torch.float16, device=dev),
+                event=torch.cuda.Event())
+        if self._ccl is None:
+            self._ccl = ops.CclWorkspace(1024, 1024, MAX_COMPONENTS, dev)
+        return self._bufs[key]
+
+    def forward(self, query_image, coarse_model_input, degrees_rotate=0):
+        if degrees_rotate != 0:
+            raise NotImplementedError("rotation TTA (util/utils.py:40-83) is outside the hot path")
+        if self.training:
+            raise NotImplementedError("training-mode outputs (logits) are outside the inference hot path")
+        original_size = query_image.shape[-2]
+        dev = query_image.device
+        coarse_model_input.set_query_images(query_image)
+        output_logits = self.coarse_segmentation_model(coarse_model_input)      # [1,2,H,W]
+        if self.coarse_pred_only:
+            return self._coarse_only(output_logits, original_size)
+        bufs = self._work_buffers(dev, original_size)
+        sam = self.sam
+        S = sam.image_encoder.img_size
+        # 1. (bilinear to 1024) -> softmax -> argmax                               ProtoSAM.py:592-602
+        bufs["fg_sum"].zero_()
+        output_p, pred = ops.prob_argmax(output_logits.float().contiguous(), S, S, prob=bufs["prob"], pred=bufs["pred"],
+                                         fg_sum=bufs["fg_sum"])
+        # 2. connected components + per-component statistics, table -> pinned host memory (async)
+        cw = ops.ccl(pred[0], output_p[0, 1], self._ccl, fg_sum=bufs["fg_sum"])
+        cw.tab_host.copy_(cw.tab, non_blocking=True)
+        bufs["event"].record()
+        # 3. image hand-off: resize -> min/max -> uint8 quantise -> SAM normalise -> im2col      ProtoSAM.py:592-593,651-660
+        q = query_image.float().contiguous()
+        if tuple(q.shape[-2:]) != (S, S):
+            q = ops.bilinear_nchw(q, S, S, out=bufs["q1024"])
+        ops.minmax(q, 1, mm=bufs["mm"])
+        ops.sam_patchify(q, bufs["mm"], S, sam.image_encoder.patch_size, sam._mean_host, sam._std_host, True,
+                         out=bufs["patches"])
+        # 4. SAM image encoder (enqueued before the host looks at the component table)
+        feat_tok = sam.image_encoder.encode_patches(bufs["patches"], 1)[0]       # [4096, 256] token-major
+        # 5. host: number of components and prompts
+        bufs["event"].synchronize()
+        tab = cw.tab_host.numpy()
+        n_found, n = int(tab[0]), int(tab[1])
+        self.last_stats = dict(n_components=n_found, fg_pixels=int(tab[2]))
+        if n == 0:                                                              # ProtoSAM.py:612-613
+            return output_p.argmax(dim=1)[0], [0]
+        coords, labels, rows = self._prompts_from_table(tab)
+        B, Ns = labels.shape
+        pe = sam.prompt_encoder._packed()
+        dpk = sam.mask_decoder._packed()
+        tokens = ops.prompt_tokens(torch.from_numpy(coords).to(dev, non_blocking=True),
+                                   torch.from_numpy(labels).to(dev, non_blocking=True), pe["G"], pe["type_emb"],
+                                   dpk["out_tok"], B, Ns, float(S))
+        # 6. batched two-way decoder over all components                         ProtoSAM.py:500-527
+        masks, iou, _ = sam.mask_decoder.predict_masks_tokens(feat_tok, pe["pe_tok"], tokens, pe["no_mask"])
+        sel = 0 if self.use_cca else 1                                          # multimask_output = not use_cca; index 0
+        # 7. upsample -> > 0 -> union over components -> nearest to the input size   ProtoSAM.py:669-676
+        out = ops.mask_union(masks, sel, S, original_size, sam.variant_id(), sam.mask_threshold)
+        scores = [np.float32(v) for v in iou[:, sel].cpu().numpy()]
+        self.last_stats.update(n_prompts=B, low_res=masks, iou=iou, sel=sel, table=rows)
+        return out, scores
+
+    def _coarse_only(self, output_logits, original_size):
+        """ProtoSAM.py:580-590 (inference): argmax map, mean fg confidence; optional CCA keeps the best component."""
+        dev = output_logits.device
+        H = output_logits.shape[-2]
+        if H != 1024:
+            raise NotImplementedError("coarse_pred_only is wired for 1024x1024 logits only")
+        bufs = self._work_buffers(dev, original_size)
+        bufs["fg_sum"].zero_()
+        prob, pred = ops.prob_argmax(output_logits.float().contiguous(), H, H, prob=bufs["prob"], pred=bufs["pred"],
+                                     fg_sum=bufs["fg_sum"])
+        cw = ops.ccl(pred[0], prob[0, 1], self._ccl, fg_sum=bufs["fg_sum"])
+        tab = cw.tab.cpu().numpy()
+        n = int(tab[1])
+        rows = tab[ops.CC_HDR:ops.CC_HDR + ops.CC_STRIDE * n].reshape(n, ops.CC_STRIDE)
+        if not self.use_cca:
+            return pred[0].long(), [float(rows[:, 7].sum())]
+        if n == 0:
+            return pred[0].long() * 0, [0]
+        k = int(tab[3])
+        keep = (cw.labels.view(H, H) == (k + 1)).long()
+        return keep, [float(rows[k, 7])]

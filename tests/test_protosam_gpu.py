@@ -1,0 +1,155 @@
+"""GPU parity of the glue kernels (connected components, prompts, image hand-off) and of the whole
+ProtoSAM.forward path against the CPU oracle on the same seeded support/query pair."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CFG = {"which_model": "dinov2_b14", "cls_name": "grid_proto", "proto_grid_size": 8, "lora": 0, "align": False,
+       "debug": False}
+
+
+def _blobs(seed, H=1024, W=1024, thr=0.15):
+    g = torch.Generator().manual_seed(seed)
+    f = torch.randn((1, 1, H // 64, W // 64), generator=g)
+    f = torch.nn.functional.interpolate(f, size=(H, W), mode="bilinear")[0, 0]
+    return f
+
+
+@pytest.mark.parametrize("seed,thr", [(0, 0.6), (1, 0.2), (2, 1.5), (3, 99.0)])
+def test_ccl_table_matches_oracle(dev, seed, thr):
+    from oracle import glue
+    from protosam_amd import ops
+    f = _blobs(seed)
+    pred = (f > thr).to(torch.uint8)
+    pfg = torch.sigmoid(f)
+    ws = ops.CclWorkspace(1024, 1024, 1024, dev)
+    fg = pred.sum().to(torch.int32).reshape(1).to(dev)
+    ops.ccl(pred.to(dev).contiguous(), pfg.to(dev).contiguous(), ws, fg_sum=fg)
+    tab = ws.tab.cpu().numpy()
+    labels = ws.labels.cpu().numpy().reshape(1024, 1024)
+    n_ref, lab_ref, stats, cent = glue.connected_components_with_stats(pred.numpy())
+    assert int(tab[0]) == n_ref - 1 and int(tab[1]) == n_ref - 1
+    assert np.array_equal(labels, lab_ref)  # same numbering rule: raster order of the first pixel
+    p = pfg.numpy()
+    for k in range(n_ref - 1):
+        r = tab[ops.CC_HDR + ops.CC_STRIDE * k: ops.CC_HDR + ops.CC_STRIDE * (k + 1)]
+        m = lab_ref == k + 1
+        assert int(r[0]) == stats[k + 1, 4]
+        assert (int(r[3]), int(r[4])) == (stats[k + 1, 0], stats[k + 1, 1])
+        assert (int(r[5]), int(r[6])) == (stats[k + 1, 0] + stats[k + 1, 2] - 1, stats[k + 1, 1] + stats[k + 1, 3] - 1)
+        assert abs(r[1] / r[0] - cent[k + 1, 0]) < 1e-9 and abs(r[2] / r[0] - cent[k + 1, 1]) < 1e-9
+        pt, conf = glue.most_conf_point(p, m)
+        assert (int(r[8]), int(r[9])) == (pt[0, 0], pt[0, 1]) and abs(r[10] - conf[0]) < 1e-7
+        cref = (p * m).sum() / (pred.sum().item() + 1e-6)
+        assert abs(r[7] - cref) < 1e-5 * max(1.0, abs(cref))
+
+
+def test_image_handoff_quantise(dev):
+    """min-max -> uint8 truncation must match numpy bit for bit (ProtoSAM.py:660)."""
+    from oracle import glue
+    from protosam_amd import ops
+    from protosam_amd.synth import synth_pair
+    _, _, q, _ = synth_pair(512, seed=5)
+    q1024 = torch.nn.functional.interpolate(q, size=(1024, 1024), mode="bilinear")
+    ref_u8 = glue.quantise_image(q1024)                     # HWC uint8
+    qd = ops.bilinear_nchw(q.to(dev), 1024, 1024)
+    torch.testing.assert_close(qd.cpu(), q1024, rtol=1e-6, atol=1e-6)
+    mm = ops.minmax(qd, 1)
+    u8 = torch.empty((1, 3, 1024, 1024), dtype=torch.uint8, device=dev)
+    patches = ops.sam_patchify(qd, mm, 1024, 16, (123.675, 116.28, 103.53), (58.395, 57.12, 57.375), True, u8out=u8)
+    got = u8[0].permute(1, 2, 0).cpu().numpy()
+    mism = (got != ref_u8).mean()
+    assert mism < 1e-4, mism   # identical unless the upstream bilinear differs by an ulp at a truncation boundary
+    ref_x = glue.sam_preprocess(got)                        # normalise the SAME uint8 image
+    ref_p = ref_x[0].reshape(3, 64, 16, 64, 16).permute(1, 3, 0, 2, 4).reshape(4096, 768)
+    torch.testing.assert_close(patches.float().cpu(), ref_p, rtol=2e-3, atol=2e-3)
+
+
+def _build(dev, sam_spec, dino_depth=None, **kw):
+    from protosam_amd.grid_proto_fewshot import FewShotSeg
+    from protosam_amd.protosam import ALPNetWrapper, ProtoSAM
+    from protosam_amd.synth import synth_state_dict
+    cfg = dict(CFG)
+    if dino_depth is not None:
+        cfg["encoder_depth"] = dino_depth
+    alp = FewShotSeg(512, None, cfg)
+    alp_sd = synth_state_dict(alp, 1234)
+    alp.load_state_dict(alp_sd)
+    alp = alp.to(dev).eval()
+    model = ProtoSAM(image_size=(1024, 1024), coarse_segmentation_model=ALPNetWrapper(alp), sam_pretrained_path=sam_spec,
+                     num_points_for_sam=1, use_sam_trans=True, **kw).to(dev).eval()
+    return model, alp_sd
+
+
+def _dice(a, b):
+    a, b = a.float(), b.float()
+    tp = (a * b).sum()
+    return (2 * tp / (2 * tp + ((1 - a) * b).sum() + (a * (1 - b)).sum() + 1e-8)).item()
+
+
+@pytest.mark.parametrize("kw", [dict(use_bbox=True, use_points=True, point_mode="both", use_cca=False),
+                                dict(use_bbox=True, use_points=True, point_mode="both", use_cca=True),
+                                dict(use_bbox=False, use_points=True, point_mode="conf", use_cca=False)])
+def test_protosam_forward_vs_oracle(dev, kw):
+    from oracle import alp as oalp, dinov2 as odino, glue
+    from protosam_amd.protosam import InputFactory, TYPE_ALPNET
+    from protosam_amd.synth import synth_pair, synth_state_dict
+    sam_depth, dino_depth = 3, 12
+    model, alp_sd = _build(dev, f"random:vit_b:1234:{sam_depth}", dino_depth, **kw)
+    sam_sd = {k: v.cpu() for k, v in synth_state_dict(model.sam, 1234).items()}
+    s_img, s_m, q_img, q_gt = synth_pair(512, seed=0)
+    inp = InputFactory.create_input(TYPE_ALPNET, q_img, support_images=[s_img], support_labels=[s_m], isval=True,
+                                    val_wsize=2)
+    inp.to(dev)
+    pred, scores = model(q_img.to(dev), inp, degrees_rotate=0)
+    assert pred.shape == (512, 512) and pred.dtype == torch.float32 and pred.is_cuda
+    st = model.last_stats
+    # --- independent oracle pipeline ---------------------------------------------------------------------------------
+    enc_sd = {k[len("encoder."):]: v for k, v in alp_sd.items() if k.startswith("encoder.")}
+    enc = lambda im: odino.forward_features(im, enc_sd, "dinov2_b14", depth=dino_depth)["x_norm_patchtokens"]  # noqa
+    logits_ref = oalp.fewshot_forward(enc, s_img, s_m, q_img, 512)
+    taps = {}
+    pred_ref, scores_ref = glue.protosam_forward(q_img, logits_ref, sam_sd, "vit_b", use_bbox=kw["use_bbox"],
+                                                 use_points=kw["use_points"], point_mode=kw["point_mode"],
+                                                 use_cca=kw["use_cca"], encoder_depth=sam_depth, taps=taps)
+    n_ref = 1 if kw["use_cca"] else taps["cc"][0] - 1
+    assert st["n_prompts"] == n_ref and len(scores) == len(scores_ref)
+    low = st["low_res"][:, st["sel"]].cpu()
+    low_ref = torch.stack([l[0] for l in taps["low_res"]])
+    perr = (torch.sigmoid(low) - torch.sigmoid(low_ref)).abs().max().item()
+    d = _dice(pred.cpu(), pred_ref)
+    flips = (pred.cpu() != pred_ref).sum().item()
+    print(f"{kw}: comps {n_ref}, max |dprob(low_res)| {perr:.3e}, final Dice {d:.5f}, flipped px {flips}, "
+          f"scores {np.abs(np.array(scores) - np.array(scores_ref)).max():.2e}, fg frac {pred_ref.mean():.3f}")
+    assert d > 0.995
+    assert perr < 2e-2
+    assert np.abs(np.array(scores, dtype=np.float64) - np.array(scores_ref)).max() < 5e-3
+
+
+def test_protosam_empty_coarse_mask(dev):
+    """Q21: an empty coarse mask returns the 1024x1024 arg-max map and [0] (ProtoSAM.py:612-613)."""
+    from protosam_amd.protosam import InputFactory, TYPE_ALPNET
+    from protosam_amd.synth import synth_pair
+    model, _ = _build(dev, "random:vit_b:1234:1", 1, use_bbox=True, use_points=True, point_mode="both")
+    s_img, s_m, q_img, _ = synth_pair(512, seed=0)
+
+    class Zero:  # coarse model that predicts background everywhere
+        def __call__(self, inp):
+            z = torch.zeros((1, 2, 512, 512), device=dev)
+            z[:, 0] = 5.0
+            return z
+    model.coarse_segmentation_model = Zero()
+    inp = InputFactory.create_input(TYPE_ALPNET, q_img, support_images=[s_img], support_labels=[s_m], isval=True,
+                                    val_wsize=2)
+    pred, scores = model(q_img.to(dev), inp)
+    assert pred.shape == (1024, 1024) and pred.dtype == torch.int64 and int(pred.sum()) == 0 and scores == [0]
+
+
+def test_protosam_constructor_errors():
+    from protosam_amd.protosam import ProtoSAM
+    with pytest.raises(AssertionError):
+        ProtoSAM((1024, 1024), None, "random:vit_b:1:0", use_points=False, use_bbox=False, use_mask=False)
+    with pytest.raises(ValueError):
+        ProtoSAM((1024, 1024), None, "random:vit_b:1:0", point_mode="nearest")
