@@ -1,0 +1,129 @@
+/* protosam_hip.h -- C ABI of libprotosam_hip.so (hand-written gfx950 / CDNA4 kernels for ProtoSAM's hot path).
+ *
+ * The reference (levayz/ProtoSAM) is pure Python on PyTorch and has no FFI layer: its drop-in boundary is the Python
+ * class API (`ProtoSAM.forward`, `FewShotSeg`, `MultiProtoAsConv`, `sam_model_registry`, `SamPredictor`, ...; see
+ * SURVEY.md 8b), mirrored by the `protosam_amd` package. This header is the native boundary underneath it: each entry
+ * point replaces one chain of stock torch ops of the reference and cites it (paths relative to the reference repo).
+ *
+ * Conventions: plain pointers and sizes only (no torch types). All pointers are DEVICE pointers unless marked
+ * "host". No ownership transfer: the caller allocates every buffer. `stream` is a hipStream_t (0 = default stream);
+ * launches are asynchronous on it. Every function returns 0 on success, 1 = bad argument, 2 = launch error.
+ * "half" = IEEE fp16 (`_Float16`). Matrices are row-major with the stated leading dimension in ELEMENTS.
+ */
+#ifndef PROTOSAM_HIP_H
+#define PROTOSAM_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- contraction engine --------------------------------------------------------------------------------------
+ * out[M,N] = epi(A[M,K] . W[N,K]^T + bias[N]); A, W half (K contiguous), fp32 accumulate on MFMA.
+ * epilogue 0: half out;  1: half out = gelu_erf(.);  2: fp32 out = (resid ? resid[r,:] : 0) + (gamma ? gamma : 1)*(.)
+ *   resid row r = resid_mod ? m % resid_mod : m.  out row = out_seg ? (m/out_seg)*out_seg_stride + out_seg_off + m%out_seg : m.
+ * N % 128 == 0, K % 64 == 0. Replaces every nn.Linear / 1x1 conv / patch-embed conv / ConvTranspose2d(2,2) GEMM:
+ *   models/segment_anything/modeling/image_encoder.py:223-249 (qkv, proj), modeling/common.py:13-26 (MLPBlock),
+ *   image_encoder.py:375-406 (PatchEmbed), :90-106 (neck), modeling/transformer.py:218-240 (image-side projections),
+ *   modeling/mask_decoder.py:53-55 (first ConvTranspose2d); DINOv2 Attention/Mlp/PatchEmbed (hub model, call site
+ *   models/grid_proto_fewshot.py:88-91). */
+int psam_gemm_f16(const void* A, const void* W, const float* bias, void* out, const float* resid, const float* gamma,
+                  int M, int N, int K, int lda, int ldw, int ldo, int ldr, int resid_mod, int out_seg,
+                  int out_seg_stride, int out_seg_off, int epilogue, void* stream);
+
+/* Row LayerNorm, fp32 in; out_dtype 0: half out (+ optional fp32 copy y2), 1: fp32 out. Appends `zero_tail_rows`
+ * all-zero rows. torch.nn.LayerNorm of image_encoder.py:174-193, transformer.py:133-144 and LayerNorm2d
+ * (modeling/common.py:31-43) on token-major rows; DINOv2 norm1/norm2/norm. */
+int psam_layernorm(const float* x, const float* w, const float* b, void* y, float* y2, int M, int D, int ldx, int ldy,
+                   float eps, int out_dtype, int zero_tail_rows, void* stream);
+
+/* Fused multi-head attention on the packed projection qkv half [B,N,3,H,hd] -> out half [B,N,H*hd]; hd in {64, 80}.
+ * mode 0 global (DINOv2 Attention); mode 1 global + decomposed rel-pos (gw == 64); mode 2 ws x ws windows with the
+ * reference's zero padding (pad_row half [3,H,hd] = qkv bias) + rel-pos.
+ * image_encoder.py:235-251 (Attention.forward), :254-300 (window_partition / unpartition), :337-372. */
+int psam_attention_f16(const void* qkv, void* out, const float* rel_h, const float* rel_w, const void* pad_row, int B,
+                       int N, int H, int hd, float scale, int mode, int gh, int gw, int ws, void* stream);
+
+/* rel_h[b,h,n,k] = q . Rh[qy - k + K-1], rel_w likewise (UNSCALED q); fp32 [B,H,N,64] (global) or [B,H,N,16] (windowed).
+ * image_encoder.py:303-372 (get_rel_pos, add_decomposed_rel_pos). */
+int psam_relpos(const void* qkv, const float* Rh, const float* Rw, float* rel_h, float* rel_w, int B, int N, int H,
+                int hd, int gw, int K, int windowed, void* stream);
+
+/* ---- ALP module ------------------------------------------------------------------------------------------------
+ * Prototype bank from token-major support features sup fp32 [h*w, C] (row stride ld) and the foreground mask fp32
+ * [MH,MW] (bmask optional, default 1 - mask): nearest resize, avg-pool coverage > thresh, pooled prototypes,
+ * global masked-average prototype, safe_norm. bank fp32 [2*cap, C]; meta int[8] = {n_bg, n_fg, fg_mode, n_fg_cells}.
+ * force_mode -1: reference FewShotSeg rule; 0 'mask'; 1 'gridconv+'; 2 'gridconv'.
+ * models/alpmodule.py:97-159 (get_prototypes), :14-18 (safe_norm); models/grid_proto_fewshot.py:228-231,253-256. */
+int psam_alp_bank(const float* sup, int ld, int h, int w, int C, const float* mask, const float* bmask, int MH, int MW,
+                  int pool_w, int kernel_size, float thresh, float eps, float* bank, int cap, int* meta, int* slot_bg,
+                  int* slot_fg, float* mres, int force_mode, void* stream);
+
+/* pred[b, {bg,fg}, pix] = sum_p softmax_p(d) * d, d = sim_scale * cos(qry[pix], proto_p), fp32 MFMA.
+ * models/alpmodule.py:57-94 (get_prediction_from_prototypes), :195. which_only -1: both banks. */
+int psam_alp_sim(const float* qry, long long q_bstride, int ld, int B, int npix, int C, const float* bank, int cap,
+                 const int* meta, float eps, float sim_scale, float* part, float* pred, int which_only, void* stream);
+
+/* ---- resampling / packing -------------------------------------------------------------------------------------- */
+/* F.interpolate(img,(S,S),'bilinear') + im2col of a PxP/stride-P conv -> half [B*(S/P)^2, Kpad].
+ * models/grid_proto_fewshot.py:88-89 + DINOv2 PatchEmbed; also SAM PatchEmbed when H == S. */
+int psam_patchify_bilinear(const float* img, int B, int C, int H, int W, int S, int P, int Kpad, void* out, void* stream);
+/* F.interpolate(x, (OH,OW), 'bilinear', align_corners=False), fp32 planes. grid_proto_fewshot.py:272-273; ProtoSAM.py:592-594 */
+int psam_bilinear_nchw(const float* in, int planes, int IH, int IW, int OH, int OW, float* out, void* stream);
+/* [bilinear to OHxOW] -> softmax(dim=1) -> argmax for 2-class logits; prob fp32 [B,2,OH,OW], pred u8, fg_sum int[B].
+ * models/ProtoSAM.py:592-602 */
+int psam_prob_argmax(const float* logits, int B, int IH, int IW, int OH, int OW, float* prob, void* pred, int* fg_sum,
+                     void* stream);
+int psam_broadcast_rows(const float* row, int D, float* out, int B, long long stride, long long off, void* stream);
+/* per-image min/max (order-preserving uint32 pairs).  models/ProtoSAM.py:660 */
+int psam_minmax(const float* x, int B, long long n_per_img, void* mm, void* stream);
+/* ((x-min)/(max-min)*255).astype(uint8) -> (u8 - mean)/std -> im2col(16x16) half; mean3/std3 are HOST pointers.
+ * models/ProtoSAM.py:651-660; modeling/sam.py:163-173; predictor.py:56-58,88. quantise 0 = ProtoMedSAM.py:203-205. */
+int psam_sam_patchify(const float* img, const void* mm, int B, int S, int P, const float* mean3, const float* std3,
+                      int quantise, void* out, void* u8out, void* stream);
+/* (x - mean[c]) / std[c] on [B,3,plane]; in_u8: x is uint8. mean3/std3 HOST pointers. modeling/sam.py:163-168 */
+int psam_normalize_chw(const void* x, int in_u8, int B, long long plane, const float* mean3, const float* std3,
+                       float* y, void* stream);
+/* im2col of the neck's 3x3/pad-1 conv on a token-major half map. image_encoder.py:98-104 */
+int psam_im2col3x3(const void* in, int B, int H, int W, int C, void* out, void* stream);
+int psam_cast_f16(const float* x, void* y, long long n, void* stream);
+
+/* ---- connected components + per-component statistics ------------------------------------------------------------
+ * util/utils.py:474-494 (cv2.connectedComponentsWithStats, confidences), models/ProtoSAM.py:242-289 (bbox, most
+ * confident point). tab fp64: [n_found, n_kept, sum(pred), argmax_conf, 0,0,0,0] then 12 doubles per component:
+ * {area, sum_x, sum_y, min_x, min_y, max_x, max_y, conf, best_x, best_y, best_p, 0}. */
+int psam_ccl(const void* pred, const float* pfg, int H, int W, int cap, int* labels, int* parent, int* counters,
+             int* roots, int* acc_i, void* acc_u, double* acc_d, const int* fg_sum, double* tab, void* stream);
+
+/* ---- SAM prompt encoder / mask decoder --------------------------------------------------------------------------- */
+/* grouped fp32 y = act((x [+ x2]) W^T + b) (+ resid); act 1 = ReLU.  transformer.py:218-240, mask_decoder.py:154-176 */
+int psam_small_linear(const float* x, const float* x2, const float* W, const float* b, const float* resid, float* y,
+                      int G, int M, int N, int K, long long xg, long long wg, long long bg, long long yg, int ldx,
+                      int ldy, int act, void* stream);
+/* softmax(q k^T / sqrt(hd)) v with <= 16 keys (token self-attention; image->token attention). transformer.py:151-182 */
+int psam_small_attention(const void* q, const float* k, const float* v, void* out, int B, int Tq, int Tk, int NH, int hd,
+                         int ldq, int ldk, int ldv, int ldo, int q_f16, void* stream);
+/* token -> image cross attention over Nk <= 4096 keys (K, V half).  transformer.py:163-167, 98-103 */
+int psam_t2i_attention(const float* q, const void* K, const void* V, float* out, int B, int T, int Nk, int NH,
+                       void* stream);
+/* y = [LayerNorm](x[row % in_mod] + add_vec); emits fp32 y, half y, half (y + pe[row % pe_mod]).
+ * mask_decoder.py:126-127; transformer.py:164,178,180 */
+int psam_ln_pe(const float* x, const float* add_vec, const float* w, const float* b, const float* pe, float* y32,
+               void* y16, void* ype16, int M, int in_mod, int pe_mod, float eps, int do_ln, void* stream);
+/* PromptEncoder.get_dense_pe (prompt_encoder.py:62-71,195-206), token-major fp32 [gh*gw, 256] */
+int psam_dense_pe(const float* G, int gh, int gw, float* pe, void* stream);
+/* output tokens ++ point / box-corner embeddings.  prompt_encoder.py:73-101,208-214; mask_decoder.py:121-123 */
+int psam_prompt_tokens(const float* coords, const int* labels, const float* G, const float* type_emb,
+                       const float* out_tok, int B, int Ns, float img_size, float* tokens, void* stream);
+/* LayerNorm2d -> GELU -> ConvTranspose2d(64->32) -> GELU -> hyper-network product.  mask_decoder.py:53-59,137-144 */
+int psam_upscale_tail(const float* u1, const float* lnw, const float* lnb, const float* W2r, const float* b2,
+                      const float* hyper, float* masks, int B, int g, void* stream);
+/* Sam.postprocess_masks first stage; variant 0 upstream (bilinear, align_corners=False), 1 vendored SamBatched
+ * (align_corners=True, modeling/sam.py:313-320), 2 vendored Sam (nearest, sam.py:154-160). */
+int psam_mask_upsample(const float* low, int planes, int IN, int MID, int variant, float* out, void* stream);
+/* pred = OR_b(upsample(low[b,sel]) > thr) sampled by F.interpolate(..., 'nearest') to OUT.  models/ProtoSAM.py:669-676 */
+int psam_mask_union(const float* low, int B, int C, int sel, int IN, int MID, int OUT, int variant, float thr,
+                    float* pred, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -13,10 +13,11 @@
 //
 // Layout: A and W are K-contiguous (nn.Linear's [out,in] weight is used as-is, no transpose).
 // Tile 128x128x64, 256 threads = 4 waves in 2x2, each wave owns a 64x64 sub-tile =
-// 2x2 MFMA 32x32 accumulators (64 acc VGPRs). A/W tiles are staged through LDS with a
-// 16-byte-slot XOR swizzle (slot ^= (row>>1)&7) that makes both the ds_write_b128 of the stage
-// and the ds_read_b128 of the fragments conflict-free; global->register prefetch of tile k+1
-// overlaps the MFMAs of tile k (one barrier per k-tile, double-buffered LDS).
+// 2x2 MFMA 32x32 accumulators (64 acc VGPRs). A/W tiles go global -> LDS by direct 16-byte DMA
+// (`global_load_lds_dwordx4`, no VGPR staging), double-buffered: the DMA of k-tile t+1 is issued
+// before the MFMAs of k-tile t, one barrier per k-tile. The 16-byte-slot XOR swizzle
+// (slot ^= (row>>1)&7) that makes the ds_read_b128 fragment reads bank-conflict-free is applied on
+// the DMA's per-lane SOURCE address, because the LDS side of the DMA is lane-linear.
 #include "common.h"
 
 enum { EPI_F16 = 0, EPI_GELU_F16 = 1, EPI_F32 = 2 };
@@ -45,6 +46,14 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
   return row * BK + ((chunk ^ ((row >> 1) & 7)) << 3);
 }
 
+// one 16-byte global -> LDS DMA per lane: LDS destination = wave-uniform base + lane*16 (the hardware adds the lane
+// offset), source address per lane. The XOR swizzle therefore lives on the SOURCE side (which 16-byte chunk of its
+// 128-byte row a lane fetches) and on the fragment reads; the LDS image itself is written linearly.
+__device__ __forceinline__ void glds16(const half_t* g, half_t* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) half_t smem[2][2][BM * BK];  // [buf][A|W] 64 KiB
@@ -56,26 +65,24 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs p) {
   const int n0 = (tile % ntn) * BN;
 
   const int t = threadIdx.x;
-  const int lc = t & 7;    // 16-byte chunk within the 128-byte k-row
-  const int lr0 = t >> 3;  // 0..31
-
-  const uint4* ag[4];
-  const uint4* wg[4];
-  int soff[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int r = lr0 + 32 * i;
-    int am = m0 + r;
-    am = am < p.M ? am : p.M - 1;
-    ag[i] = reinterpret_cast<const uint4*>(p.A + (size_t)am * p.lda + lc * 8);
-    wg[i] = reinterpret_cast<const uint4*>(p.W + (size_t)(n0 + r) * p.ldw + lc * 8);
-    soff[i] = lds_off(r, lc);
-  }
-
   const int lane = t & 63;
-  const int wv = t >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wv >> 1, wn = wv & 1;
   const int lr = lane & 31, lg = lane >> 5;
+
+  // staging: wave wv moves 1-KiB pieces q = wv*4 + j (8 tile rows each) of the A tile and of the W tile.
+  // lane -> (row = q*8 + lane/8, LDS slot = lane%8) fetches source chunk = slot ^ ((row>>1)&7) of that row.
+  const half_t* ag[4];
+  const half_t* wg[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (wv * 4 + j) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    int am = m0 + row;
+    am = am < p.M ? am : p.M - 1;
+    ag[j] = p.A + (size_t)am * p.lda + chunk * 8;
+    wg[j] = p.W + (size_t)(n0 + row) * p.ldw + chunk * 8;
+  }
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -85,29 +92,21 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  uint4 ra[4], rw[4];
+  auto stage = [&](int buf, int kt) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    ra[i] = ag[i][0];
-    rw[i] = wg[i][0];
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    *reinterpret_cast<uint4*>(&smem[0][0][soff[i]]) = ra[i];
-    *reinterpret_cast<uint4*>(&smem[0][1][soff[i]]) = rw[i];
-  }
-  __syncthreads();
+    for (int j = 0; j < 4; ++j) {
+      glds16(ag[j] + kt * BK, &smem[buf][0][(wv * 4 + j) * 8 * BK]);
+      glds16(wg[j] + kt * BK, &smem[buf][1][(wv * 4 + j) * 8 * BK]);
+    }
+  };
 
   const int nk = p.K / BK;
+  stage(0, 0);
+  __syncthreads();  // carries the vmcnt(0) for the pending LDS-DMA
+
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        ra[i] = ag[i][(kt + 1) * (BK / 8)];
-        rw[i] = wg[i][(kt + 1) * (BK / 8)];
-      }
-    }
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);  // next tile's DMA flies under this tile's MFMAs
     const half_t* sa = smem[cur][0];
     const half_t* sw = smem[cur][1];
 #pragma unroll
@@ -129,14 +128,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs p) {
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        *reinterpret_cast<uint4*>(&smem[cur ^ 1][0][soff[i]]) = ra[i];
-        *reinterpret_cast<uint4*>(&smem[cur ^ 1][1][soff[i]]) = rw[i];
-      }
-    }
-    __syncthreads();
+    __syncthreads();  // all waves done reading buf[cur]; DMA into buf[cur^1] has landed (vmcnt(0))
   }
 
   // epilogue. C layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)

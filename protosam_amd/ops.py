@@ -11,6 +11,32 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class KernelTimer:
+    """Optional HIP-event bracket around every launch of one C-ABI entry (used by bench.py for the roofline object:
+    events are recorded on the stream the kernel is launched on). `work` is the algorithmic FLOPs or bytes per launch."""
+
+    def __init__(self):
+        self.records = []  # (start_event, end_event, work)
+
+    def start(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def stop(self, e0, work):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.records.append((e0, e1, work))
+
+    def summary(self):
+        """(n_launches, total_seconds, total_work) -- call after a device synchronize."""
+        t = sum(a.elapsed_time(b) for a, b, _ in self.records) * 1e-3
+        return len(self.records), t, float(sum(w for _, _, w in self.records))
+
+
+GEMM_TIMER = None  # set to a KernelTimer to time psam_gemm_f16 launches
+
+
 def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
@@ -46,9 +72,12 @@ def gemm(a, w, bias=None, out=None, epilogue=EPI_F16, resid=None, gamma=None, re
     if resid is not None:
         r2 = resid.reshape(-1, resid.shape[-1]) if resid.dim() != 2 else resid
         ldr = r2.stride(0)
+    t0 = GEMM_TIMER.start() if GEMM_TIMER is not None else None
     st = _lib.lib().psam_gemm_f16(_ptr(a2), _ptr(w), _ptr(bias), _ptr(out2), _ptr(resid), _ptr(gamma), M, N, K,
                                  a2.stride(0), w.stride(0), out2.stride(0), ldr, resid_mod, out_seg,
                                  out_seg_stride, out_seg_off, epilogue, _stream())
+    if t0 is not None:
+        GEMM_TIMER.stop(t0, 2.0 * M * N * K)
     _lib.check(st, "psam_gemm_f16")
     return out
 

@@ -1,0 +1,96 @@
+"""Volume-level driver: the per-slice loop of /root/reference/validation_protosam.py:346-388 (support per z-part,
+one `ProtoSAM.forward` per query slice) plus data-parallel sharding of slices over ranks.
+
+Slices are independent given the (replicated) support set, so rank r of W takes slices z = r (mod W) with no
+data-path collective; the only exchange is one all-gather of the uint8 masks per volume / step.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+from .grid_proto_fewshot import FewShotSeg
+from .protosam import ALPNetWrapper, InputFactory, ProtoSAM, TYPE_ALPNET
+from .synth import synth_state_dict
+
+ALP_CFG = {"which_model": "dinov2_b14", "cls_name": "grid_proto", "proto_grid_size": 8, "lora": 0, "align": False,
+           "debug": False}
+
+
+def build_protosam(device, sam_type="vit_h", image_size=512, seed=1234, dino_depth=None, sam_depth=None,
+                   cache_support=True, **protosam_kw):
+    """Seeded synthetic-weight ProtoSAM as validation_protosam.get_model builds it (:188-232)."""
+    cfg = dict(ALP_CFG)
+    if dino_depth is not None:
+        cfg["encoder_depth"] = dino_depth
+    alp = FewShotSeg(image_size, None, cfg, cache_support=cache_support)
+    alp_sd = synth_state_dict(alp, seed)
+    alp.load_state_dict(alp_sd)
+    alp = alp.to(device).eval()
+    spec = f"random:{sam_type}:{seed}" + (f":{sam_depth}" if sam_depth is not None else "")
+    kw = dict(use_bbox=True, use_points=True, point_mode="both", use_cca=False, num_points_for_sam=1,
+              use_sam_trans=True)
+    kw.update(protosam_kw)
+    model = ProtoSAM(image_size=(1024, 1024), coarse_segmentation_model=ALPNetWrapper(alp), sam_pretrained_path=spec,
+                     **kw).to(device).eval()
+    return model, alp_sd
+
+
+def part_assign(z, n_slices, n_parts=3):
+    """dataloaders/common.py:241-249 style: equal z-chunks."""
+    return min(int(z * n_parts / n_slices), n_parts - 1)
+
+
+def support_set(vol, lab, n_parts=3):
+    """Middle slice of each z-chunk of the support volume (ManualAnnoDatasetv2.py:457-462), tiled x3."""
+    n = vol.shape[0]
+    imgs, masks = [], []
+    for p in range(n_parts):
+        z = int((p + 0.5) * n / n_parts)
+        imgs.append(vol[z][None, None].repeat(1, 3, 1, 1).contiguous())
+        masks.append(lab[z][None].contiguous())
+    return imgs, masks
+
+
+def shard_slices(n_slices, rank, world):
+    return list(range(rank, n_slices, world))
+
+
+@torch.no_grad()
+def run_slices(model, vol, sup_imgs, sup_masks, zs, device, out=None):
+    """Runs ProtoSAM.forward on slices `zs` of `vol` [n,S,S] (device tensor); returns uint8 masks [len(zs),S,S]."""
+    n, S = vol.shape[0], vol.shape[-1]
+    if out is None:
+        out = torch.zeros((len(zs), S, S), dtype=torch.uint8, device=device)
+    stats = []
+    cur_part, inp = None, None
+    for i, z in enumerate(zs):
+        part = part_assign(z, n)
+        q = vol[z][None, None].expand(1, 3, S, S).contiguous()
+        if part != cur_part:
+            inp = InputFactory.create_input(TYPE_ALPNET, q, support_images=[sup_imgs[part]],
+                                            support_labels=[sup_masks[part]], isval=True, val_wsize=2)
+            cur_part = part
+        pred, scores = model(q, inp, degrees_rotate=0)
+        if pred.shape[-1] == S:
+            out[i] = pred.to(torch.uint8)
+        stats.append(model.last_stats.get("n_prompts", 0))
+    return out, stats
+
+
+def gather_masks(local, world):
+    """One all-gather of the per-rank uint8 masks (RCCL on GPUs, gloo on CPU). [k,S,S] -> [world*k,S,S] (rank-major)."""
+    if world == 1 or not dist.is_initialized():
+        return local
+    full = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(full, local.contiguous())
+    return full
+
+
+def interleave_rank_major(full, n_slices, world):
+    """Undo the z = r (mod W) sharding: rank-major gathered masks -> z order (pads dropped)."""
+    k = math.ceil(n_slices / world)
+    idx = []
+    for z in range(n_slices):
+        idx.append((z % world) * k + z // world)
+    return full[torch.tensor(idx, device=full.device)]

@@ -1,0 +1,66 @@
+"""CPU / gloo, world_size 2: slice sharding z = r (mod W) and the single all-gather of uint8 masks reassemble the
+volume exactly as a 1-rank run would produce it (the N > 1 path of bench.py / protosam_amd.runner)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_mask(z, S=16):
+    g = torch.Generator().manual_seed(1000 + z)
+    return (torch.rand((S, S), generator=g) > 0.5).to(torch.uint8)
+
+
+def _worker(rank, world, port, n_slices, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from protosam_amd.runner import gather_masks, interleave_rank_major, shard_slices
+    zs = shard_slices(n_slices, rank, world)
+    k = -(-n_slices // world)
+    local = torch.zeros((k, 16, 16), dtype=torch.uint8)
+    for i, z in enumerate(zs):
+        local[i] = _fake_mask(z)
+    full = gather_masks(local, world)
+    vol = interleave_rank_major(full, n_slices, world)
+    ok = all(torch.equal(vol[z], _fake_mask(z)) for z in range(n_slices))
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the max-over-ranks timing reduction used by bench.py
+    q.put((rank, ok, float(t.item()), zs))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_slices", [8, 7])
+def test_two_rank_gather_matches_single_rank(n_slices):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_slices, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, tmax, zs in res:
+        assert ok and tmax == 2.0
+    shards = sorted(z for r in res for z in r[3])
+    assert shards == list(range(n_slices))  # disjoint cover
+
+
+def test_part_assignment_and_support_set():
+    from protosam_amd.runner import part_assign, support_set
+    assert [part_assign(z, 9) for z in range(9)] == [0, 0, 0, 1, 1, 1, 2, 2, 2]
+    vol = torch.arange(9.0).view(9, 1, 1).expand(9, 4, 4).contiguous()
+    imgs, masks = support_set(vol, vol)
+    assert [int(i[0, 0, 0, 0]) for i in imgs] == [1, 4, 7] and imgs[0].shape == (1, 3, 4, 4) and masks[0].shape == (1, 4, 4)
