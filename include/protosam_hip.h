@@ -36,16 +36,20 @@ int psam_layernorm(const float* x, const float* w, const float* b, void* y, floa
                    float eps, int out_dtype, int zero_tail_rows, void* stream);
 
 /* Fused multi-head attention on the packed projection qkv half [B,N,3,H,hd] -> out half [B,N,H*hd]; hd in {64, 80}.
- * mode 0 global (DINOv2 Attention); mode 1 global + decomposed rel-pos (gw == 64); mode 2 ws x ws windows with the
- * reference's zero padding (pad_row half [3,H,hd] = qkv bias) + rel-pos.
+ * mode 0 global (DINOv2 Attention); mode 1 global + decomposed rel-pos (rel_h/rel_w fp32, gw == 64); mode 2 ws x ws
+ * windows with the reference's zero padding (pad_row half [3,H,hd] = qkv bias) + rel-pos folded into the score MFMA
+ * as 32 extra k-slots (relq half [B,H,N,2,32] from psam_relpos).
  * image_encoder.py:235-251 (Attention.forward), :254-300 (window_partition / unpartition), :337-372. */
-int psam_attention_f16(const void* qkv, void* out, const float* rel_h, const float* rel_w, const void* pad_row, int B,
-                       int N, int H, int hd, float scale, int mode, int gh, int gw, int ws, void* stream);
+int psam_attention_f16(const void* qkv, void* out, const float* rel_h, const float* rel_w, const void* relq,
+                       const void* pad_row, int B, int N, int H, int hd, float scale, int mode, int gh, int gw, int ws,
+                       void* stream);
 
-/* rel_h[b,h,n,k] = q . Rh[qy - k + K-1], rel_w likewise (UNSCALED q); fp32 [B,H,N,64] (global) or [B,H,N,16] (windowed).
+/* rel_h[b,h,n,k] = q . Rh[qy - k + K-1], rel_w likewise (UNSCALED q), as an MFMA GEMM against the whole table followed by
+ * a scatter. Rpack half [2 (h,w)][2 (hi,lo)][RP][HDP] (RP = 128 global / 32 windowed, zero padded).
+ * global: rel_h, rel_w fp32 [B,H,N,64]. windowed: relq half [B,H,N,2,32] = hi/lo of (rel_h | rel_w | 0) / scale.
  * image_encoder.py:303-372 (get_rel_pos, add_decomposed_rel_pos). */
-int psam_relpos(const void* qkv, const float* Rh, const float* Rw, float* rel_h, float* rel_w, int B, int N, int H,
-                int hd, int gw, int K, int windowed, void* stream);
+int psam_relpos(const void* qkv, const void* Rpack, float* rel_h, float* rel_w, void* relq, int B, int N, int H, int hd,
+                int gw, int K, int windowed, float scale, void* stream);
 
 /* ---- ALP module ------------------------------------------------------------------------------------------------
  * Prototype bank from token-major support features sup fp32 [h*w, C] (row stride ld) and the foreground mask fp32

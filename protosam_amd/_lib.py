@@ -20,9 +20,9 @@ SIGNATURES = {
     "psam_gemm_f16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p],
     "psam_layernorm": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                        c_int, c_int, c_void_p],
-    "psam_attention_f16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
-                           c_int, c_int, c_int, c_int, c_void_p],
-    "psam_relpos": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p],
+    "psam_attention_f16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                           c_float, c_int, c_int, c_int, c_int, c_void_p],
+    "psam_relpos": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_float, c_void_p],
     "psam_alp_bank": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float,
                       c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "psam_alp_sim": [c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_float, c_float,

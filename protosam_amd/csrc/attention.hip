@@ -32,6 +32,7 @@ struct AttnArgs {
   const float* rel_h;     // mode1: [B,H,N,gw(64)]  mode2: [B,H,N,16]
   const float* rel_w;
   const half_t* pad_row;  // mode2: [3, H, HD] = fp16(qkv bias)
+  const half_t* relq;     // mode2: [B,H,N,2(hi,lo),32] = (rel_h[0:ws] | rel_w[0:ws] | 0) / scale, split in two halfs
   int B, N, H;
   float scale;
   int gh, gw, ws, nwx, nwin;  // token grid, window size, windows per row, windows per image
@@ -55,8 +56,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
 
   __shared__ __attribute__((aligned(16))) half_t Ks[KT * KLD];
   __shared__ __attribute__((aligned(16))) half_t Vt[HD * VLD];
-  __shared__ float relh_s[MODE == 2 ? QB * 16 : 1];
-  __shared__ float relw_s[MODE == 2 ? QB * 16 : 1];
+  __shared__ unsigned short klut[MODE == 2 ? 256 : 1];  // window key index -> kh | (kw << 8)
 
   const int t = threadIdx.x;
   const int lane = t & 63, wv = t >> 6;
@@ -129,19 +129,20 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
       }
     }
   }
+  // MODE 2: the decomposed rel-pos bias is folded into the S^T MFMA as 32 extra k-slots:
+  //   B operand (query side) = [rel_h(q, 0..ws) | rel_w(q, 0..ws) | 0] / scale  (fp16 hi + lo parts, from psam_relpos)
+  //   A operand (key side)   = one-hot(kh) | one-hot(kw)  built in registers per key tile
+  half8_t qaug[2][2];
   if (MODE == 2) {
-    for (int idx = t; idx < QB * 16; idx += NT) {
-      int qr = idx >> 4, k = idx & 15;
-      int q = blockIdx.x * QB + qr;
-      int tok = q < nkeys ? win_token(q) : -1;
-      float vh = 0.f, vw = 0.f;
-      if (tok >= 0) {
-        size_t base = (((size_t)b * H + h) * N + tok) * 16 + k;
-        vh = p.rel_h[base];
-        vw = p.rel_w[base];
-      }
-      relh_s[idx] = vh;
-      relw_s[idx] = vw;
+    for (int idx = t; idx < 256; idx += NT) {
+      int kh = idx / p.ws, kw = idx - kh * p.ws;
+      klut[idx] = (unsigned short)(kh | (kw << 8));
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const half_t* rq = p.relq + (((size_t)b * H + h) * N + qtok[qt]) * 64 + g * 8;
+      qaug[qt][0] = *reinterpret_cast<const half8_t*>(rq);
+      qaug[qt][1] = *reinterpret_cast<const half8_t*>(rq + 32);
     }
   }
 
@@ -260,6 +261,22 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
         for (int qt = 0; qt < 2; ++qt)
           st[tt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qt][s], st[tt][qt], 0, 0, 0);
       }
+      if (MODE == 2) {
+        const int kidx = tile * KT + krow;
+        const unsigned lut = klut[kidx & 255];
+        const int kh = lut & 0xff, kw = (int)(lut >> 8) + p.ws;  // slots of the two one-hots
+        half8_t oh;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int slot = g * 8 + e;
+          oh[e] = (kidx < nkeys && (slot == kh || slot == kw)) ? (half_t)1.f : (half_t)0.f;
+        }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          st[tt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(oh, qaug[qt][0], st[tt][qt], 0, 0, 0);
+          st[tt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(oh, qaug[qt][1], st[tt][qt], 0, 0, 0);
+        }
+      }
     }
 
     // scale + bias + mask, online softmax
@@ -268,7 +285,6 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
     for (int qt = 0; qt < 2; ++qt) {
       float bh = 0.f;
       if (MODE == 1) bh = relh_q[qt][tile];
-      const int qr = wv * 32 + qt * 16 + li;  // block-local q row (MODE 2 tables)
       float mx = -INFINITY;
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
@@ -278,10 +294,6 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
           const int kidx = tile * KT + kk;
           float sv = st[tt][qt][r] * p.scale;
           if (MODE == 1) sv += bh + rwreg[qt][tt][r];
-          if (MODE == 2) {
-            int kh = kidx / p.ws, kw = kidx - kh * p.ws;
-            if (kidx < nkeys) sv += relh_s[qr * 16 + kh] + relw_s[qr * 16 + kw];
-          }
           if (kidx >= nkeys) sv = -INFINITY;
           st[tt][qt][r] = sv;
           mx = fmaxf(mx, sv);
@@ -366,10 +378,11 @@ static int launch_attn(const AttnArgs& p, int mode, hipStream_t s) {
 }
 
 // mode 0: global, no bias.  mode 1: global + decomposed rel-pos (requires gw == 64, N == gh*gw).
-// mode 2: ws x ws windows over the gh x gw token map (zero-padded as the reference) + rel-pos.
+// mode 2: ws x ws windows over the gh x gw token map (zero-padded as the reference) + rel-pos folded into the MFMA
+//         (relq = psam_relpos' windowed output).
 extern "C" int psam_attention_f16(const void* qkv, void* out, const float* rel_h, const float* rel_w,
-                                  const void* pad_row, int B, int N, int H, int hd, float scale, int mode, int gh,
-                                  int gw, int ws, void* stream) {
+                                  const void* relq, const void* pad_row, int B, int N, int H, int hd, float scale,
+                                  int mode, int gh, int gw, int ws, void* stream) {
   if (B <= 0 || N <= 0 || H <= 0 || mode < 0 || mode > 2) return PSAM_ERR_ARG;
   AttnArgs p;
   p.qkv = (const half_t*)qkv;
@@ -377,6 +390,7 @@ extern "C" int psam_attention_f16(const void* qkv, void* out, const float* rel_h
   p.rel_h = rel_h;
   p.rel_w = rel_w;
   p.pad_row = (const half_t*)pad_row;
+  p.relq = (const half_t*)relq;
   p.B = B;
   p.N = N;
   p.H = H;
@@ -389,7 +403,7 @@ extern "C" int psam_attention_f16(const void* qkv, void* out, const float* rel_h
     if (gw != KT || gh * gw != N || !rel_h || !rel_w) return PSAM_ERR_ARG;
   }
   if (mode == 2) {
-    if (ws <= 0 || ws > 16 || gh * gw != N || !rel_h || !rel_w || !pad_row) return PSAM_ERR_ARG;
+    if (ws <= 0 || ws > 16 || gh * gw != N || !relq || !pad_row) return PSAM_ERR_ARG;
     p.nwx = (gw + ws - 1) / ws;
     p.nwin = p.nwx * ((gh + ws - 1) / ws);
   }
@@ -402,42 +416,99 @@ extern "C" int psam_attention_f16(const void* qkv, void* out, const float* rel_h
 // ---------------------------------------------------------------------------------------------
 // Decomposed relative-position terms (models/segment_anything/modeling/image_encoder.py:303-372):
 //   rel_h[b,h,n,kh] = q[b,n,h,:] . Rh[qy - kh + (K-1), :],   rel_w[b,h,n,kw] = q . Rw[qx - kw + (K-1), :]
-// with (qy,qx) the query's position inside its attention region (whole 64x64 map, or its 14x14
-// window) and K the region side. Rh/Rw are the (2K-1, hd) tables `rel_pos_h/w` (get_rel_pos is the
-// identity gather when the table length already equals 2K-1, the only case SAM's 1024 input hits).
-// q is the UNSCALED fp16 query from the packed qkv buffer. Output fp32 [B,H,N,KO] (KO = 64 or 16).
-__global__ void relpos_kernel(const half_t* __restrict__ qkv, const float* __restrict__ Rh,
-                              const float* __restrict__ Rw, float* __restrict__ rel_h, float* __restrict__ rel_w,
-                              int B, int N, int H, int hd, int gw, int K, int KO, int windowed) {
-  // one block per (token n, head h, batch b); 2*KO threads: [0,KO) -> rel_h, [KO,2KO) -> rel_w
-  extern __shared__ float qs[];
-  const int n = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-  const half_t* q = qkv + ((size_t)b * N + n) * ((size_t)3 * H * hd) + (size_t)h * hd;
-  for (int c = threadIdx.x; c < hd; c += blockDim.x) qs[c] = (float)q[c];
-  __syncthreads();
-  int y = n / gw, x = n % gw;
-  if (windowed) {
-    y %= K;
-    x %= K;
+// with (qy,qx) the query's position inside its attention region (whole 64x64 map, or its 14x14 window) and K the
+// region side. Rh/Rw are the (2K-1, hd) tables `rel_pos_h/w` (get_rel_pos is the identity gather when the table
+// length already equals 2K-1, the only case SAM's 1024 input hits). q is the UNSCALED fp16 query of the packed qkv.
+//
+// MFMA formulation: T[n, r] = q_n . R[r] for ALL table rows r (a [64 tokens] x [RP rows] x [hd] GEMM per block on
+// v_mfma_f32_16x16x32_f16, tables pre-split into fp16 hi + lo parts so the result is fp32-accurate), then each
+// (n, r) is scattered to its key index k = pos(n) - r + K-1 when 0 <= k < K.
+//   global  (windowed = 0): rel_h / rel_w fp32 [B,H,N,64]
+//   windowed             : relq fp16 [B,H,N,2,32] = hi/lo halves of (rel_h[0:K] | rel_w[0:K] | 0) / scale, the extra
+//                          k-slots of the window attention's S^T MFMA (caller zero-fills the buffer once).
+// Rpack: fp16 [2 (h,w)][2 (hi,lo)][RP][HDP], zero padded; RP = 128 (global) or 32 (windowed).
+template <int HD>
+__global__ __launch_bounds__(256) void relpos_mfma_kernel(const half_t* __restrict__ qkv, const half_t* __restrict__ Rpack,
+                                                          float* __restrict__ rel_h, float* __restrict__ rel_w,
+                                                          half_t* __restrict__ relq, int N, int H, int gw, int K, int RP,
+                                                          int windowed, float inv_scale) {
+  constexpr int HDP = (HD + 31) / 32 * 32;
+  constexpr int KS = HDP / 32;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int n0 = blockIdx.x * 64 + wv * 16;
+  // A operand: 16 query rows
+  half8_t qf[KS];
+  {
+    const half_t* qp = qkv + ((size_t)b * N + n0 + li) * ((size_t)3 * H * HD) + (size_t)h * HD;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int c0 = s * 32 + g * 8;
+      if (c0 < HD) {
+        qf[s] = *reinterpret_cast<const half8_t*>(qp + c0);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[s][e] = (half_t)0.f;
+      }
+    }
   }
-  const int k = threadIdx.x % KO;
-  const bool is_w = threadIdx.x >= KO;
-  float acc = 0.f;
-  if (k < K) {
-    const float* R = is_w ? Rw + (size_t)(x - k + K - 1) * hd : Rh + (size_t)(y - k + K - 1) * hd;
-    for (int c = 0; c < hd; ++c) acc += qs[c] * R[c];
+  const size_t bh = (size_t)b * H + h;
+#pragma unroll 1
+  for (int tab = 0; tab < 2; ++tab) {
+    const half_t* Rhi = Rpack + (size_t)(tab * 2 + 0) * RP * HDP;
+    const half_t* Rlo = Rpack + (size_t)(tab * 2 + 1) * RP * HDP;
+#pragma unroll 1
+    for (int rt = 0; rt < RP / 16; ++rt) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const size_t off = (size_t)(rt * 16 + li) * HDP + s * 32 + g * 8;
+        half8_t rh = *reinterpret_cast<const half8_t*>(Rhi + off);
+        half8_t rl = *reinterpret_cast<const half8_t*>(Rlo + off);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[s], rh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[s], rl, acc, 0, 0, 0);
+      }
+      // acc[e]: token n0 + g*4 + e, table row r = rt*16 + li
+      const int r = rt * 16 + li;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = n0 + g * 4 + e;
+        int pos = tab == 0 ? n / gw : n % gw;
+        if (windowed) pos %= K;
+        const int k = pos - r + K - 1;
+        if (k >= 0 && k < K && r < 2 * K - 1) {
+          if (windowed) {
+            const float v = acc[e] * inv_scale;
+            const half_t hi = (half_t)v;
+            const half_t lo = (half_t)(v - (float)hi);
+            half_t* o = relq + (bh * N + n) * 64 + tab * K + k;
+            o[0] = hi;
+            o[32] = lo;
+          } else {
+            (tab == 0 ? rel_h : rel_w)[(bh * N + n) * 64 + k] = acc[e];
+          }
+        }
+      }
+    }
   }
-  float* o = is_w ? rel_w : rel_h;
-  o[(((size_t)b * H + h) * N + n) * KO + k] = acc;
 }
 
-extern "C" int psam_relpos(const void* qkv, const float* Rh, const float* Rw, float* rel_h, float* rel_w, int B,
-                           int N, int H, int hd, int gw, int K, int windowed, void* stream) {
-  if (B <= 0 || N <= 0 || K <= 0 || K > 64) return PSAM_ERR_ARG;
-  const int KO = windowed ? 16 : 64;
-  if (K > KO) return PSAM_ERR_ARG;
-  dim3 grid(N, H, B), block(2 * KO);
-  hipLaunchKernelGGL(relpos_kernel, grid, block, hd * sizeof(float), (hipStream_t)stream, (const half_t*)qkv, Rh, Rw,
-                     rel_h, rel_w, B, N, H, hd, gw, K, KO, windowed);
+extern "C" int psam_relpos(const void* qkv, const void* Rpack, float* rel_h, float* rel_w, void* relq, int B, int N,
+                           int H, int hd, int gw, int K, int windowed, float scale, void* stream) {
+  if (B <= 0 || N <= 0 || (N % 64) != 0 || K <= 0 || K > 64) return PSAM_ERR_ARG;
+  if (windowed ? (K > 16 || !relq) : (!rel_h || !rel_w)) return PSAM_ERR_ARG;
+  const int RP = windowed ? 32 : 128;
+  dim3 grid(N / 64, H, B), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  const float inv = 1.0f / scale;
+  if (hd == 64)
+    hipLaunchKernelGGL(relpos_mfma_kernel<64>, grid, block, 0, s, (const half_t*)qkv, (const half_t*)Rpack, rel_h, rel_w,
+                       (half_t*)relq, N, H, gw, K, RP, windowed, inv);
+  else if (hd == 80)
+    hipLaunchKernelGGL(relpos_mfma_kernel<80>, grid, block, 0, s, (const half_t*)qkv, (const half_t*)Rpack, rel_h, rel_w,
+                       (half_t*)relq, N, H, gw, K, RP, windowed, inv);
+  else
+    return PSAM_ERR_ARG;
   return psam_launch_status();
 }

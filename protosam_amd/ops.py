@@ -99,31 +99,51 @@ def layernorm(x, weight, bias, eps, out=None, out_dtype=torch.float16, out2=None
     return out
 
 
-def attention(qkv, B, N, H, hd, scale, out=None, mode=0, rel_h=None, rel_w=None, pad_row=None, gh=0, gw=0, ws=0):
+def attention(qkv, B, N, H, hd, scale, out=None, mode=0, rel_h=None, rel_w=None, relq=None, pad_row=None, gh=0, gw=0,
+              ws=0):
     """qkv fp16 [B,N,3,H,hd] (packed as nn.Linear(dim,3*dim) emits it) -> fp16 [B,N,H*hd]."""
     _req(qkv, torch.float16, "qkv"); _req(rel_h, torch.float32, "rel_h"); _req(rel_w, torch.float32, "rel_w")
-    _req(pad_row, torch.float16, "pad_row")
+    _req(pad_row, torch.float16, "pad_row"); _req(relq, torch.float16, "relq")
     assert qkv.is_contiguous()
     if out is None:
         out = torch.empty((B, N, H * hd), dtype=torch.float16, device=qkv.device)
-    st = _lib.lib().psam_attention_f16(_ptr(qkv), _ptr(out), _ptr(rel_h), _ptr(rel_w), _ptr(pad_row), B, N, H, hd,
-                                      float(scale), mode, gh, gw, ws, _stream())
+    st = _lib.lib().psam_attention_f16(_ptr(qkv), _ptr(out), _ptr(rel_h), _ptr(rel_w), _ptr(relq), _ptr(pad_row), B, N,
+                                      H, hd, float(scale), mode, gh, gw, ws, _stream())
     _lib.check(st, "psam_attention_f16")
     return out
 
 
-def relpos(qkv, Rh, Rw, B, N, H, hd, gw, K, windowed, rel_h=None, rel_w=None):
-    _req(qkv, torch.float16, "qkv"); _req(Rh, torch.float32, "Rh"); _req(Rw, torch.float32, "Rw")
-    KO = 16 if windowed else 64
-    if rel_h is None:
-        rel_h = torch.empty((B, H, N, KO), dtype=torch.float32, device=qkv.device)
-    if rel_w is None:
-        rel_w = torch.empty((B, H, N, KO), dtype=torch.float32, device=qkv.device)
-    assert Rh.is_contiguous() and Rw.is_contiguous()
-    st = _lib.lib().psam_relpos(_ptr(qkv), _ptr(Rh), _ptr(Rw), _ptr(rel_h), _ptr(rel_w), B, N, H, hd, gw, K,
-                               1 if windowed else 0, _stream())
+def pack_rel_tables(rel_pos_h, rel_pos_w, windowed, hd):
+    """fp32 (2K-1, hd) tables -> fp16 [2 (h,w)][2 (hi,lo)][RP][HDP] for psam_relpos (one-time weight packing)."""
+    RP = 32 if windowed else 128
+    HDP = (hd + 31) // 32 * 32
+    out = torch.zeros((2, 2, RP, HDP), dtype=torch.float16, device=rel_pos_h.device)
+    for t, R in enumerate((rel_pos_h, rel_pos_w)):
+        R = R.detach().float()
+        assert R.shape[0] <= RP and R.shape[1] == hd
+        hi = R.half()
+        lo = (R - hi.float()).half()
+        out[t, 0, :R.shape[0], :hd] = hi
+        out[t, 1, :R.shape[0], :hd] = lo
+    return out.contiguous()
+
+
+def relpos(qkv, rpack, B, N, H, hd, gw, K, windowed, scale, rel_h=None, rel_w=None, relq=None):
+    """global: returns (rel_h, rel_w) fp32 [B,H,N,64]; windowed: returns relq fp16 [B,H,N,2,32] (zero-initialised once)."""
+    _req(qkv, torch.float16, "qkv"); _req(rpack, torch.float16, "rpack")
+    assert rpack.is_contiguous()
+    if windowed:
+        if relq is None:
+            relq = torch.zeros((B, H, N, 2, 32), dtype=torch.float16, device=qkv.device)
+    else:
+        if rel_h is None:
+            rel_h = torch.empty((B, H, N, 64), dtype=torch.float32, device=qkv.device)
+        if rel_w is None:
+            rel_w = torch.empty((B, H, N, 64), dtype=torch.float32, device=qkv.device)
+    st = _lib.lib().psam_relpos(_ptr(qkv), _ptr(rpack), _ptr(rel_h), _ptr(rel_w), _ptr(relq), B, N, H, hd, gw, K,
+                               1 if windowed else 0, float(scale), _stream())
     _lib.check(st, "psam_relpos")
-    return rel_h, rel_w
+    return relq if windowed else (rel_h, rel_w)
 
 
 # ---- ALP -----------------------------------------------------------------------------------------------

@@ -97,7 +97,8 @@ class ImageEncoderViT(nn.Module):
             pk["blocks"].append(dict(
                 ws=blk.window_size, n1w=f32(blk.norm1.weight), n1b=f32(blk.norm1.bias), n2w=f32(blk.norm2.weight),
                 n2b=f32(blk.norm2.bias), qkv_w=f16(a.qkv.weight), qkv_b=f32(a.qkv.bias), pad_row=f16(a.qkv.bias),
-                proj_w=f16(a.proj.weight), proj_b=f32(a.proj.bias), rh=f32(a.rel_pos_h), rw=f32(a.rel_pos_w),
+                proj_w=f16(a.proj.weight), proj_b=f32(a.proj.bias),
+                rpack=ops.pack_rel_tables(a.rel_pos_h, a.rel_pos_w, blk.window_size > 0, D // self.num_heads),
                 l1w=f16(blk.mlp.lin1.weight), l1b=f32(blk.mlp.lin1.bias), l2w=f16(blk.mlp.lin2.weight),
                 l2b=f32(blk.mlp.lin2.bias)))
             K = blk.window_size if blk.window_size > 0 else self.grid
@@ -119,6 +120,7 @@ class ImageEncoderViT(nn.Module):
             self._ws[B] = dict(x=e((M, D), torch.float32), ln=e((M, D), torch.float16), qkv=e((M, 3 * D), torch.float16),
                                att=e((M, D), torch.float16), hid=e((M, 4 * D), torch.float16),
                                relh=e((B, H, N, 64), torch.float32), relw=e((B, H, N, 64), torch.float32),
+                               relq=torch.zeros((B, H, N, 2, 32), dtype=torch.float16, device=dev),
                                n0=e((M, oc), torch.float32), n1=e((M, oc), torch.float16),
                                col=e((M, 9 * oc), torch.float16), n2=e((M, oc), torch.float32),
                                out=e((B, N, oc), torch.float32))
@@ -136,11 +138,12 @@ class ImageEncoderViT(nn.Module):
             ops.layernorm(x, bp["n1w"], bp["n1b"], LN_EPS, out=ws["ln"])
             ops.gemm(ws["ln"], bp["qkv_w"], bp["qkv_b"], out=ws["qkv"], epilogue=ops.EPI_F16)
             if bp["ws"] > 0:
-                ops.relpos(ws["qkv"], bp["rh"], bp["rw"], B, N, H, hd, g, bp["ws"], True, ws["relh"], ws["relw"])
-                ops.attention(ws["qkv"], B, N, H, hd, hd ** -0.5, out=ws["att"], mode=2, rel_h=ws["relh"],
-                              rel_w=ws["relw"], pad_row=bp["pad_row"], gh=g, gw=g, ws=bp["ws"])
+                ops.relpos(ws["qkv"], bp["rpack"], B, N, H, hd, g, bp["ws"], True, hd ** -0.5, relq=ws["relq"])
+                ops.attention(ws["qkv"], B, N, H, hd, hd ** -0.5, out=ws["att"], mode=2, relq=ws["relq"],
+                              pad_row=bp["pad_row"], gh=g, gw=g, ws=bp["ws"])
             else:
-                ops.relpos(ws["qkv"], bp["rh"], bp["rw"], B, N, H, hd, g, g, False, ws["relh"], ws["relw"])
+                ops.relpos(ws["qkv"], bp["rpack"], B, N, H, hd, g, g, False, hd ** -0.5, rel_h=ws["relh"],
+                           rel_w=ws["relw"])
                 ops.attention(ws["qkv"], B, N, H, hd, hd ** -0.5, out=ws["att"], mode=1, rel_h=ws["relh"],
                               rel_w=ws["relw"], gh=g, gw=g)
             ops.gemm(ws["att"], bp["proj_w"], bp["proj_b"], out=x, epilogue=ops.EPI_F32, resid=x)

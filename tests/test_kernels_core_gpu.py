@@ -123,7 +123,7 @@ def test_attention_global_relpos(dev, H, hd):
     Rh = _rand((2 * g - 1, hd), dev, 0.3, 12)
     Rw = _rand((2 * g - 1, hd), dev, 0.3, 13)
     scale = hd ** -0.5
-    rel_h, rel_w = ops.relpos(qkv, Rh, Rw, B, N, H, hd, g, g, False)
+    rel_h, rel_w = ops.relpos(qkv, ops.pack_rel_tables(Rh, Rw, False, hd), B, N, H, hd, g, g, False, scale)
     q = qkv.float().view(B, N, 3, H, hd)[:, :, 0].permute(0, 2, 1, 3).reshape(B * H, N, hd)
     rh_ref, rw_ref = decomposed_rel_pos_terms(q.cpu(), Rh.cpu(), Rw.cpu(), (g, g))
     torch.testing.assert_close(rel_h.cpu().view(B * H, g, g, g), rh_ref, rtol=1e-4, atol=1e-4)
@@ -146,8 +146,8 @@ def test_attention_window_relpos(dev, H, hd):
     Rh = _rand((2 * ws - 1, hd), dev, 0.3, 23)
     Rw = _rand((2 * ws - 1, hd), dev, 0.3, 24)
     scale = hd ** -0.5
-    rel_h, rel_w = ops.relpos(qkv, Rh, Rw, B, N, H, hd, g, ws, True)
-    out = ops.attention(qkv, B, N, H, hd, scale, mode=2, rel_h=rel_h, rel_w=rel_w, pad_row=pad, gh=g, gw=g, ws=ws)
+    relq = ops.relpos(qkv, ops.pack_rel_tables(Rh, Rw, True, hd), B, N, H, hd, g, ws, True, scale)
+    out = ops.attention(qkv, B, N, H, hd, scale, mode=2, relq=relq, pad_row=pad, gh=g, gw=g, ws=ws)
 
     # reference on CPU: pad the qkv map with the pad row, partition, attend per window, unpartition
     m = qkv.float().cpu().view(B, g, g, 3 * C) - pad.float().cpu().view(1, 1, 1, 3 * C)

@@ -46,11 +46,14 @@ def main():
             K = 14 if mode == 2 else 64
             Rh = torch.randn(2 * K - 1, hd, device=dev) * 0.1
             Rw = torch.randn(2 * K - 1, hd, device=dev) * 0.1
-            tr = timeit(lambda: ops.relpos(qkv, Rh, Rw, B, N, H, hd, 64, K, mode == 2))
+            rp = ops.pack_rel_tables(Rh, Rw, mode == 2, hd)
+            tr = timeit(lambda: ops.relpos(qkv, rp, B, N, H, hd, 64, K, mode == 2, hd ** -0.5))
             print(f"relpos mode{mode}: {tr*1e6:8.1f} us", flush=True)
-            rh, rw = ops.relpos(qkv, Rh, Rw, B, N, H, hd, 64, K, mode == 2)
-            kw = dict(mode=mode, rel_h=rh, rel_w=rw, gh=64, gw=64, ws=14 if mode == 2 else 0,
-                      pad_row=torch.randn(3, H, hd, device=dev).half())
+            r = ops.relpos(qkv, rp, B, N, H, hd, 64, K, mode == 2, hd ** -0.5)
+            if mode == 2:
+                kw = dict(mode=2, relq=r, gh=64, gw=64, ws=14, pad_row=torch.randn(3, H, hd, device=dev).half())
+            else:
+                kw = dict(mode=1, rel_h=r[0], rel_w=r[1], gh=64, gw=64)
         out = torch.empty(B, N, H * hd, device=dev, dtype=torch.float16)
         t = timeit(lambda: ops.attention(qkv, B, N, H, hd, hd ** -0.5, out=out, **kw))
         nk = 196 if mode == 2 else N
