@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8, help="query slices per rank per step")
+    ap.add_argument("--micro", type=int, default=4, help="slices pushed through the kernels together (1 = per-slice "
+                    "ProtoSAM.forward exactly as the reference caller; >1 = ProtoSAM.forward_batch)")
     ap.add_argument("--sam", default="vit_h", choices=["vit_b", "vit_l", "vit_h"])
     ap.add_argument("--slices", type=int, default=64)
     ap.add_argument("--no-support-cache", action="store_true")
@@ -79,7 +81,7 @@ def main():
         # rank r takes slices z = r (mod W) of the step's window (interleaved sharding)
         zs = [((s * B + j) * world + rank) % args.slices for j in range(B)]
         zs.sort()
-        masks, st = run_slices(model, vol_d, sup_imgs, sup_masks, zs, dev, out=out)
+        masks, st = run_slices(model, vol_d, sup_imgs, sup_masks, zs, dev, out=out, batch=args.micro)
         full = gather_masks(masks, world)
         return zs, full, st
 
@@ -130,7 +132,8 @@ def main():
         "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"ProtoSAM.forward per 512x512 slice: DINOv2 ViT-B/14 + ALP + SAM {args.sam} "
                                f"(encoder + prompt encoder + mask decoder), synthetic CT-like volume",
-                   "slices_per_step_per_gpu": B, "volume_slices": args.slices, "support_cached": not args.no_support_cache,
+                   "slices_per_step_per_gpu": B, "micro_batch": args.micro, "volume_slices": args.slices,
+                   "support_cached": not args.no_support_cache,
                    "mean_components_per_slice": round(sum(ncomp) / max(len(ncomp), 1), 2),
                    "flags": "use_bbox use_points point_mode=both use_cca=False", "weights": "seeded random (1234)"},
         "roofline": roofline, "cpu_baseline": cpu,

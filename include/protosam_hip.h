@@ -29,6 +29,10 @@ int psam_gemm_f16(const void* A, const void* W, const float* bias, void* out, co
                   int M, int N, int K, int lda, int ldw, int ldo, int ldr, int resid_mod, int out_seg,
                   int out_seg_stride, int out_seg_off, int epilogue, void* stream);
 
+/* Tile override for psam_gemm_f16: 0 auto (default; also env PSAM_GEMM_TILE), 1 = 128x128x64 double-buffered,
+ * 2 = 256x128x32 and 3 = 256x256x32 with a 4-deep direct-to-LDS DMA ring. */
+int psam_gemm_set_tile(int tile);
+
 /* Row LayerNorm, fp32 in; out_dtype 0: half out (+ optional fp32 copy y2), 1: fp32 out. Appends `zero_tail_rows`
  * all-zero rows. torch.nn.LayerNorm of image_encoder.py:174-193, transformer.py:133-144 and LayerNorm2d
  * (modeling/common.py:31-43) on token-major rows; DINOv2 norm1/norm2/norm. */
@@ -108,10 +112,12 @@ int psam_small_attention(const void* q, const float* k, const float* v, void* ou
 /* token -> image cross attention over Nk <= 4096 keys (K, V half).  transformer.py:163-167, 98-103 */
 int psam_t2i_attention(const float* q, const void* K, const void* V, float* out, int B, int T, int Nk, int NH,
                        void* stream);
-/* y = [LayerNorm](x[row % in_mod] + add_vec); emits fp32 y, half y, half (y + pe[row % pe_mod]).
+/* y = [LayerNorm](x[src row] + add_vec); emits fp32 y, half y, half (y + pe[row % pe_mod]). With in_mod > 0 the input
+ * is one [in_mod,256] embedding per image and prompt row/in_mod reads image img_of_prompt[prompt] (null: image 0).
  * mask_decoder.py:126-127; transformer.py:164,178,180 */
 int psam_ln_pe(const float* x, const float* add_vec, const float* w, const float* b, const float* pe, float* y32,
-               void* y16, void* ype16, int M, int in_mod, int pe_mod, float eps, int do_ln, void* stream);
+               void* y16, void* ype16, int M, int in_mod, int pe_mod, float eps, int do_ln, const int* img_of_prompt,
+               void* stream);
 /* PromptEncoder.get_dense_pe (prompt_encoder.py:62-71,195-206), token-major fp32 [gh*gw, 256] */
 int psam_dense_pe(const float* G, int gh, int gw, float* pe, void* stream);
 /* output tokens ++ point / box-corner embeddings.  prompt_encoder.py:73-101,208-214; mask_decoder.py:121-123 */

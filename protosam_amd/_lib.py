@@ -18,6 +18,7 @@ c_void_p, c_int, c_float, c_longlong = ctypes.c_void_p, ctypes.c_int, ctypes.c_f
 # name -> argtypes; every entry point returns int (0 = ok). Kept in the same order as the header.
 SIGNATURES = {
     "psam_gemm_f16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p],
+    "psam_gemm_set_tile": [c_int],
     "psam_layernorm": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                        c_int, c_int, c_void_p],
     "psam_attention_f16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
@@ -37,7 +38,7 @@ SIGNATURES = {
     "psam_small_linear": [c_void_p] * 6 + [c_int] * 4 + [c_longlong] * 4 + [c_int] * 3 + [c_void_p],
     "psam_small_attention": [c_void_p] * 4 + [c_int] * 10 + [c_void_p],
     "psam_t2i_attention": [c_void_p] * 4 + [c_int] * 4 + [c_void_p],
-    "psam_ln_pe": [c_void_p] * 8 + [c_int, c_int, c_int, c_float, c_int, c_void_p],
+    "psam_ln_pe": [c_void_p] * 8 + [c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p],
     "psam_dense_pe": [c_void_p, c_int, c_int, c_void_p, c_void_p],
     "psam_prompt_tokens": [c_void_p] * 5 + [c_int, c_int, c_float, c_void_p, c_void_p],
     "psam_upscale_tail": [c_void_p] * 7 + [c_int, c_int, c_void_p],

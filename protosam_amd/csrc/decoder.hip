@@ -232,11 +232,15 @@ __global__ __launch_bounds__(256) void ln_pe_kernel(const float* __restrict__ x,
                                                     const float* __restrict__ w, const float* __restrict__ b,
                                                     const float* __restrict__ pe, float* __restrict__ y32,
                                                     half_t* __restrict__ y16, half_t* __restrict__ ype16, int M,
-                                                    int in_mod, int pe_mod, float eps, int do_ln) {
+                                                    int in_mod, int pe_mod, float eps, int do_ln,
+                                                    const int* __restrict__ img_of_prompt) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= M) return;
-  const int irow = in_mod ? row % in_mod : row;
+  // in_mod > 0: the input holds one [in_mod,256] embedding per image; prompt (row / in_mod) reads image
+  // img_of_prompt[prompt] (or image 0): `torch.repeat_interleave(image_embeddings, B)` of mask_decoder.py:126
+  int irow = row;
+  if (in_mod) irow = (img_of_prompt ? img_of_prompt[row / in_mod] : 0) * in_mod + row % in_mod;
   float4 v = reinterpret_cast<const float4*>(x + (size_t)irow * 256)[lane];
   if (add_vec) {
     float4 a = reinterpret_cast<const float4*>(add_vec)[lane];
@@ -267,10 +271,10 @@ __global__ __launch_bounds__(256) void ln_pe_kernel(const float* __restrict__ x,
 
 extern "C" int psam_ln_pe(const float* x, const float* add_vec, const float* w, const float* b, const float* pe,
                           float* y32, void* y16, void* ype16, int M, int in_mod, int pe_mod, float eps, int do_ln,
-                          void* stream) {
+                          const int* img_of_prompt, void* stream) {
   if (M <= 0 || pe_mod <= 0) return PSAM_ERR_ARG;
   hipLaunchKernelGGL(ln_pe_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, add_vec, w, b, pe, y32,
-                     (half_t*)y16, (half_t*)ype16, M, in_mod, pe_mod, eps, do_ln);
+                     (half_t*)y16, (half_t*)ype16, M, in_mod, pe_mod, eps, do_ln, img_of_prompt);
   return psam_launch_status();
 }
 

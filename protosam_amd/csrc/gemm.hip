@@ -19,6 +19,7 @@
 // (slot ^= (row>>1)&7) that makes the ds_read_b128 fragment reads bank-conflict-free is applied on
 // the DMA's per-lane SOURCE address, because the LDS side of the DMA is lane-linear.
 #include "common.h"
+#include <stdlib.h>
 
 enum { EPI_F16 = 0, EPI_GELU_F16 = 1, EPI_F32 = 2 };
 
@@ -35,7 +36,101 @@ struct GemmArgs {
   int out_seg;         // out row = out_seg ? (m / out_seg) * out_seg_stride + out_seg_off + m % out_seg : m
   int out_seg_stride;
   int out_seg_off;
+  int map_mode;  // 0: XCD-region tile map (default); 1: identity; 2: contiguous chunk per XCD
 };
+
+
+// ---- tile -> workgroup mapping ------------------------------------------------------------------------------------
+// Block b runs on XCD b % 8 (observed placement; used for speed only, never for correctness) and every XCD has a
+// private 4 MiB L2. The tiles an XCD works on CONCURRENTLY (32 CUs x blocks/CU) should therefore share as many A row
+// panels and W column panels as possible: the 8 XCDs are laid out as an xm x xn grid over the tile space (the split
+// that minimises rows + cols per region) and each XCD walks its region in 4-row strips, column by column, so any 32
+// consecutive tiles of an XCD form a ~4 x 8 patch (12 operand panels instead of 33 for a row-major chunk).
+// Measured on 8192^3 (256x256 tiles): DMA-only time 1213 us (contiguous chunk per XCD) -> 500 us (2-D spread).
+__device__ __forceinline__ bool tile_map(int bid, int ntm, int ntn, int mode, int& tm, int& tn) {
+  if (mode == 1) {
+    if (bid >= ntm * ntn) return false;
+    tm = bid / ntn;
+    tn = bid % ntn;
+    return true;
+  }
+  if (mode == 2) {
+    if (bid >= ntm * ntn) return false;
+    const int t = xcd_remap(bid, ntm * ntn);
+    tm = t / ntn;
+    tn = t % ntn;
+    return true;
+  }
+  const int xcd = bid & 7, idx = bid >> 3;
+  int xm = 8, xn = 1, best = (ntm + 7) / 8 + ntn;
+  {
+    int c = (ntm + 3) / 4 + (ntn + 1) / 2;
+    if (c < best) { best = c; xm = 4; xn = 2; }
+    c = (ntm + 1) / 2 + (ntn + 3) / 4;
+    if (c < best) { best = c; xm = 2; xn = 4; }
+    c = ntm + (ntn + 7) / 8;
+    if (c < best) { best = c; xm = 1; xn = 8; }
+  }
+  // proportional (balanced) split: region rx owns rows [rx*ntm/xm, (rx+1)*ntm/xm)
+  const int rx = xcd / xn, cx = xcd % xn;
+  const int r0 = (rx * ntm) / xm, c0 = (cx * ntn) / xn;
+  const int nr = ((rx + 1) * ntm) / xm - r0, nc = ((cx + 1) * ntn) / xn - c0;
+  if (nr <= 0 || nc <= 0 || idx >= nr * nc) return false;
+  const int strip = idx / (4 * nc), rem = idx - strip * 4 * nc;
+  const int rows = min(4, nr - strip * 4);
+  tm = r0 + strip * 4 + rem % rows;
+  tn = c0 + rem / rows;
+  return true;
+}
+// grid size that covers every region of tile_map (host side)
+static int tile_map_grid(int ntm, int ntn, int mode) {
+  if (mode != 0) return ntm * ntn;
+  int xm = 8, xn = 1, best = (ntm + 7) / 8 + ntn;
+  int c = (ntm + 3) / 4 + (ntn + 1) / 2;
+  if (c < best) { best = c; xm = 4; xn = 2; }
+  c = (ntm + 1) / 2 + (ntn + 3) / 4;
+  if (c < best) { best = c; xm = 2; xn = 4; }
+  c = ntm + (ntn + 7) / 8;
+  if (c < best) { best = c; xm = 1; xn = 8; }
+  const int R = (ntm + xm - 1) / xm, Cc = (ntn + xn - 1) / xn;
+  return 8 * R * Cc;
+}
+
+// Epilogue for one 32x32 accumulator computed as D^T = W_frag . X_frag^T (weights as the MFMA A operand): lane holds
+// output row m = mbase + (lane & 31) and, per register group q, four CONSECUTIVE columns n = nbase + 8q + 4*(lane>>5)
+// + 0..3, so bias / LayerScale / residual are float4 loads and the result is one 8-byte (fp16) or 16-byte (fp32) store.
+template <int EPI>
+__device__ __forceinline__ void store_acc32(const f32x16& acc, int m, int nb, const GemmArgs& p) {
+  if (m >= p.M) return;
+  const size_t orow = p.out_seg ? (size_t)(m / p.out_seg) * p.out_seg_stride + p.out_seg_off + (m % p.out_seg) : (size_t)m;
+  const size_t rrow = p.resid_mod ? (size_t)(m % p.resid_mod) : (size_t)m;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int n = nb + 8 * q;
+    float4 v = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    if (p.bias) {
+      const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    if (EPI == EPI_F16) {
+      half4_t h = {(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
+      *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(p.out) + orow * p.ldo + n) = h;
+    } else if (EPI == EPI_GELU_F16) {
+      half4_t h = {(half_t)gelu_erf(v.x), (half_t)gelu_erf(v.y), (half_t)gelu_erf(v.z), (half_t)gelu_erf(v.w)};
+      *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(p.out) + orow * p.ldo + n) = h;
+    } else {
+      if (p.gamma) {
+        const float4 g = *reinterpret_cast<const float4*>(p.gamma + n);
+        v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w;
+      }
+      if (p.resid) {
+        const float4 r = *reinterpret_cast<const float4*>(p.resid + rrow * p.ldr + n);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+      }
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + orow * p.ldo + n) = v;
+    }
+  }
+}
 
 #define BM 128
 #define BN 128
@@ -60,9 +155,10 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs p) {
 
   const int ntn = p.N / BN;
   const int ntm = (p.M + BM - 1) / BM;
-  const int tile = xcd_remap(blockIdx.x, ntm * ntn);
-  const int m0 = (tile / ntn) * BM;
-  const int n0 = (tile % ntn) * BN;
+  int tm, tn;
+  if (!tile_map(blockIdx.x, ntm, ntn, p.map_mode, tm, tn)) return;
+  const int m0 = tm * BM;
+  const int n0 = tn * BN;
 
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -126,50 +222,211 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs p) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);  // D^T
     }
     __syncthreads();  // all waves done reading buf[cur]; DMA into buf[cur^1] has landed (vmcnt(0))
   }
 
-  // epilogue. C layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // epilogue (transposed accumulators, see store_acc32)
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = n0 + wn * 64 + j * 32 + lr;
-    const float bv = p.bias ? p.bias[col] : 0.f;
-    float gv = 1.f;
-    if (EPI == EPI_F32) gv = p.gamma ? p.gamma[col] : 1.f;
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int j = 0; j < 2; ++j)
+      store_acc32<EPI>(acc[i][j], m0 + wm * 64 + i * 32 + lr, n0 + wn * 64 + j * 32 + 4 * lg, p);
+}
+
+// =====================================================================================================
+// Large-tile variant: 256 x BN x 32 k-steps, 512 threads = 8 waves (2 x 4), wave tile 128 x BN/4, 4-deep LDS ring
+// (4 x 32 KiB for BN = 256) filled by direct-to-LDS DMA three k-steps ahead. The load path (L2 -> LDS, ~20 B/clk/CU)
+// is what bounds a 128x128 tile (64 FLOP/B); the 256x256 tile halves the bytes per FLOP. One raw s_barrier per
+// k-step; the DMA queue is never drained inside the loop: `s_waitcnt vmcnt(2*LPT)` only retires the k-step about to
+// be read and leaves the next two in flight across the barrier.
+//   iteration t:  wait(tile t landed, own pieces) -> barrier (everyone's pieces landed; everyone finished reading
+//                 tile t-1) -> issue DMA of tile t+3 into the slot of tile t-1 -> MFMAs on tile t.
+template <int BN_>
+struct G256 {
+  static constexpr int BM_ = 256, BK_ = 32, NST = 4;
+  static constexpr int WN = BN_ / 4;        // wave tile width
+  static constexpr int NJ = WN / 32;        // 32-wide MFMA tiles per wave along N
+  static constexpr int A_EL = BM_ * BK_;    // halfs per stage (A)
+  static constexpr int B_EL = BN_ * BK_;
+  static constexpr int ST_EL = A_EL + B_EL;
+  static constexpr int PA = 2;              // 1-KiB A pieces per wave per stage (16 pieces / 8 waves)
+  static constexpr int PB = BN_ / 128;      // 1-KiB B pieces per wave per stage
+  static constexpr int LPT = PA + PB;       // DMA instructions per thread per stage
+  static constexpr int LDS_BYTES = NST * ST_EL * 2;
+};
+
+__device__ __forceinline__ int lds_off32(int row, int chunk) {
+  // [rows][32] fp16 tile (64-byte rows, 4 rows per 256-byte bank row): slot ^= (row>>2)&3 is conflict-free for the
+  // 16-lane groups of ds_read_b128
+  return row * 32 + ((chunk ^ ((row >> 2) & 3)) << 3);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int EPI, int BN_>
+__global__ __launch_bounds__(512) void gemm256_f16_kernel(GemmArgs p) {
+  using C = G256<BN_>;
+  extern __shared__ __attribute__((aligned(16))) half_t ring[];  // the ONLY LDS object of this kernel
+
+  const int ntn = p.N / BN_;
+  const int ntm = (p.M + C::BM_ - 1) / C::BM_;
+  int tm, tn;
+  if (!tile_map(blockIdx.x, ntm, ntn, p.map_mode, tm, tn)) return;
+  const int m0 = tm * C::BM_;
+  const int n0 = tn * BN_;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wv >> 2, wn = wv & 3;
+  const int lr = lane & 31, lg = lane >> 5;
+
+  // DMA source pointers: piece q = 16 tile rows; lane -> (row = q*16 + lane/4, slot = lane%4), chunk = slot ^ ((row>>2)&3)
+  const half_t* ag[C::PA];
+  const half_t* wg[C::PB];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
-        if (m < p.M) {
-          float v = acc[i][j][r] + bv;
-          size_t orow = p.out_seg ? (size_t)(m / p.out_seg) * p.out_seg_stride + p.out_seg_off + (m % p.out_seg)
-                                  : (size_t)m;
-          if (EPI == EPI_F16) {
-            reinterpret_cast<half_t*>(p.out)[orow * p.ldo + col] = (half_t)v;
-          } else if (EPI == EPI_GELU_F16) {
-            reinterpret_cast<half_t*>(p.out)[orow * p.ldo + col] = (half_t)gelu_erf(v);
-          } else {
-            v *= gv;
-            if (p.resid) {
-              size_t rrow = p.resid_mod ? (size_t)(m % p.resid_mod) : (size_t)m;
-              v += p.resid[rrow * p.ldr + col];
-            }
-            reinterpret_cast<float*>(p.out)[orow * p.ldo + col] = v;
-          }
-        }
-      }
-    }
+  for (int j = 0; j < C::PA; ++j) {
+    const int row = (wv * C::PA + j) * 16 + (lane >> 2);
+    const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+    int am = m0 + row;
+    am = am < p.M ? am : p.M - 1;
+    ag[j] = p.A + (size_t)am * p.lda + chunk * 8;
   }
+#pragma unroll
+  for (int j = 0; j < C::PB; ++j) {
+    const int row = (wv * C::PB + j) * 16 + (lane >> 2);
+    const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+    wg[j] = p.W + (size_t)(n0 + row) * p.ldw + chunk * 8;
+  }
+
+  auto stage = [&](int kt) {
+    half_t* base = ring + (kt & (C::NST - 1)) * C::ST_EL;
+#pragma unroll
+    for (int j = 0; j < C::PA; ++j) glds16(ag[j] + kt * C::BK_, base + (wv * C::PA + j) * 512);
+#pragma unroll
+    for (int j = 0; j < C::PB; ++j) glds16(wg[j] + kt * C::BK_, base + C::A_EL + (wv * C::PB + j) * 512);
+  };
+
+  f32x16 acc[4][C::NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < C::NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // Two wave groups (waves 0-3 / 4-7: one wave of each per SIMD) run the same phase sequence one barrier apart, so
+  // while one group is in its MFMA phase the other issues DMA and reads fragments:
+  //   L_s: issue DMA of k-step s+3 (into the slot of k-step s-1), read the 12 fragments of k-step s into registers,
+  //        wait until this wave's pieces of k-step s+1 have landed (two k-steps stay in flight), lgkmcnt(0), barrier
+  //   M_s: 16 MFMAs, barrier
+  // Slot reuse is safe: k-step s-1 was last read in L_{s-1} (lagging group: one phase before the leading group's L_s)
+  // and those reads were retired by the lgkmcnt(0) before that phase's closing barrier. A k-step is read only after a
+  // barrier that every wave passed after waiting for its own pieces of it.
+  const int nk = p.K / C::BK_;
+  stage(0);
+  if (nk > 1) stage(1);
+  if (nk > 2) stage(2);
+  if (nk > 2)
+    wait_vmcnt<2 * C::LPT>();
+  else if (nk > 1)
+    wait_vmcnt<C::LPT>();
+  else
+    wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();  // stagger the second group by one phase
+  asm volatile("" ::: "memory");
+
+  for (int kt = 0; kt < nk; ++kt) {
+    // ---- L phase -------------------------------------------------------------------------------------------------
+    if (kt + 3 < nk) stage(kt + 3);
+    const half_t* sa = ring + (kt & (C::NST - 1)) * C::ST_EL;
+    const half_t* sw = sa + C::A_EL;
+    half8_t fa[2][4], fb[2][C::NJ];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        fa[s][i] = *reinterpret_cast<const half8_t*>(&sa[lds_off32(wm * 128 + i * 32 + lr, s * 2 + lg)]);
+#pragma unroll
+      for (int j = 0; j < C::NJ; ++j)
+        fb[s][j] = *reinterpret_cast<const half8_t*>(&sw[lds_off32(wn * C::WN + j * 32 + lr, s * 2 + lg)]);
+    }
+    if (kt + 3 < nk)
+      wait_vmcnt<2 * C::LPT>();
+    else if (kt + 2 < nk)
+      wait_vmcnt<C::LPT>();
+    else
+      wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- M phase -------------------------------------------------------------------------------------------------
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < C::NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[s][j], fa[s][i], acc[i][j], 0, 0, 0);  // D^T
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();  // balance the stagger
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < C::NJ; ++j)
+      store_acc32<EPI>(acc[i][j], m0 + wm * 128 + i * 32 + lr, n0 + wn * C::WN + j * 32 + 4 * lg, p);
+}
+
+template <int EPI, int BN_>
+static void launch256(const GemmArgs& p, hipStream_t s) {
+  using C = G256<BN_>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm256_f16_kernel<EPI, BN_>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              C::LDS_BYTES);
+    attr = true;
+  }
+  const int ntm = (p.M + 255) / 256, ntn = p.N / BN_;
+  hipLaunchKernelGGL((gemm256_f16_kernel<EPI, BN_>), dim3(tile_map_grid(ntm, ntn, p.map_mode)), dim3(512),
+                     C::LDS_BYTES, s, p);
+}
+
+// tile choice: 0 = auto, 1 = 128x128, 2 = 256x128, 3 = 256x256 (PSAM_GEMM_TILE env var or psam_gemm_set_tile)
+static int g_tile_override = -1;
+extern "C" int psam_gemm_set_tile(int t) {
+  g_tile_override = t;
+  return PSAM_OK;
+}
+static int pick_tile(int M, int N, int K) {
+  if (g_tile_override < 0) {
+    const char* e = getenv("PSAM_GEMM_TILE");
+    g_tile_override = e ? atoi(e) : 0;
+  }
+  if (g_tile_override > 0) return g_tile_override;
+  // measured on MI355X (tools/gemm_maps.py): the 128x128 double-buffered kernel (2 workgroups per CU) wins on every
+  // K <= 5120 shape of the two ViTs; the 256x256 DMA-ring kernel wins once K and N are both large (8192^3: 1068 vs 908).
+  if (M >= 4096 && N >= 4096 && K >= 4096 && N % 256 == 0) return 3;
+  return 1;
 }
 
 extern "C" int psam_gemm_f16(const void* A, const void* W, const float* bias, void* out, const float* resid,
                              const float* gamma, int M, int N, int K, int lda, int ldw, int ldo, int ldr,
                              int resid_mod, int out_seg, int out_seg_stride, int out_seg_off, int epilogue,
                              void* stream) {
-  if (M <= 0 || N <= 0 || K <= 0 || (N % BN) != 0 || (K % BK) != 0 || (lda % 8) != 0 || (ldw % 8) != 0)
+  if (M <= 0 || N <= 0 || K <= 0 || (N % BN) != 0 || (K % BK) != 0 || (lda % 8) != 0 || (ldw % 8) != 0 ||
+      (ldo % 4) != 0 || (resid && (ldr % 4) != 0))
     return PSAM_ERR_ARG;
   if (epilogue < 0 || epilogue > 2) return PSAM_ERR_ARG;
   GemmArgs p;
@@ -190,9 +447,23 @@ extern "C" int psam_gemm_f16(const void* A, const void* W, const float* bias, vo
   p.out_seg = out_seg;
   p.out_seg_stride = out_seg_stride;
   p.out_seg_off = out_seg_off;
+  { const char* e = getenv("PSAM_GEMM_MAP"); p.map_mode = e ? atoi(e) : 0; }
   const int ntm = (M + BM - 1) / BM, ntn = N / BN;
-  dim3 grid(ntm * ntn), block(256);
+  dim3 grid(tile_map_grid(ntm, ntn, p.map_mode)), block(256);
   hipStream_t s = (hipStream_t)stream;
+  const int tsel = pick_tile(M, N, K);
+  if (tsel == 3 && N % 256 == 0) {
+    if (epilogue == EPI_F16) launch256<EPI_F16, 256>(p, s);
+    else if (epilogue == EPI_GELU_F16) launch256<EPI_GELU_F16, 256>(p, s);
+    else launch256<EPI_F32, 256>(p, s);
+    return psam_launch_status();
+  }
+  if (tsel == 2) {
+    if (epilogue == EPI_F16) launch256<EPI_F16, 128>(p, s);
+    else if (epilogue == EPI_GELU_F16) launch256<EPI_GELU_F16, 128>(p, s);
+    else launch256<EPI_F32, 128>(p, s);
+    return psam_launch_status();
+  }
   switch (epilogue) {
     case EPI_F16: hipLaunchKernelGGL(gemm_f16_kernel<EPI_F16>, grid, block, 0, s, p); break;
     case EPI_GELU_F16: hipLaunchKernelGGL(gemm_f16_kernel<EPI_GELU_F16>, grid, block, 0, s, p); break;

@@ -82,6 +82,11 @@ def gemm(a, w, bias=None, out=None, epilogue=EPI_F16, resid=None, gamma=None, re
     return out
 
 
+def gemm_set_tile(tile):
+    """0 auto, 1 = 128x128, 2 = 256x128, 3 = 256x256 (see csrc/gemm.hip)."""
+    _lib.check(_lib.lib().psam_gemm_set_tile(int(tile)), "psam_gemm_set_tile")
+
+
 def layernorm(x, weight, bias, eps, out=None, out_dtype=torch.float16, out2=None, zero_tail_rows=0, M=None):
     """Row LayerNorm of fp32 x[M,D]. Optionally writes `zero_tail_rows` all-zero rows after row M-1."""
     _req(x, torch.float32, "x"); _req(weight, torch.float32, "weight"); _req(bias, torch.float32, "bias")
@@ -328,10 +333,11 @@ def t2i_attention(q, K, V, out, B, T, Nk, NH):
     return out
 
 
-def ln_pe(x, pe, M, y32=None, y16=None, ype16=None, add_vec=None, w=None, b=None, in_mod=0, pe_mod=4096, eps=1e-5):
-    _req(x, torch.float32, "x"); _req(pe, torch.float32, "pe")
+def ln_pe(x, pe, M, y32=None, y16=None, ype16=None, add_vec=None, w=None, b=None, in_mod=0, pe_mod=4096, eps=1e-5,
+          img_of_prompt=None):
+    _req(x, torch.float32, "x"); _req(pe, torch.float32, "pe"); _req(img_of_prompt, torch.int32, "img_of_prompt")
     st = _lib.lib().psam_ln_pe(_ptr(x), _ptr(add_vec), _ptr(w), _ptr(b), _ptr(pe), _ptr(y32), _ptr(y16), _ptr(ype16), M,
-                              in_mod, pe_mod, float(eps), 1 if w is not None else 0, _stream())
+                              in_mod, pe_mod, float(eps), 1 if w is not None else 0, _ptr(img_of_prompt), _stream())
     _lib.check(st, "psam_ln_pe")
 
 
@@ -406,23 +412,33 @@ CC_HDR, CC_STRIDE = 8, 12
 
 
 class CclWorkspace:
-    def __init__(self, H, W, cap, device):
+    """Scratch for psam_ccl plus `slots` result tables (one per image of a batch), and their pinned host mirror."""
+
+    def __init__(self, H, W, cap, device, slots=1):
         n = H * W
-        self.H, self.W, self.cap = H, W, cap
+        self.H, self.W, self.cap, self.slots = H, W, cap, slots
         i32 = lambda k: torch.empty(k, dtype=torch.int32, device=device)  # noqa: E731
         self.parent, self.labels, self.counters, self.roots, self.acc_i = i32(n), i32(n), i32(2), i32(cap), i32(5 * cap)
         self.acc_u = torch.empty(3 * cap, dtype=torch.int64, device=device)
         self.acc_d = torch.empty(cap, dtype=torch.float64, device=device)
-        self.tab = torch.zeros(CC_HDR + CC_STRIDE * cap, dtype=torch.float64, device=device)
-        self.tab_host = torch.empty(CC_HDR + CC_STRIDE * cap, dtype=torch.float64).pin_memory()
+        self.tabs = torch.zeros((slots, CC_HDR + CC_STRIDE * cap), dtype=torch.float64, device=device)
+        self.tabs_host = torch.empty((slots, CC_HDR + CC_STRIDE * cap), dtype=torch.float64).pin_memory()
+
+    @property
+    def tab(self):
+        return self.tabs[0]
+
+    @property
+    def tab_host(self):
+        return self.tabs_host[0]
 
 
-def ccl(pred_u8, pfg, ws, fg_sum=None):
-    """pred uint8 [H,W], pfg fp32 [H,W] -> ws.labels (int32 [H*W]) and ws.tab (fp64 table, see csrc/ccl.hip)."""
+def ccl(pred_u8, pfg, ws, fg_sum=None, slot=0):
+    """pred uint8 [H,W], pfg fp32 [H,W] -> ws.labels (int32 [H*W]) and ws.tabs[slot] (fp64 table, see csrc/ccl.hip)."""
     assert pred_u8.dtype == torch.uint8 and pred_u8.is_cuda and pred_u8.is_contiguous()
     _req(pfg, torch.float32, "pfg")
     st = _lib.lib().psam_ccl(_ptr(pred_u8), _ptr(pfg), ws.H, ws.W, ws.cap, _ptr(ws.labels), _ptr(ws.parent),
                             _ptr(ws.counters), _ptr(ws.roots), _ptr(ws.acc_i), _ptr(ws.acc_u), _ptr(ws.acc_d),
-                            _ptr(fg_sum), _ptr(ws.tab), _stream())
+                            _ptr(fg_sum), _ptr(ws.tabs[slot]), _stream())
     _lib.check(st, "psam_ccl")
     return ws

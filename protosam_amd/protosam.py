@@ -233,74 +233,110 @@ class ProtoSAM(nn.Module):
         # predictor.predict: apply_coords with original_size == 1024 is the identity; torch.as_tensor(dtype=float)
         return np.asarray(coords, dtype=np.float64).astype(np.float32), np.asarray(labels, dtype=np.int32), rows
 
-    def _work_buffers(self, dev, H):
-        key = (str(dev), H)
+    def _work_buffers(self, dev, B):
+        key = (str(dev), B)
         if key not in self._bufs:
             self._bufs[key] = dict(
-                fg_sum=torch.zeros(1, dtype=torch.int32, device=dev),
-                prob=torch.empty((1, 2, 1024, 1024), dtype=torch.float32, device=dev),
-                pred=torch.empty((1, 1024, 1024), dtype=torch.uint8, device=dev),
-                q1024=torch.empty((1, 3, 1024, 1024), dtype=torch.float32, device=dev),
-                mm=torch.empty(2, dtype=torch.int32, device=dev),
-                patches=torch.empty((4096, 768), dtype=torch.float16, device=dev),
+                fg_sum=torch.zeros(B, dtype=torch.int32, device=dev),
+                prob=torch.empty((B, 2, 1024, 1024), dtype=torch.float32, device=dev),
+                pred=torch.empty((B, 1024, 1024), dtype=torch.uint8, device=dev),
+                q1024=torch.empty((B, 3, 1024, 1024), dtype=torch.float32, device=dev),
+                mm=torch.empty(2 * B, dtype=torch.int32, device=dev),
+                patches=torch.empty((B * 4096, 768), dtype=torch.float16, device=dev),
                 event=torch.cuda.Event())
-        if self._ccl is None:
-            self._ccl = ops.CclWorkspace(1024, 1024, MAX_COMPONENTS, dev)
+        if self._ccl is None or self._ccl.slots < B:
+            self._ccl = ops.CclWorkspace(1024, 1024, MAX_COMPONENTS, dev, slots=max(B, 1))
         return self._bufs[key]
 
     def forward(self, query_image, coarse_model_input, degrees_rotate=0):
+        """Reference contract (ProtoSAM.py:536-678): one query slice [1,3,H,W] -> (pred [H,W] float {0,1}, scores)."""
         if degrees_rotate != 0:
             raise NotImplementedError("rotation TTA (util/utils.py:40-83) is outside the hot path")
         if self.training:
             raise NotImplementedError("training-mode outputs (logits) are outside the inference hot path")
-        original_size = query_image.shape[-2]
-        dev = query_image.device
-        coarse_model_input.set_query_images(query_image)
-        output_logits = self.coarse_segmentation_model(coarse_model_input)      # [1,2,H,W]
         if self.coarse_pred_only:
-            return self._coarse_only(output_logits, original_size)
-        bufs = self._work_buffers(dev, original_size)
+            coarse_model_input.set_query_images(query_image)
+            output_logits = self.coarse_segmentation_model(coarse_model_input)
+            return self._coarse_only(output_logits, query_image.shape[-2])
+        return self.forward_batch(query_image, coarse_model_input)[0]
+
+    @torch.no_grad()
+    def forward_batch(self, query_images, coarse_model_input):
+        """MI355X extension: B independent query slices [B,3,H,W] sharing one support set go through every stage as
+        one batch (the ViT GEMMs see M = B*tokens rows, the mask decoder sees all components of all slices at once).
+        Slices never interact, so each result equals the per-slice `forward`. Returns a list of (pred, scores)."""
+        B = query_images.shape[0]
+        original_size = query_images.shape[-2]
+        dev = query_images.device
+        coarse_model_input.set_query_images(query_images)
+        output_logits = self.coarse_segmentation_model(coarse_model_input)      # [B,2,H,W]
+        bufs = self._work_buffers(dev, B)
         sam = self.sam
         S = sam.image_encoder.img_size
         # 1. (bilinear to 1024) -> softmax -> argmax                               ProtoSAM.py:592-602
         bufs["fg_sum"].zero_()
         output_p, pred = ops.prob_argmax(output_logits.float().contiguous(), S, S, prob=bufs["prob"], pred=bufs["pred"],
                                          fg_sum=bufs["fg_sum"])
-        # 2. connected components + per-component statistics, table -> pinned host memory (async)
-        cw = ops.ccl(pred[0], output_p[0, 1], self._ccl, fg_sum=bufs["fg_sum"])
-        cw.tab_host.copy_(cw.tab, non_blocking=True)
+        # 2. connected components + per-component statistics; the tables go to pinned host memory asynchronously
+        cw = self._ccl
+        for b in range(B):
+            ops.ccl(pred[b], output_p[b, 1], cw, fg_sum=bufs["fg_sum"][b:b + 1], slot=b)
+        cw.tabs_host[:B].copy_(cw.tabs[:B], non_blocking=True)
         bufs["event"].record()
         # 3. image hand-off: resize -> min/max -> uint8 quantise -> SAM normalise -> im2col      ProtoSAM.py:592-593,651-660
-        q = query_image.float().contiguous()
+        q = query_images.float().contiguous()
         if tuple(q.shape[-2:]) != (S, S):
             q = ops.bilinear_nchw(q, S, S, out=bufs["q1024"])
-        ops.minmax(q, 1, mm=bufs["mm"])
+        ops.minmax(q, B, mm=bufs["mm"])
         ops.sam_patchify(q, bufs["mm"], S, sam.image_encoder.patch_size, sam._mean_host, sam._std_host, True,
                          out=bufs["patches"])
-        # 4. SAM image encoder (enqueued before the host looks at the component table)
-        feat_tok = sam.image_encoder.encode_patches(bufs["patches"], 1)[0]       # [4096, 256] token-major
-        # 5. host: number of components and prompts
+        # 4. SAM image encoder (enqueued before the host looks at the component tables)
+        feat_tok = sam.image_encoder.encode_patches(bufs["patches"], B)         # [B, 4096, 256] token-major
+        # 5. host: number of components and prompts per slice
         bufs["event"].synchronize()
-        tab = cw.tab_host.numpy()
-        n_found, n = int(tab[0]), int(tab[1])
-        self.last_stats = dict(n_components=n_found, fg_pixels=int(tab[2]))
-        if n == 0:                                                              # ProtoSAM.py:612-613
-            return output_p.argmax(dim=1)[0], [0]
-        coords, labels, rows = self._prompts_from_table(tab)
-        B, Ns = labels.shape
-        pe = sam.prompt_encoder._packed()
-        dpk = sam.mask_decoder._packed()
-        tokens = ops.prompt_tokens(torch.from_numpy(coords).to(dev, non_blocking=True),
-                                   torch.from_numpy(labels).to(dev, non_blocking=True), pe["G"], pe["type_emb"],
-                                   dpk["out_tok"], B, Ns, float(S))
-        # 6. batched two-way decoder over all components                         ProtoSAM.py:500-527
-        masks, iou, _ = sam.mask_decoder.predict_masks_tokens(feat_tok, pe["pe_tok"], tokens, pe["no_mask"])
-        sel = 0 if self.use_cca else 1                                          # multimask_output = not use_cca; index 0
-        # 7. upsample -> > 0 -> union over components -> nearest to the input size   ProtoSAM.py:669-676
-        out = ops.mask_union(masks, sel, S, original_size, sam.variant_id(), sam.mask_threshold)
-        scores = [np.float32(v) for v in iou[:, sel].cpu().numpy()]
-        self.last_stats.update(n_prompts=B, low_res=masks, iou=iou, sel=sel, table=rows)
-        return out, scores
+        tabs = cw.tabs_host[:B].numpy()
+        results = [None] * B
+        coords, labels, img_idx, spans = [], [], [], []
+        stats = []
+        for b in range(B):
+            tab = tabs[b]
+            n_found, n = int(tab[0]), int(tab[1])
+            stats.append(dict(n_components=n_found, fg_pixels=int(tab[2]), n_prompts=0))
+            if n == 0:                                                          # ProtoSAM.py:612-613
+                results[b] = (output_p[b].argmax(dim=0), [0])
+                continue
+            c, l, rows = self._prompts_from_table(tab)
+            spans.append((b, len(img_idx), len(l)))
+            coords.append(c)
+            labels.append(l)
+            img_idx += [b] * len(l)
+            stats[b].update(n_prompts=len(l), table=rows)
+        self.last_stats = stats[0] if B == 1 else dict(per_slice=stats)
+        if spans:
+            coords = np.concatenate(coords, 0)
+            labels = np.concatenate(labels, 0)
+            P, Ns = labels.shape
+            pe = sam.prompt_encoder._packed()
+            dpk = sam.mask_decoder._packed()
+            tokens = ops.prompt_tokens(torch.from_numpy(coords).to(dev, non_blocking=True),
+                                       torch.from_numpy(labels).to(dev, non_blocking=True), pe["G"], pe["type_emb"],
+                                       dpk["out_tok"], P, Ns, float(S))
+            iop = torch.tensor(img_idx, dtype=torch.int32).to(dev, non_blocking=True)
+            # 6. batched two-way decoder over all components of all slices           ProtoSAM.py:500-527
+            masks, iou, _ = sam.mask_decoder.predict_masks_tokens(feat_tok, pe["pe_tok"], tokens, pe["no_mask"],
+                                                                  img_of_prompt=iop)
+            sel = 0 if self.use_cca else 1                                      # multimask_output = not use_cca; index 0
+            iou_host = iou[:, sel].cpu().numpy()
+            for (b, start, cnt) in spans:
+                # 7. upsample -> > 0 -> union over components -> nearest to the input size   ProtoSAM.py:669-676
+                out = ops.mask_union(masks[start:start + cnt], sel, S, original_size, sam.variant_id(),
+                                     sam.mask_threshold)
+                results[b] = (out, [np.float32(v) for v in iou_host[start:start + cnt]])
+            if B == 1:
+                self.last_stats.update(low_res=masks, iou=iou, sel=sel)
+            else:
+                self.last_stats.update(low_res=masks, iou=iou, sel=sel, spans=spans)
+        return results
 
     def _coarse_only(self, output_logits, original_size):
         """ProtoSAM.py:580-590 (inference): argmax map, mean fg confidence; optional CCA keeps the best component."""
@@ -308,7 +344,7 @@ class ProtoSAM(nn.Module):
         H = output_logits.shape[-2]
         if H != 1024:
             raise NotImplementedError("coarse_pred_only is wired for 1024x1024 logits only")
-        bufs = self._work_buffers(dev, original_size)
+        bufs = self._work_buffers(dev, 1)
         bufs["fg_sum"].zero_()
         prob, pred = ops.prob_argmax(output_logits.float().contiguous(), H, H, prob=bufs["prob"], pred=bufs["pred"],
                                      fg_sum=bufs["fg_sum"])

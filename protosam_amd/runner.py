@@ -57,24 +57,36 @@ def shard_slices(n_slices, rank, world):
 
 
 @torch.no_grad()
-def run_slices(model, vol, sup_imgs, sup_masks, zs, device, out=None):
-    """Runs ProtoSAM.forward on slices `zs` of `vol` [n,S,S] (device tensor); returns uint8 masks [len(zs),S,S]."""
+def run_slices(model, vol, sup_imgs, sup_masks, zs, device, out=None, batch=1):
+    """Runs ProtoSAM on slices `zs` of `vol` [n,S,S] (device tensor), `batch` slices of one z-part at a time through
+    `forward_batch`; returns uint8 masks [len(zs),S,S] and the number of prompts per slice."""
     n, S = vol.shape[0], vol.shape[-1]
     if out is None:
         out = torch.zeros((len(zs), S, S), dtype=torch.uint8, device=device)
-    stats = []
-    cur_part, inp = None, None
-    for i, z in enumerate(zs):
-        part = part_assign(z, n)
-        q = vol[z][None, None].expand(1, 3, S, S).contiguous()
-        if part != cur_part:
-            inp = InputFactory.create_input(TYPE_ALPNET, q, support_images=[sup_imgs[part]],
-                                            support_labels=[sup_masks[part]], isval=True, val_wsize=2)
-            cur_part = part
-        pred, scores = model(q, inp, degrees_rotate=0)
-        if pred.shape[-1] == S:
-            out[i] = pred.to(torch.uint8)
-        stats.append(model.last_stats.get("n_prompts", 0))
+    stats = [0] * len(zs)
+    inputs = {}
+    i = 0
+    while i < len(zs):
+        part = part_assign(zs[i], n)
+        j = i
+        while j < len(zs) and j - i < batch and part_assign(zs[j], n) == part:
+            j += 1
+        idx = torch.tensor(zs[i:j], device=device)
+        q = vol[idx][:, None].expand(j - i, 3, S, S).contiguous()
+        if part not in inputs:
+            inputs[part] = InputFactory.create_input(TYPE_ALPNET, q, support_images=[sup_imgs[part]],
+                                                     support_labels=[sup_masks[part]], isval=True, val_wsize=2)
+        if batch == 1:
+            res = [model(q, inputs[part], degrees_rotate=0)]
+            st = [model.last_stats]
+        else:
+            res = model.forward_batch(q, inputs[part])
+            st = model.last_stats.get("per_slice", [model.last_stats])
+        for k, (pred, scores) in enumerate(res):
+            if pred.shape[-1] == S:
+                out[i + k] = pred.to(torch.uint8)
+            stats[i + k] = st[k].get("n_prompts", 0) if k < len(st) else 0
+        i = j
     return out, stats
 
 

@@ -109,12 +109,14 @@ class MaskDecoder(nn.Module):
         return self._ws[key]
 
     # ---- the decoder ---------------------------------------------------------------------------------------------
-    def predict_masks_tokens(self, feat_tok, pe_tok, tokens, dense_vec):
-        """feat_tok fp32 [Nk,256] token-major image embedding (ONE image), pe_tok fp32 [Nk,256], tokens fp32 [B,T,256]
-        (output tokens ++ sparse prompts), dense_vec fp32 [256] (no-mask embedding). -> masks [B,4,256,256], iou [B,4]."""
+    def predict_masks_tokens(self, feat_tok, pe_tok, tokens, dense_vec, img_of_prompt=None):
+        """feat_tok fp32 [Nk,256] (one image) or [n_img,Nk,256] token-major image embeddings, pe_tok fp32 [Nk,256],
+        tokens fp32 [B,T,256] (output tokens ++ sparse prompts), dense_vec fp32 [256] (no-mask embedding),
+        img_of_prompt int32 [B] (which image each prompt set belongs to; None = image 0).
+        -> masks [B,4,256,256], iou [B,4]."""
         pk = self._packed()
         B, T, _ = tokens.shape
-        Nk = feat_tok.shape[0]
+        Nk = feat_tok.shape[-2]
         g = int(Nk ** 0.5)
         if T > 16:
             raise NotImplementedError("more than 11 sparse prompt tokens per prompt set")
@@ -123,7 +125,8 @@ class MaskDecoder(nn.Module):
         keys, k16, kpe16, q = ws["keys"], ws["k16"], ws["kpe16"], ws["q"]
         tok2 = tokens.reshape(B * T, 256).contiguous()  # query_pe (transformer.py:88-96)
         lin = ops.small_linear
-        ops.ln_pe(feat_tok, pe_tok, B * Nk, y32=keys, y16=k16, ype16=kpe16, add_vec=dense_vec, in_mod=Nk, pe_mod=Nk)
+        ops.ln_pe(feat_tok, pe_tok, B * Nk, y32=keys, y16=k16, ype16=kpe16, add_vec=dense_vec, in_mod=Nk, pe_mod=Nk,
+                  img_of_prompt=img_of_prompt)
 
         def t2i(ap, resid_ln):
             lin(q, ap["qw"], ap["qb"], out=ws["tq128"], x2=tok2)

@@ -38,6 +38,35 @@ def test_gemm(dev, M, N, K, epi):
         torch.testing.assert_close(out, resid + gamma * ref, rtol=1e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("tile", [2, 3])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (1297, 768, 768), (4096, 1280, 1280), (1000, 512, 192)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_large_tiles(dev, tile, M, N, K, epi):
+    """256x128 / 256x256 DMA-ring kernels, forced through psam_gemm_set_tile (K multiple of 32 suffices here)."""
+    from protosam_amd import ops
+    if K % 64:
+        pytest.skip("the C ABI requires K % 64 == 0 for every tile")
+    a = _rand((M, K), dev, 1.0, 11).half()
+    w = _rand((N, K), dev, 0.05, 12).half()
+    bias = _rand((N,), dev, 0.5, 13)
+    ref = a.float() @ w.float().t() + bias
+    ops.gemm_set_tile(tile)
+    try:
+        if epi == 0:
+            out = ops.gemm(a, w, bias, epilogue=ops.EPI_F16)
+            torch.testing.assert_close(out.float(), ref, rtol=2e-3, atol=2e-3)
+        elif epi == 1:
+            out = ops.gemm(a, w, bias, epilogue=ops.EPI_GELU_F16)
+            torch.testing.assert_close(out.float(), torch.nn.functional.gelu(ref), rtol=2e-3, atol=2e-3)
+        else:
+            resid = _rand((M, N), dev, 1.0, 14)
+            gamma = _rand((N,), dev, 1.0, 15)
+            out = ops.gemm(a, w, bias, epilogue=ops.EPI_F32, resid=resid, gamma=gamma)
+            torch.testing.assert_close(out, resid + gamma * ref, rtol=1e-4, atol=2e-4)
+    finally:
+        ops.gemm_set_tile(0)
+
+
 def test_gemm_row_remap_and_resid_mod(dev):
     """patch-embed style: rows of batch b land at b*stride + off + p, resid (pos-embed) indexed by p."""
     from protosam_amd import ops

@@ -153,3 +153,25 @@ def test_protosam_constructor_errors():
         ProtoSAM((1024, 1024), None, "random:vit_b:1:0", use_points=False, use_bbox=False, use_mask=False)
     with pytest.raises(ValueError):
         ProtoSAM((1024, 1024), None, "random:vit_b:1:0", point_mode="nearest")
+
+
+def test_forward_batch_equals_per_slice(dev):
+    """The batched extension gives, slice by slice, what the reference-shaped per-slice forward gives."""
+    from protosam_amd.protosam import InputFactory, TYPE_ALPNET
+    from protosam_amd.synth import synth_pair
+    model, _ = _build(dev, "random:vit_b:1234:2", 2, use_bbox=True, use_points=True, point_mode="both")
+    s_img, s_m, q0, _ = synth_pair(512, seed=0)
+    _, _, q1, _ = synth_pair(512, seed=3)
+    _, _, q2, _ = synth_pair(512, seed=5)
+    qs = torch.cat([q0, q1, q2], 0).to(dev)
+    inp = InputFactory.create_input(TYPE_ALPNET, qs, support_images=[s_img], support_labels=[s_m], isval=True,
+                                    val_wsize=2)
+    inp.to(dev)
+    batched = model.forward_batch(qs, inp)
+    assert len(batched) == 3
+    for b in range(3):
+        p1, s1 = model(qs[b:b + 1], inp, degrees_rotate=0)
+        pb, sb = batched[b]
+        assert pb.shape == p1.shape
+        assert (pb != p1).sum().item() <= 8, (b, (pb != p1).sum().item())
+        assert len(sb) == len(s1) and np.allclose(np.array(sb, dtype=np.float64), np.array(s1, dtype=np.float64), atol=2e-3)

@@ -28,8 +28,13 @@ def main():
         w = (torch.randn(N, K, device=dev) * 0.05).half()
         b = torch.randn(N, device=dev)
         out = torch.empty(M, N, device=dev, dtype=torch.float16)
-        t = timeit(lambda: ops.gemm(a, w, b, out=out, epilogue=ops.EPI_F16))
-        print(f"gemm {M}x{N}x{K}: {t*1e6:8.1f} us  {2*M*N*K/t/1e12:7.1f} TF/s", flush=True)
+        for tile in (1, 2, 3, 0):
+            if tile == 3 and N % 256:
+                continue
+            ops.gemm_set_tile(tile)
+            t = timeit(lambda: ops.gemm(a, w, b, out=out, epilogue=ops.EPI_F16))
+            print(f"gemm {M}x{N}x{K} tile{tile}: {t*1e6:8.1f} us  {2*M*N*K/t/1e12:7.1f} TF/s", flush=True)
+        ops.gemm_set_tile(0)
         tt = timeit(lambda: torch.matmul(a, w.t()))
         print(f"   torch(hipblaslt) same shape: {tt*1e6:8.1f} us  {2*M*N*K/tt/1e12:7.1f} TF/s", flush=True)
     for (M, D) in [(4096, 1280), (8 * 1297, 768)]:
