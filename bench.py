@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8, help="query slices per rank per step")
-    ap.add_argument("--micro", type=int, default=4, help="slices pushed through the kernels together (1 = per-slice "
+    ap.add_argument("--micro", type=int, default=8, help="slices pushed through the kernels together (1 = per-slice "
                     "ProtoSAM.forward exactly as the reference caller; >1 = ProtoSAM.forward_batch)")
     ap.add_argument("--sam", default="vit_h", choices=["vit_b", "vit_l", "vit_h"])
     ap.add_argument("--slices", type=int, default=64)

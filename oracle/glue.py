@@ -167,7 +167,7 @@ def protosam_forward(query_image, output_logits, sam_sd, sam_type="vit_b", use_b
         query_image = F.interpolate(query_image, size=(1024, 1024), mode="bilinear")
         output_logits = F.interpolate(output_logits, size=(1024, 1024), mode="bilinear")
     output_p = output_logits.softmax(dim=1)                                               # :599-602
-    _pred = np.array(output_p.argmax(dim=1)[0])
+    _pred = output_p.argmax(dim=1)[0].numpy()
     if use_cca:
         cc, conf = cca(_pred, output_logits), None
     else:
@@ -196,3 +196,30 @@ def protosam_forward(query_image, output_logits, sam_sd, sam_type="vit_b", use_b
     pred = torch.tensor(sum(masks) > 0).float()                                            # :669-672
     pred = F.interpolate(pred[None, None], size=original_size, mode="nearest")[0][0]       # :676
     return pred, scores
+
+
+def protomedsam_forward(query_image, output_logits, sam_sd, sam_type="vit_b", use_cca=True, encoder_depth=None, taps=None):
+    """ProtoMedSAM.forward after the coarse model (models/ProtoMedSAM.py:122-222; PARITY UNPINNED as a whole -- the file
+    imports the absent pip `segment_anything` and cv2 -- but every stage it calls is pinned elsewhere)."""
+    original_size = query_image.shape[-2]
+    if tuple(query_image.shape[-2:]) != (1024, 1024):
+        query_image = F.interpolate(query_image, size=(1024, 1024), mode="bilinear")
+        output_logits = F.interpolate(output_logits, size=(1024, 1024), mode="bilinear")
+    output_p = output_logits.softmax(dim=1)                       # need_softmax(ALP logits) is True (:178-179)
+    _pred = output_p.argmax(dim=1)[0].numpy()
+    cc = cca(_pred, output_p) if use_cca else get_connected_components(_pred, output_p)[0]   # softmax applied AGAIN inside
+    if _pred.max() == 0:
+        return F.interpolate(output_p, size=original_size, mode="bilinear").argmax(dim=1)[0], [0]
+    H, W = query_image.shape[-2:]
+    bbox = bbox_per_cc(cc) / np.array([W, H, W, H]) * 1024
+    qi = (query_image - query_image.min()) / (query_image.max() - query_image.min())
+    feats = oenc.image_encoder(qi, sam_sd, model_type=sam_type, depth=encoder_depth)
+    box = torch.as_tensor(bbox, dtype=torch.float)[:, None, :]
+    sparse, dense = odec.prompt_encoder(sam_sd, None, box)
+    low, conf = odec.mask_decoder(sam_sd, feats, odec.dense_pe(sam_sd), sparse, dense, False)
+    pr = F.interpolate(torch.sigmoid(low), size=(H, W), mode="bilinear", align_corners=False).squeeze()
+    seg = torch.tensor((pr.numpy() > 0.5).astype(np.uint8))
+    if taps is not None:
+        taps.update(low=low, cc=cc)
+    seg = F.interpolate(seg[None, None], size=original_size, mode="nearest")[0][0]
+    return seg, [conf.numpy()]

@@ -432,7 +432,8 @@ extern "C" int psam_upscale_tail(const float* u1, const float* lnw, const float*
 
 // =====================================================================================================
 // Mask post-processing. variant 0: bilinear align_corners=False (pip segment_anything 1.0 `Sam`),
-// 1: bilinear align_corners=True (vendored `SamBatched`, sam.py:313-320), 2: nearest (vendored `Sam`, sam.py:154-160).
+// 1: bilinear align_corners=True (vendored `SamBatched`, sam.py:313-320), 2: nearest (vendored `Sam`, sam.py:154-160),
+// 3: sigmoid, then bilinear align_corners=False (MedSAM inference, models/ProtoMedSAM.py:49-60; threshold 0.5).
 struct Lin2 {
   int i0, i1;
   float l0, l1;
@@ -470,7 +471,14 @@ __device__ __forceinline__ float up_sample(const float* __restrict__ p, int IN, 
   Lin2 ly = lin2(y, IN, MID, variant == 1), lx = lin2(x, IN, MID, variant == 1);
   const float* r0 = p + (size_t)ly.i0 * IN;
   const float* r1 = p + (size_t)ly.i1 * IN;
-  return ly.l0 * (lx.l0 * r0[lx.i0] + lx.l1 * r0[lx.i1]) + ly.l1 * (lx.l0 * r1[lx.i0] + lx.l1 * r1[lx.i1]);
+  float a = r0[lx.i0], b = r0[lx.i1], c = r1[lx.i0], d = r1[lx.i1];
+  if (variant == 3) {  // torch.sigmoid(low_res_logits) BEFORE the bilinear resize (models/ProtoMedSAM.py:49-56)
+    a = 1.f / (1.f + expf(-a));
+    b = 1.f / (1.f + expf(-b));
+    c = 1.f / (1.f + expf(-c));
+    d = 1.f / (1.f + expf(-d));
+  }
+  return ly.l0 * (lx.l0 * a + lx.l1 * b) + ly.l1 * (lx.l0 * c + lx.l1 * d);
 }
 
 // masks [B, C, IN, IN] logits -> logits at [B, C, MID, MID] (the predictor's `masks` before thresholding when the image
@@ -482,7 +490,7 @@ __global__ void mask_upsample_kernel(const float* __restrict__ low, int IN, int 
   out[((size_t)pl * MID + y) * MID + x] = up_sample(low + (size_t)pl * IN * IN, IN, MID, y, x, variant);
 }
 extern "C" int psam_mask_upsample(const float* low, int planes, int IN, int MID, int variant, float* out, void* stream) {
-  if (planes <= 0 || variant < 0 || variant > 2) return PSAM_ERR_ARG;
+  if (planes <= 0 || variant < 0 || variant > 3) return PSAM_ERR_ARG;
   hipLaunchKernelGGL(mask_upsample_kernel, dim3((MID + 255) / 256, MID, planes), dim3(256), 0, (hipStream_t)stream, low,
                      IN, MID, variant, out);
   return psam_launch_status();
@@ -507,7 +515,7 @@ __global__ void mask_union_kernel(const float* __restrict__ low, int B, int C, i
 }
 extern "C" int psam_mask_union(const float* low, int B, int C, int sel, int IN, int MID, int OUT, int variant, float thr,
                                float* pred, void* stream) {
-  if (B <= 0 || sel < 0 || sel >= C || variant < 0 || variant > 2) return PSAM_ERR_ARG;
+  if (B <= 0 || sel < 0 || sel >= C || variant < 0 || variant > 3) return PSAM_ERR_ARG;
   hipLaunchKernelGGL(mask_union_kernel, dim3((OUT + 255) / 256, OUT), dim3(256), 0, (hipStream_t)stream, low, B, C, sel,
                      IN, MID, OUT, variant, thr, pred);
   return psam_launch_status();

@@ -1,0 +1,121 @@
+"""`ProtoMedSAM` on the HIP path (mirror of /root/reference/models/ProtoMedSAM.py:10-222).
+
+Same constructor and `forward(query_image, coarse_model_input, degrees_rotate=0) -> (uint8 mask [H,W], [conf])` contract.
+Differences from `ProtoSAM` that are reproduced: box prompts only; the image is min-max scaled to [0,1]
+floats (no uint8 quantisation, no mean/std) before `medsam.image_encoder`; `mask_decoder(multimask_output=False)`;
+`sigmoid` BEFORE the bilinear resize and a 0.5 threshold; the component confidences are computed from
+`softmax(softmax(logits))` because `get_connected_components` re-applies softmax to the already-softmaxed tensor
+(ProtoMedSAM.py:178-187, util/utils.py:485); an empty coarse mask returns the arg-max map at the ORIGINAL size (:194-197).
+More than one connected component without `use_cca` is undefined in the reference (5-D nearest interpolate, SURVEY
+Q16) and raises here.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .protosam import MAX_COMPONENTS, ModelWrapper
+from .segment_anything import sam_model_registry
+
+
+class ProtoMedSAM(nn.Module):
+    def __init__(self, image_size, coarse_segmentation_model: ModelWrapper,
+                 sam_pretrained_path="pretrained_model/medsam_vit_b.pth", debug=False, use_cca=False,
+                 coarse_pred_only=False):
+        super().__init__()
+        if isinstance(image_size, int):
+            image_size = (image_size, image_size)
+        self.image_size = image_size
+        self.coarse_segmentation_model = coarse_segmentation_model
+        self.get_sam(sam_pretrained_path)
+        self.coarse_pred_only = coarse_pred_only
+        self.debug = debug
+        self.use_cca = use_cca
+        if debug or coarse_pred_only:
+            raise NotImplementedError("debug plots / coarse_pred_only are outside the accelerated path")
+        if tuple(self.image_size) != (1024, 1024):
+            raise NotImplementedError("image_size must be (1024, 1024) as in validation_protosam.py:234")
+        self._ccl = None
+        self._bufs = {}
+        self.last_stats = {}
+
+    def get_sam(self, checkpoint_path):
+        model_type = "vit_b"
+        if checkpoint_path is not None and "vit_h" in checkpoint_path:
+            model_type = "vit_h"
+        if checkpoint_path is not None and checkpoint_path.startswith("random:"):
+            from .synth import synth_state_dict
+            parts = checkpoint_path.split(":")
+            model_type = parts[1]
+            seed = int(parts[2]) if len(parts) > 2 else 1234
+            depth = int(parts[3]) if len(parts) > 3 else None
+            self.medsam = sam_model_registry[model_type](encoder_depth=depth)
+            self.medsam.load_state_dict(synth_state_dict(self.medsam, seed))
+            self.medsam.eval()
+        else:
+            self.medsam = sam_model_registry[model_type](checkpoint=checkpoint_path).eval()
+
+    def _work(self, dev):
+        if not self._bufs:
+            self._bufs = dict(fg_sum=torch.zeros(1, dtype=torch.int32, device=dev),
+                              prob=torch.empty((1, 2, 1024, 1024), dtype=torch.float32, device=dev),
+                              prob2=torch.empty((1, 2, 1024, 1024), dtype=torch.float32, device=dev),
+                              pred=torch.empty((1, 1024, 1024), dtype=torch.uint8, device=dev),
+                              pred2=torch.empty((1, 1024, 1024), dtype=torch.uint8, device=dev),
+                              q1024=torch.empty((1, 3, 1024, 1024), dtype=torch.float32, device=dev),
+                              mm=torch.empty(2, dtype=torch.int32, device=dev),
+                              patches=torch.empty((4096, 768), dtype=torch.float16, device=dev),
+                              event=torch.cuda.Event())
+            self._ccl = ops.CclWorkspace(1024, 1024, MAX_COMPONENTS, dev)
+        return self._bufs
+
+    @torch.no_grad()
+    def forward(self, query_image, coarse_model_input, degrees_rotate=0):
+        if degrees_rotate != 0:
+            raise NotImplementedError("rotation TTA is outside the hot path")
+        original_size = query_image.shape[-2]
+        dev = query_image.device
+        coarse_model_input.set_query_images(query_image)
+        output_logits = self.coarse_segmentation_model(coarse_model_input)                 # [1,2,H,W] ALP logits
+        bufs = self._work(dev)
+        sam = self.medsam
+        S = sam.image_encoder.img_size
+        bufs["fg_sum"].zero_()
+        # bilinear to 1024 -> softmax (need_softmax is True for ALP logits, :178-179) -> argmax
+        output_p, pred = ops.prob_argmax(output_logits.float().contiguous(), S, S, prob=bufs["prob"], pred=bufs["pred"],
+                                         fg_sum=bufs["fg_sum"])
+        # get_connected_components softmaxes its `logits` argument again (util/utils.py:485)
+        p2, _ = ops.prob_argmax(output_p, S, S, prob=bufs["prob2"], pred=bufs["pred2"])
+        cw = ops.ccl(pred[0], p2[0, 1], self._ccl, fg_sum=bufs["fg_sum"])
+        cw.tab_host.copy_(cw.tab, non_blocking=True)
+        bufs["event"].record()
+        q = query_image.float().contiguous()
+        if tuple(q.shape[-2:]) != (S, S):
+            q = ops.bilinear_nchw(q, S, S, out=bufs["q1024"])
+        ops.minmax(q, 1, mm=bufs["mm"])
+        ops.sam_patchify(q, bufs["mm"], S, sam.image_encoder.patch_size, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), False,
+                         out=bufs["patches"])                                              # :203-205
+        feat_tok = sam.image_encoder.encode_patches(bufs["patches"], 1)[0]
+        bufs["event"].synchronize()
+        tab = cw.tab_host.numpy()
+        n = int(tab[1])
+        self.last_stats = dict(n_components=int(tab[0]))
+        if n == 0:                                                                         # :194-197
+            return torch.zeros((original_size, original_size), dtype=torch.int64, device=dev), [0]
+        rows = tab[ops.CC_HDR:ops.CC_HDR + ops.CC_STRIDE * n].reshape(n, ops.CC_STRIDE)
+        if self.use_cca:
+            rows = rows[int(tab[3]):int(tab[3]) + 1]
+        if rows.shape[0] != 1:
+            raise NotImplementedError("ProtoMedSAM with several components is undefined in the reference (SURVEY Q16); "
+                                      "use use_cca=True")
+        boxes = rows[:, 3:7] / np.array([S, S, S, S]) * max(self.image_size)               # :201-202 (identity at 1024)
+        coords = boxes.reshape(-1, 2, 2).astype(np.float32)
+        labels = np.tile(np.array([[2, 3]], dtype=np.int32), (coords.shape[0], 1))
+        pe = sam.prompt_encoder._packed()
+        dpk = sam.mask_decoder._packed()
+        tokens = ops.prompt_tokens(torch.from_numpy(coords).to(dev), torch.from_numpy(labels).to(dev), pe["G"],
+                                   pe["type_emb"], dpk["out_tok"], coords.shape[0], 2, float(S))
+        masks, iou, _ = sam.mask_decoder.predict_masks_tokens(feat_tok, pe["pe_tok"], tokens, pe["no_mask"])
+        seg = ops.mask_union(masks, 0, S, original_size, 3, 0.5)                           # sigmoid -> bilinear -> > 0.5
+        self.last_stats.update(low_res=masks, iou=iou)
+        return seg.to(torch.uint8), [iou[:, 0:1].cpu().numpy()]

@@ -175,3 +175,33 @@ def test_forward_batch_equals_per_slice(dev):
         assert pb.shape == p1.shape
         assert (pb != p1).sum().item() <= 8, (b, (pb != p1).sum().item())
         assert len(sb) == len(s1) and np.allclose(np.array(sb, dtype=np.float64), np.array(s1, dtype=np.float64), atol=2e-3)
+
+
+def test_protomedsam_forward_vs_oracle(dev):
+    from oracle import alp as oalp, dinov2 as odino, glue
+    from protosam_amd.grid_proto_fewshot import FewShotSeg
+    from protosam_amd.protomedsam import ProtoMedSAM
+    from protosam_amd.protosam import ALPNetWrapper, InputFactory, TYPE_ALPNET
+    from protosam_amd.synth import synth_pair, synth_state_dict
+    cfg = dict(CFG)
+    cfg["encoder_depth"] = 4
+    alp = FewShotSeg(512, None, cfg)
+    alp_sd = synth_state_dict(alp, 1234)
+    alp.load_state_dict(alp_sd)
+    alp = alp.to(dev).eval()
+    model = ProtoMedSAM((1024, 1024), ALPNetWrapper(alp), "random:vit_b:1234:2", use_cca=True).to(dev).eval()
+    sam_sd = {k: v.cpu() for k, v in synth_state_dict(model.medsam, 1234).items()}
+    s_img, s_m, q_img, _ = synth_pair(512, seed=0)
+    inp = InputFactory.create_input(TYPE_ALPNET, q_img, support_images=[s_img], support_labels=[s_m], isval=True,
+                                    val_wsize=2)
+    inp.to(dev)
+    seg, conf = model(q_img.to(dev), inp)
+    assert seg.shape == (512, 512) and seg.dtype == torch.uint8
+    enc_sd = {k[len("encoder."):]: v for k, v in alp_sd.items() if k.startswith("encoder.")}
+    enc = lambda im: odino.forward_features(im, enc_sd, "dinov2_b14", depth=4)["x_norm_patchtokens"]  # noqa: E731
+    logits_ref = oalp.fewshot_forward(enc, s_img, s_m, q_img, 512)
+    seg_ref, conf_ref = glue.protomedsam_forward(q_img, logits_ref, sam_sd, "vit_b", use_cca=True, encoder_depth=2)
+    d = _dice(seg.cpu(), seg_ref)
+    print(f"ProtoMedSAM: Dice {d:.5f}, flipped {(seg.cpu() != seg_ref).sum().item()}, "
+          f"conf {float(conf[0].ravel()[0]):.4f} vs {float(conf_ref[0].ravel()[0]):.4f}")
+    assert d > 0.995 and abs(float(conf[0].ravel()[0]) - float(conf_ref[0].ravel()[0])) < 5e-3
