@@ -41,7 +41,7 @@ struct AttnArgs {
 #define KT 64  // keys per tile
 
 template <int HD, int MODE, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
+__global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
   constexpr int NT = NW * 64;
   constexpr int QB = NW * 32;
   constexpr int HDP = (HD + 31) / 32 * 32;
@@ -53,10 +53,13 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
   constexpr int NKL = (KT * CH + NT - 1) / NT;        // K chunk loads per thread
   constexpr int NVL = ((KT / 2) * CH + NT - 1) / NT;  // V chunk-pair loads per thread
   const float LOG2E = 1.4426950408889634f;
+  const float RESCALE_THR = 8.0f;  // log2 units
 
   __shared__ __attribute__((aligned(16))) half_t Ks[KT * KLD];
   __shared__ __attribute__((aligned(16))) half_t Vt[HD * VLD];
   __shared__ unsigned short klut[MODE == 2 ? 256 : 1];  // window key index -> kh | (kw << 8)
+  constexpr int RWLD = 68;                               // padded row (floats) of the rel_w stage
+  __shared__ __attribute__((aligned(16))) float relw_s[MODE == 1 ? QB * RWLD : 4];  // rel_w[q][kw] * log2(e)
 
   const int t = threadIdx.x;
   const int lane = t & 63, wv = t >> 6;
@@ -114,19 +117,19 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
   }
 
   // ---- rel-pos bias state ------------------------------------------------------------------
-  float rwreg[2][4][4];  // MODE 1: rel_w[q][kw] for this lane's 32 key columns
+  // MODE 1: rel_w[q][0..63] * log2(e) is identical for every key tile (a 64-key tile is one key row): staged once in LDS
   const float* relh_q[2] = {nullptr, nullptr};
   if (MODE == 1) {
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      size_t base = (((size_t)b * H + h) * N + qtok[qt]) * (size_t)p.gw;
-      relh_q[qt] = p.rel_h + base;
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
-        int kk = (tt >> 1) * 32 + g * 8 + (tt & 1) * 4;
-        float4 v = *reinterpret_cast<const float4*>(p.rel_w + base + kk);
-        rwreg[qt][tt][0] = v.x; rwreg[qt][tt][1] = v.y; rwreg[qt][tt][2] = v.z; rwreg[qt][tt][3] = v.w;
-      }
+    for (int qt = 0; qt < 2; ++qt)
+      relh_q[qt] = p.rel_h + (((size_t)b * H + h) * N + qtok[qt]) * (size_t)p.gw;
+    for (int idx = t; idx < QB * 16; idx += NT) {
+      const int qr = idx >> 4, c4 = idx & 15;
+      int q = blockIdx.x * QB + qr;
+      q = q < N ? q : N - 1;
+      float4 v = *reinterpret_cast<const float4*>(p.rel_w + (((size_t)b * H + h) * N + q) * (size_t)p.gw + c4 * 4);
+      v.x *= LOG2E; v.y *= LOG2E; v.z *= LOG2E; v.w *= LOG2E;
+      *reinterpret_cast<float4*>(&relw_s[qr * RWLD + c4 * 4]) = v;
     }
   }
   // MODE 2: the decomposed rel-pos bias is folded into the S^T MFMA as 32 extra k-slots:
@@ -232,6 +235,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
     for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) ot[d][qt][r] = 0.f;
+  const float sl2 = p.scale * LOG2E;
   float mrun[2] = {-INFINITY, -INFINITY};
   float lrun[2] = {0.f, 0.f};
 
@@ -279,46 +283,62 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs p) {
       }
     }
 
-    // scale + bias + mask, online softmax
+    // scale + bias + mask, online softmax (base-2 domain: scale and bias are pre-multiplied by log2(e))
     half8_t pf[2][2];
+    const bool last_partial = (tile == ntiles - 1) && (nkeys % KT != 0);  // wave-uniform
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-      float bh = 0.f;
-      if (MODE == 1) bh = relh_q[qt][tile];
+      // bias that is constant over this lane's keys of the tile is added to the row max instead of to every element
+      float bh2 = 0.f;
+      if (MODE == 1) bh2 = relh_q[qt][tile] * LOG2E;
       float mx = -INFINITY;
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
+        float4 rw4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (MODE == 1)
+          rw4 = *reinterpret_cast<const float4*>(
+              &relw_s[(wv * 32 + qt * 16 + li) * RWLD + (tt >> 1) * 32 + g * 8 + (tt & 1) * 4]);
+        const float rwv[4] = {rw4.x, rw4.y, rw4.z, rw4.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int kk = (tt >> 1) * 32 + g * 8 + (tt & 1) * 4 + r;
-          const int kidx = tile * KT + kk;
-          float sv = st[tt][qt][r] * p.scale;
-          if (MODE == 1) sv += bh + rwreg[qt][tt][r];
-          if (kidx >= nkeys) sv = -INFINITY;
+          float sv = MODE == 1 ? fmaf(st[tt][qt][r], sl2, rwv[r]) : st[tt][qt][r] * sl2;
+          if (last_partial) {
+            const int kidx = tile * KT + (tt >> 1) * 32 + g * 8 + (tt & 1) * 4 + r;
+            if (kidx >= nkeys) sv = -INFINITY;
+          }
           st[tt][qt][r] = sv;
           mx = fmaxf(mx, sv);
         }
       }
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mnew = fmaxf(mrun[qt], mx);
-      const float alpha = exp2f((mrun[qt] - mnew) * LOG2E);
-      mrun[qt] = mnew;
+      mx += bh2;
+      // lazy rescale: keep the running max while the tile max exceeds it by < 2^RESCALE_THR (P stays <= 2^THR, fine in
+      // fp16/fp32); the branch is wave-uniform and alpha == 1 for lanes whose max did not grow.
+      float mref = mrun[qt];
+      if (!__all(mx <= mrun[qt] + RESCALE_THR)) {
+        const float mnew = fmaxf(mrun[qt], mx);
+        const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
+        mrun[qt] = mnew;
+        mref = mnew;
+        lrun[qt] *= alpha;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ot[d][qt][r] *= alpha;
+      }
+      const float moff = mref - bh2;  // exp2(sv + bh2 - mref)
       float ps = 0.f;
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float pv = exp2f((st[tt][qt][r] - mnew) * LOG2E);
+          const float pv = __builtin_amdgcn_exp2f(st[tt][qt][r] - moff);
           ps += pv;
           pf[qt][tt >> 1][(tt & 1) * 4 + r] = (half_t)pv;
         }
       }
-      lrun[qt] = lrun[qt] * alpha + ps;
-#pragma unroll
-      for (int d = 0; d < DT; ++d)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ot[d][qt][r] *= alpha;
+      lrun[qt] += ps;
     }
 
     // O^T += V^T P^T

@@ -5,8 +5,9 @@
 // sum(p_fg * [label == j]) / (sum(pred) + 1e-6)), `get_bbox_per_cc` (ProtoSAM.py:242-264: XYXY min/max per label) and
 // `get_most_conf_points` with k = 1 (ProtoSAM.py:266-289: arg-max of p_fg inside the component).
 //
-// Algorithm: lock-free union-find over pixels (link larger root -> smaller with atomicMin, so a component's root is its
-// first pixel in raster order), flatten, collect the roots, rank them (labels are numbered by raster order of the first
+// Algorithm: every pixel first points at the start of its horizontal run (ballot, no atomics); lock-free union-find
+// (link larger root -> smaller with atomicMin, so a component's root is its first pixel in raster order) is then only
+// needed at run boundaries; flatten, collect the roots, rank them (labels are numbered by raster order of the first
 // pixel; cv2's numbering is an implementation detail and every downstream use is order-invariant, ProtoSAM.py:669),
 // then one pass that accumulates the statistics with wave-level pre-aggregation (a 64-pixel row segment almost always
 // holds a single label) before the atomics. Integer work throughout, except the confidence sum (fp64 atomics).
@@ -45,26 +46,51 @@ __device__ __forceinline__ void uf_union(int* parent, int a, int b) {
   }
 }
 
-__global__ void ccl_init_kernel(const uint8_t* __restrict__ pred, int n, int* __restrict__ parent, int* counters) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) {
+// init: every foreground pixel points at the start of its horizontal run inside its 64-pixel wave segment (found with
+// one ballot, no atomics), so horizontal connectivity inside a segment costs nothing and find() paths stay short.
+__global__ __launch_bounds__(256) void ccl_init_kernel(const uint8_t* __restrict__ pred, int H, int W,
+                                                       int* __restrict__ parent, int* counters) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x == 0 && y == 0) {
     counters[0] = 0;
     counters[1] = 0;
   }
-  if (i < n) parent[i] = pred[i] ? i : -1;
+  const int lane = threadIdx.x & 63;
+  const bool fg = x < W && pred[(size_t)y * W + x] != 0;
+  const unsigned long long mask = __ballot(fg);
+  if (x >= W) return;
+  int par = -1;
+  if (fg) {
+    const unsigned long long below = lane ? (~mask & ((1ull << lane) - 1ull)) : 0ull;  // background lanes left of me
+    const int start = below ? 64 - __clzll((long long)below) : 0;
+    par = y * W + (x - lane) + start;
+  }
+  parent[(size_t)y * W + x] = par;
 }
 
-__global__ void ccl_merge_kernel(const uint8_t* __restrict__ pred, int H, int W, int* __restrict__ parent) {
+// merge: unions only where connectivity is not already implied by a horizontal run (Playne/Hawick-style reduction):
+//   W  : only for the first lane of a segment (runs crossing a 64-pixel boundary)
+//   N  : unless W and NW are both foreground (then W already linked to NW, which is in N's run)
+//   NW : only if N and W are background
+//   NE : only if N is background
+__global__ __launch_bounds__(256) void ccl_merge_kernel(const uint8_t* __restrict__ pred, int H, int W,
+                                                        int* __restrict__ parent) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
   if (x >= W) return;
   const int p = y * W + x;
   if (!pred[p]) return;
-  if (x + 1 < W && pred[p + 1]) uf_union(parent, p, p + 1);
-  if (y + 1 < H) {
-    const int q = p + W;
-    if (x > 0 && pred[q - 1]) uf_union(parent, p, q - 1);
-    if (pred[q]) uf_union(parent, p, q);
-    if (x + 1 < W && pred[q + 1]) uf_union(parent, p, q + 1);
+  const bool w = x > 0 && pred[p - 1];
+  if (w && (threadIdx.x & 63) == 0) uf_union(parent, p, p - 1);
+  if (y == 0) return;
+  const int q = p - W;
+  const bool n = pred[q] != 0;
+  const bool nw = x > 0 && pred[q - 1];
+  const bool ne = x + 1 < W && pred[q + 1];
+  if (n) {
+    if (!(w && nw)) uf_union(parent, p, q);
+  } else {
+    if (nw && !w) uf_union(parent, p, q - 1);
+    if (ne) uf_union(parent, p, q + 1);
   }
 }
 
@@ -238,7 +264,7 @@ extern "C" int psam_ccl(const void* pred, const float* pfg, int H, int W, int ca
   const int n = H * W;
   const uint8_t* pr = (const uint8_t*)pred;
   (void)hipMemsetAsync(labels, 0, (size_t)n * sizeof(int), s);
-  hipLaunchKernelGGL(ccl_init_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pr, n, parent, counters);
+  hipLaunchKernelGGL(ccl_init_kernel, dim3((W + 255) / 256, H), dim3(256), 0, s, pr, H, W, parent, counters);
   hipLaunchKernelGGL(ccl_merge_kernel, dim3((W + 255) / 256, H), dim3(256), 0, s, pr, H, W, parent);
   hipLaunchKernelGGL(ccl_flatten_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, parent, roots, cap, counters);
   hipLaunchKernelGGL(ccl_compress_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, parent);
