@@ -30,7 +30,8 @@ int psam_gemm_f16(const void* A, const void* W, const float* bias, void* out, co
                   int out_seg_stride, int out_seg_off, int epilogue, void* stream);
 
 /* Tile override for psam_gemm_f16: 0 auto (default; also env PSAM_GEMM_TILE), 1 = 128x128x64 double-buffered,
- * 2 = 256x128x32 and 3 = 256x256x32 with a 4-deep direct-to-LDS DMA ring. */
+ * 2 = 256x128x32 / 3 = 256x256x32 (two staggered wave groups) and 5 = 256x256x32 (plain) with a 4-deep direct-to-LDS
+ * DMA ring. */
 int psam_gemm_set_tile(int tile);
 
 /* Row LayerNorm, fp32 in; out_dtype 0: half out (+ optional fp32 copy y2), 1: fp32 out. Appends `zero_tail_rows`

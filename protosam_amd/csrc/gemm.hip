@@ -268,7 +268,7 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int EPI, int BN_>
+template <int EPI, int BN_, int STAG>
 __global__ __launch_bounds__(512) void gemm256_f16_kernel(GemmArgs p) {
   using C = G256<BN_>;
   extern __shared__ __attribute__((aligned(16))) half_t ring[];  // the ONLY LDS object of this kernel
@@ -320,6 +320,41 @@ __global__ __launch_bounds__(512) void gemm256_f16_kernel(GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  const int nk = p.K / C::BK_;
+  if (STAG == 0) {
+    // plain ring: one barrier per k-step, DMA of k-step t+3 issued right after it, fragments read and consumed in place
+    stage(0);
+    if (nk > 1) stage(1);
+    if (nk > 2) stage(2);
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 2 < nk)
+        wait_vmcnt<2 * C::LPT>();
+      else if (kt + 1 < nk)
+        wait_vmcnt<C::LPT>();
+      else
+        wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + 3 < nk) stage(kt + 3);
+      const half_t* sa = ring + (kt & (C::NST - 1)) * C::ST_EL;
+      const half_t* sw = sa + C::A_EL;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        half8_t fa[4], fb[C::NJ];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          fa[i] = *reinterpret_cast<const half8_t*>(&sa[lds_off32(wm * 128 + i * 32 + lr, s * 2 + lg)]);
+#pragma unroll
+        for (int j = 0; j < C::NJ; ++j)
+          fb[j] = *reinterpret_cast<const half8_t*>(&sw[lds_off32(wn * C::WN + j * 32 + lr, s * 2 + lg)]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < C::NJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);  // D^T
+      }
+    }
+  } else {
   // Two wave groups (waves 0-3 / 4-7: one wave of each per SIMD) run the same phase sequence one barrier apart, so
   // while one group is in its MFMA phase the other issues DMA and reads fragments:
   //   L_s: issue DMA of k-step s+3 (into the slot of k-step s-1), read the 12 fragments of k-step s into registers,
@@ -328,7 +363,6 @@ __global__ __launch_bounds__(512) void gemm256_f16_kernel(GemmArgs p) {
   // Slot reuse is safe: k-step s-1 was last read in L_{s-1} (lagging group: one phase before the leading group's L_s)
   // and those reads were retired by the lgkmcnt(0) before that phase's closing barrier. A k-step is read only after a
   // barrier that every wave passed after waiting for its own pieces of it.
-  const int nk = p.K / C::BK_;
   stage(0);
   if (nk > 1) stage(1);
   if (nk > 2) stage(2);
@@ -382,6 +416,8 @@ __global__ __launch_bounds__(512) void gemm256_f16_kernel(GemmArgs p) {
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();  // balance the stagger
 
+  }
+
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -389,21 +425,22 @@ __global__ __launch_bounds__(512) void gemm256_f16_kernel(GemmArgs p) {
       store_acc32<EPI>(acc[i][j], m0 + wm * 128 + i * 32 + lr, n0 + wn * C::WN + j * 32 + 4 * lg, p);
 }
 
-template <int EPI, int BN_>
+template <int EPI, int BN_, int STAG>
 static void launch256(const GemmArgs& p, hipStream_t s) {
   using C = G256<BN_>;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm256_f16_kernel<EPI, BN_>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              C::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm256_f16_kernel<EPI, BN_, STAG>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     attr = true;
   }
   const int ntm = (p.M + 255) / 256, ntn = p.N / BN_;
-  hipLaunchKernelGGL((gemm256_f16_kernel<EPI, BN_>), dim3(tile_map_grid(ntm, ntn, p.map_mode)), dim3(512),
+  hipLaunchKernelGGL((gemm256_f16_kernel<EPI, BN_, STAG>), dim3(tile_map_grid(ntm, ntn, p.map_mode)), dim3(512),
                      C::LDS_BYTES, s, p);
 }
 
-// tile choice: 0 = auto, 1 = 128x128, 2 = 256x128, 3 = 256x256 (PSAM_GEMM_TILE env var or psam_gemm_set_tile)
+// tile choice: 0 = auto, 1 = 128x128x64 double buffer, 2 = 256x128 / 3 = 256x256 staggered ring, 5 = 256x256 plain ring
+// (PSAM_GEMM_TILE env var or psam_gemm_set_tile)
 static int g_tile_override = -1;
 extern "C" int psam_gemm_set_tile(int t) {
   g_tile_override = t;
@@ -415,9 +452,14 @@ static int pick_tile(int M, int N, int K) {
     g_tile_override = e ? atoi(e) : 0;
   }
   if (g_tile_override > 0) return g_tile_override;
-  // measured on MI355X (tools/gemm_maps.py): the 128x128 double-buffered kernel (2 workgroups per CU) wins on every
-  // K <= 5120 shape of the two ViTs; the 256x256 DMA-ring kernel wins once K and N are both large (8192^3: 1068 vs 908).
-  if (M >= 4096 && N >= 4096 && K >= 4096 && N % 256 == 0) return 3;
+  // measured on MI355X (tools/gemm_ablate.py, within-run A/B): the 256x256 plain DMA-ring kernel (5) beats the 128x128
+  // double-buffered kernel (1) by 5-10 % once there are >= ~2.5 full rounds of 256-tiles and either N or K is large
+  // (qkv / lin1 at >= 4 batched slices, lin2 at 8); everywhere else (single slice, DINOv2's M = 1297*B, N = 1280 with
+  // K = 1280) the 128x128 kernel with two workgroups per CU wins. 3 = staggered two-phase variant of 5 (kept for A/B).
+  if (N % 256 == 0 && M % 256 == 0) {
+    const long t256 = (long)(M / 256) * (N / 256);
+    if (t256 >= 600 && (N >= 2560 || K >= 4096)) return 5;
+  }
   return 1;
 }
 
@@ -452,16 +494,22 @@ extern "C" int psam_gemm_f16(const void* A, const void* W, const float* bias, vo
   dim3 grid(tile_map_grid(ntm, ntn, p.map_mode)), block(256);
   hipStream_t s = (hipStream_t)stream;
   const int tsel = pick_tile(M, N, K);
-  if (tsel == 3 && N % 256 == 0) {
-    if (epilogue == EPI_F16) launch256<EPI_F16, 256>(p, s);
-    else if (epilogue == EPI_GELU_F16) launch256<EPI_GELU_F16, 256>(p, s);
-    else launch256<EPI_F32, 256>(p, s);
+  if ((tsel == 3 || tsel == 5) && N % 256 == 0) {
+    if (tsel == 3) {
+      if (epilogue == EPI_F16) launch256<EPI_F16, 256, 1>(p, s);
+      else if (epilogue == EPI_GELU_F16) launch256<EPI_GELU_F16, 256, 1>(p, s);
+      else launch256<EPI_F32, 256, 1>(p, s);
+    } else {
+      if (epilogue == EPI_F16) launch256<EPI_F16, 256, 0>(p, s);
+      else if (epilogue == EPI_GELU_F16) launch256<EPI_GELU_F16, 256, 0>(p, s);
+      else launch256<EPI_F32, 256, 0>(p, s);
+    }
     return psam_launch_status();
   }
   if (tsel == 2) {
-    if (epilogue == EPI_F16) launch256<EPI_F16, 128>(p, s);
-    else if (epilogue == EPI_GELU_F16) launch256<EPI_GELU_F16, 128>(p, s);
-    else launch256<EPI_F32, 128>(p, s);
+    if (epilogue == EPI_F16) launch256<EPI_F16, 128, 1>(p, s);
+    else if (epilogue == EPI_GELU_F16) launch256<EPI_GELU_F16, 128, 1>(p, s);
+    else launch256<EPI_F32, 128, 1>(p, s);
     return psam_launch_status();
   }
   switch (epilogue) {
