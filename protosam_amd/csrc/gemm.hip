@@ -425,6 +425,119 @@ __global__ __launch_bounds__(512) void gemm256_f16_kernel(GemmArgs p) {
       store_acc32<EPI>(acc[i][j], m0 + wm * 128 + i * 32 + lr, n0 + wn * C::WN + j * 32 + 4 * lg, p);
 }
 
+// =====================================================================================================
+// Wave-specialised variant: 384 x 128 x 32 k-steps, 512 threads = 6 consumer waves (3 x 2, wave tile 128 x 64) + 2 loader
+// waves that issue ALL direct-to-LDS DMA (16 one-KiB pieces each per k-step) and never touch the matrix pipe. A wave
+// stalled at VMEM issue cannot issue its MFMAs (in-order issue); with every wave both loading and computing, DMA time
+// and MFMA time add up (measured: 195 + 164 us ~ 365 us on 32768x3840x1280), with dedicated loaders they overlap.
+// Same 4-deep ring and barrier protocol as the plain ring kernel: loader waits for its pieces of k-step t, everyone
+// meets at the barrier, loader then refills the slot of k-step t-1 with k-step t+3 while the consumers work on t.
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_ws_f16_kernel(GemmArgs p) {
+  constexpr int BMW = 384, BNW = 128, BKW = 32, NST = 4;
+  constexpr int A_EL = BMW * BKW, B_EL = BNW * BKW, ST_EL = A_EL + B_EL;  // 16384 halfs = 32 KiB per stage
+  constexpr int NPIECE = (BMW + BNW) / 16;                              // 32 one-KiB pieces per stage
+  constexpr int LP = NPIECE / 2;                                        // per loader wave
+  extern __shared__ __attribute__((aligned(16))) half_t ring[];
+
+  const int ntn = p.N / BNW;
+  const int ntm = (p.M + BMW - 1) / BMW;
+  int tm, tn;
+  if (!tile_map(blockIdx.x, ntm, ntn, p.map_mode, tm, tn)) return;
+  const int m0 = tm * BMW, n0 = tn * BNW;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int nk = p.K / BKW;
+
+  if (wv >= 6) {
+    // ---------------- loader wave ----------------
+    const int ld = wv - 6;
+    const half_t* src[LP];
+#pragma unroll
+    for (int j = 0; j < LP; ++j) {
+      const int piece = ld * LP + j;                 // 0..23: A rows, 24..31: W rows
+      const int row = piece * 16 + (lane >> 2);      // row inside the stacked [A | W] stage image
+      const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+      if (piece < BMW / 16) {
+        int am = m0 + row;
+        am = am < p.M ? am : p.M - 1;
+        src[j] = p.A + (size_t)am * p.lda + chunk * 8;
+      } else {
+        src[j] = p.W + (size_t)(n0 + row - BMW) * p.ldw + chunk * 8;
+      }
+    }
+    auto stage = [&](int kt) {
+      half_t* base = ring + (kt & (NST - 1)) * ST_EL + (ld * LP) * 512;
+#pragma unroll
+      for (int j = 0; j < LP; ++j) glds16(src[j] + kt * BKW, base + j * 512);
+    };
+    stage(0);
+    if (nk > 1) stage(1);
+    if (nk > 2) stage(2);
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 2 < nk)
+        wait_vmcnt<2 * LP>();
+      else if (kt + 1 < nk)
+        wait_vmcnt<LP>();
+      else
+        wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + 3 < nk) stage(kt + 3);
+    }
+    return;
+  }
+
+  // ---------------- consumer wave ----------------
+  const int wm = wv >> 1, wn = wv & 1;
+  const int lr = lane & 31, lg = lane >> 5;
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  for (int kt = 0; kt < nk; ++kt) {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const half_t* sa = ring + (kt & (NST - 1)) * ST_EL;
+    const half_t* sw = sa + A_EL;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      half8_t fa[4], fb[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        fa[i] = *reinterpret_cast<const half8_t*>(&sa[lds_off32(wm * 128 + i * 32 + lr, s * 2 + lg)]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        fb[j] = *reinterpret_cast<const half8_t*>(&sw[lds_off32(wn * 64 + j * 32 + lr, s * 2 + lg)]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);  // D^T
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      store_acc32<EPI>(acc[i][j], m0 + wm * 128 + i * 32 + lr, n0 + wn * 64 + j * 32 + 4 * lg, p);
+}
+
+template <int EPI>
+static void launch_ws(const GemmArgs& p, hipStream_t s) {
+  constexpr int LDS = 4 * (384 + 128) * 32 * 2;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm_ws_f16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr = true;
+  }
+  const int ntm = (p.M + 383) / 384, ntn = p.N / 128;
+  hipLaunchKernelGGL((gemm_ws_f16_kernel<EPI>), dim3(tile_map_grid(ntm, ntn, p.map_mode)), dim3(512), LDS, s, p);
+}
+
 template <int EPI, int BN_, int STAG>
 static void launch256(const GemmArgs& p, hipStream_t s) {
   using C = G256<BN_>;
@@ -504,6 +617,12 @@ extern "C" int psam_gemm_f16(const void* A, const void* W, const float* bias, vo
       else if (epilogue == EPI_GELU_F16) launch256<EPI_GELU_F16, 256, 0>(p, s);
       else launch256<EPI_F32, 256, 0>(p, s);
     }
+    return psam_launch_status();
+  }
+  if (tsel == 6) {
+    if (epilogue == EPI_F16) launch_ws<EPI_F16>(p, s);
+    else if (epilogue == EPI_GELU_F16) launch_ws<EPI_GELU_F16>(p, s);
+    else launch_ws<EPI_F32>(p, s);
     return psam_launch_status();
   }
   if (tsel == 2) {
