@@ -77,9 +77,15 @@ def main():
     B = args.batch
     out = torch.zeros((B, 512, 512), dtype=torch.uint8, device=dev)
 
+    from protosam_amd.runner import part_assign
+    parts = [[z for z in range(args.slices) if part_assign(z, args.slices) == pt] for pt in range(3)]
+
     def step(s):
-        # rank r takes slices z = r (mod W) of the step's window (interleaved sharding)
-        zs = [((s * B + j) * world + rank) % args.slices for j in range(B)]
+        # a step = one window of W*B consecutive slices of one z-part (the caller walks a scan part by part,
+        # validation_protosam.py:352-362); rank r takes the slices z = r (mod W) of the window
+        pz = parts[s % 3]
+        base = (s // 3) * B * world
+        zs = [pz[(base + j * world + rank) % len(pz)] for j in range(B)]
         zs.sort()
         masks, st = run_slices(model, vol_d, sup_imgs, sup_masks, zs, dev, out=out, batch=args.micro)
         full = gather_masks(masks, world)

@@ -38,9 +38,7 @@ class FewShotSeg(nn.Module):
         self.cache_support = cache_support
         self.get_encoder()
         self.get_cls()
-        self._sup_key = None
-        self._sup_bank = None
-        self._sup_tokens = None
+        self._sup_cache = []
         if self.pretrained_path:
             self.load_state_dict(torch.load(self.pretrained_path), strict=True)
             print(f"###### Pre-trained model f{self.pretrained_path} has been loaded ######")
@@ -84,17 +82,21 @@ class FewShotSeg(nn.Module):
         return t[:, 1 + R:].reshape(B, g, g, C).permute(0, 3, 1, 2)
 
     def _support_bank(self, supp, fg, bg, pool_w):
-        """Support features + prototype bank, cached while the support is unchanged. The cache holds references to
-        the tensors it was built from (so their storage cannot be recycled under the same address); a different
-        tensor object with identical content (the reference caller re-uploads the support every slice,
-        validation_protosam.py:374-385) is recognised by an on-device equality test instead of a re-encode."""
-        if self.cache_support and self._sup_key is not None:
-            k_supp, k_fg, k_bg, k_pool, k_ver = self._sup_key
-            if k_pool == pool_w and k_supp.shape == supp.shape and k_fg.shape == fg.shape:
-                same_obj = (k_supp is supp and k_fg is fg and k_bg is bg and k_ver == (supp._version, fg._version))
-                if same_obj or (torch.equal(k_supp, supp) and torch.equal(k_fg, fg)
+        """Support features + prototype bank, cached while the support is unchanged (a small LRU: one entry per z-part
+        of a scan, validation_protosam.py:355-362). Entries hold references to the tensors they were built from (so
+        their storage cannot be recycled under the same address); a different tensor object with identical content
+        (the reference caller re-uploads the support every slice, validation_protosam.py:374-385) is recognised by an
+        on-device equality test instead of a re-encode."""
+        if self.cache_support:
+            for i, (k_supp, k_fg, k_bg, k_pool, k_ver, bank, tok) in enumerate(self._sup_cache):
+                if k_pool != pool_w or k_supp.shape != supp.shape or k_fg.shape != fg.shape:
+                    continue
+                same_obj = (k_supp is supp and k_fg is fg and k_ver == (supp._version, fg._version))
+                if same_obj or (k_supp is not supp and torch.equal(k_supp, supp) and torch.equal(k_fg, fg)
                                 and (k_bg is bg or (k_bg is not None and bg is not None and torch.equal(k_bg, bg)))):
-                    return self._sup_bank, self._sup_tokens
+                    if i:
+                        self._sup_cache.insert(0, self._sup_cache.pop(i))
+                    return bank, tok
         S, g = self._grid()
         C = self.encoder.embed_dim
         R = self.encoder.num_register_tokens
@@ -105,8 +107,9 @@ class FewShotSeg(nn.Module):
         if bg is not None and not bool(torch.equal(bg.float(), 1 - fg.float())):   # ProtoSAM.py:63 builds 1 - fg
             bg2 = bg.reshape(bg.shape[-2], bg.shape[-1]).float().contiguous()
         bank = self.cls_unit.build_bank(tok, C, g, g, fg2, pool_w, FG_THRESH, force_mode=-1, bank=None, bg_mask=bg2)
-        self._sup_key = (supp, fg, bg, pool_w, (supp._version, fg._version))
-        self._sup_bank, self._sup_tokens = bank, tok
+        if self.cache_support:
+            self._sup_cache.insert(0, (supp, fg, bg, pool_w, (supp._version, fg._version), bank, tok))
+            del self._sup_cache[4:]
         return bank, tok
 
     def forward(self, supp_imgs, fore_mask, back_mask, qry_imgs, isval, val_wsize, show_viz=False, supp_fts=None):

@@ -126,3 +126,25 @@ def test_fewshot_forward_probability_map(dev, depth):
     # second call hits the support cache and must give the same answer
     out2 = m([[s_img.to(dev)]], [[s_m.to(dev)]], [[(1 - s_m).to(dev)]], [q_img.to(dev)], True, 2)
     assert torch.equal(out2[0].cpu(), logits)
+
+
+@pytest.mark.parametrize("which", ["dinov2_l14", "dinov2_l14_reg"])
+def test_dinov2_large_variants(dev, which):
+    """ViT-L/14 and ViT-L/14 + 4 register tokens (the encoders run_protosam.sh defaults to), 2 blocks, 448x448."""
+    from oracle import dinov2 as odino
+    from protosam_amd.grid_proto_fewshot import FewShotSeg
+    from protosam_amd.synth import synth_pair, synth_state_dict
+    cfg = dict(CFG)
+    cfg.update(which_model=which, encoder_depth=2)
+    m = FewShotSeg(448, None, cfg)
+    sd = synth_state_dict(m, 99)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).eval()
+    _, _, q, _ = synth_pair(448, seed=4)
+    enc_sd = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+    ref = odino.forward_features(q, enc_sd, which, depth=2)["x_norm_patchtokens"]
+    out = m.encoder.forward_features(q.to(dev))["x_norm_patchtokens"].cpu()
+    assert out.shape == ref.shape == (1, 32 * 32, 1024)
+    err = (out - ref).abs()
+    print(f"{which}: max abs err {err.max():.3e} mean {err.mean():.3e}")
+    assert err.max() < 3e-2 and err.mean() < 2e-3
