@@ -132,6 +132,78 @@ __device__ __forceinline__ void store_acc32(const f32x16& acc, int m, int nb, co
   }
 }
 
+// LDS-staged epilogue for a 64-row x 64-column slab held by one wave as 2 x 2 transposed 32x32 accumulators: the wave
+// parks the slab in its own 16 KiB of (now idle) stage memory, then re-reads it so that 16 lanes cover one full 64-column
+// row: every global access instruction then touches 4 rows x 256 contiguous bytes (fp32) / 128 bytes (fp16) instead of
+// 32 rows x 32 bytes. Measured before: the fp32 residual epilogue ran at ~1.5 TB/s (proj GEMM 230 us for 107 GFLOP).
+// 16-byte chunks are XOR-swizzled by (row & 15) so the ds_write_b128 of 8 consecutive rows hit distinct banks.
+// residual rows of a 64x64 slab in the staged epilogue's lane mapping, fetched EARLY (before the k-loop) so the HBM
+// latency of `x += ...` hides under the MFMAs; in-place updates are safe because the thread that reads resid[m][n] is
+// the thread that later writes out[m][n].
+__device__ __forceinline__ void prefetch_resid(const GemmArgs& p, int mbase, int nbase, int lane, float4 (&r)[16]) {
+  const int n = nbase + (lane & 15) * 4;
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    int m = mbase + it * 4 + (lane >> 4);
+    m = m < p.M ? m : p.M - 1;
+    const size_t rrow = p.resid_mod ? (size_t)(m % p.resid_mod) : (size_t)m;
+    r[it] = *reinterpret_cast<const float4*>(p.resid + rrow * p.ldr + n);
+  }
+}
+
+template <int EPI, bool PRE = false>
+__device__ __forceinline__ void store_slab_staged(const f32x16 (&a00), const f32x16 (&a01), const f32x16 (&a10),
+                                                  const f32x16 (&a11), float* __restrict__ slab, int mbase, int nbase,
+                                                  int lane, const GemmArgs& p, const float4* pre = nullptr) {
+  const int lr = lane & 31, lg = lane >> 5;
+  const f32x16* accs[2][2] = {{&a00, &a01}, {&a10, &a11}};
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = i * 32 + lr;
+        const int chunk = (j * 32 + 8 * q + 4 * lg) >> 2;
+        const f32x16& a = *accs[i][j];
+        *reinterpret_cast<float4*>(&slab[row * 64 + ((chunk ^ (row & 15)) << 2)]) =
+            make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+      }
+  // same-wave LDS traffic is ordered; the compiler inserts the lgkmcnt wait for the reads below
+  const int c4 = lane & 15;
+  const int n = nbase + c4 * 4;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), gv = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + n);
+  if (EPI == EPI_F32 && p.gamma) gv = *reinterpret_cast<const float4*>(p.gamma + n);
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int row = it * 4 + (lane >> 4);
+    const int m = mbase + row;
+    float4 v = *reinterpret_cast<const float4*>(&slab[row * 64 + ((c4 ^ (row & 15)) << 2)]);
+    if (m >= p.M) continue;
+    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+    const size_t orow = p.out_seg ? (size_t)(m / p.out_seg) * p.out_seg_stride + p.out_seg_off + (m % p.out_seg) : (size_t)m;
+    if (EPI == EPI_F16) {
+      half4_t h = {(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
+      *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(p.out) + orow * p.ldo + n) = h;
+    } else if (EPI == EPI_GELU_F16) {
+      half4_t h = {(half_t)gelu_erf(v.x), (half_t)gelu_erf(v.y), (half_t)gelu_erf(v.z), (half_t)gelu_erf(v.w)};
+      *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(p.out) + orow * p.ldo + n) = h;
+    } else {
+      v.x *= gv.x; v.y *= gv.y; v.z *= gv.z; v.w *= gv.w;
+      if (PRE) {
+        const float4 r = pre[it];
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+      } else if (p.resid) {
+        const size_t rrow = p.resid_mod ? (size_t)(m % p.resid_mod) : (size_t)m;
+        const float4 r = *reinterpret_cast<const float4*>(p.resid + rrow * p.ldr + n);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+      }
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + orow * p.ldo + n) = v;
+    }
+  }
+}
+
 #define BM 128
 #define BN 128
 #define BK 64
@@ -198,6 +270,10 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs p) {
 
   const int nk = p.K / BK;
   stage(0, 0);
+  // residual prefetch (EPI_F32): 16 float4 per lane, landed long before the epilogue
+  float4 rpre[16];
+  const bool has_res = (EPI == EPI_F32) && p.resid != nullptr;
+  if (EPI == EPI_F32 && has_res) prefetch_resid(p, m0 + wm * 64, n0 + wn * 64, lane, rpre);
   __syncthreads();  // carries the vmcnt(0) for the pending LDS-DMA
 
   for (int kt = 0; kt < nk; ++kt) {
@@ -227,12 +303,14 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs p) {
     __syncthreads();  // all waves done reading buf[cur]; DMA into buf[cur^1] has landed (vmcnt(0))
   }
 
-  // epilogue (transposed accumulators, see store_acc32)
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      store_acc32<EPI>(acc[i][j], m0 + wm * 64 + i * 32 + lr, n0 + wn * 64 + j * 32 + 4 * lg, p);
+  // epilogue: each wave stages its 64x64 slab through its own quarter of the (idle) 64 KiB stage memory; the loop's
+  // closing __syncthreads() guarantees nobody still reads the k-tile buffers
+  float* slab = reinterpret_cast<float*>(&smem[0][0][0]) + wv * 4096;
+  if (EPI == EPI_F32 && has_res)
+    store_slab_staged<EPI, true>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], slab, m0 + wm * 64, n0 + wn * 64, lane, p,
+                                 rpre);
+  else
+    store_slab_staged<EPI, false>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], slab, m0 + wm * 64, n0 + wn * 64, lane, p);
 }
 
 // =====================================================================================================
@@ -320,6 +398,11 @@ __global__ __launch_bounds__(512) void gemm256_f16_kernel(GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // residual rows of the first epilogue pass, fetched before any DMA is queued (they are the OLDEST entries of the
+  // in-order vmcnt queue, so the counted waits below are unchanged)
+  float4 rpre[16];
+  const bool has_res = (EPI == EPI_F32) && (C::NJ == 2) && p.resid != nullptr;
+  if (EPI == EPI_F32 && C::NJ == 2 && has_res) prefetch_resid(p, m0 + wm * 128, n0 + wn * 64, lane, rpre);
   const int nk = p.K / C::BK_;
   if (STAG == 0) {
     // plain ring: one barrier per k-step, DMA of k-step t+3 issued right after it, fragments read and consumed in place
