@@ -37,9 +37,21 @@ __device__ __forceinline__ float wave_min(float v) {
   return v;
 }
 
-// exact (erf) GELU, as torch.nn.GELU() default
+// erf-form GELU (torch.nn.GELU() default). erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the fp16
+// rounding of every consumer) on the hardware exp2 / rcp: ~14 VALU ops instead of libm erff's ~40 with branches.
+__device__ __forceinline__ float fast_erf(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f);
+  const float y = fmaf(-poly * t, e, 1.0f);
+  return copysignf(y, x);
+}
 __device__ __forceinline__ float gelu_erf(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f));
 }
 
 // XCD-aware bijective block remap (8 XCDs; block b runs on XCD b % 8): gives each XCD a
