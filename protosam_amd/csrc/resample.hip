@@ -298,3 +298,29 @@ extern "C" int psam_normalize_chw(const void* x, int in_u8, int B, long long pla
                      in_u8, (size_t)plane, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], y, total);
   return psam_launch_status();
 }
+
+// Token-major bilinear resize of a feature map: in fp32 [B][ih*iw, C] (batch stride in_bstride, row stride ld) ->
+// out fp32 [B][oh*ow, C] contiguous. F.interpolate(img_fts, size=(32,32), mode='bilinear') of
+// models/grid_proto_fewshot.py:96-98 (taken when the encoder yields fewer than 32x32 patches) without the NCHW detour.
+__global__ void bilinear_tokens_kernel(const float* __restrict__ in, size_t in_bstride, int ld, int ih, int iw, int C,
+                                       int oh, int ow, float* __restrict__ out) {
+  const int opix = blockIdx.x, b = blockIdx.y;
+  const int oy = opix / ow, ox = opix % ow;
+  const float sh = (float)ih / (float)oh, sw = (float)iw / (float)ow;
+  const Lin ly = lin_src(oy, sh, ih), lx = lin_src(ox, sw, iw);
+  const float* base = in + (size_t)b * in_bstride;
+  const float* p00 = base + (size_t)(ly.i0 * iw + lx.i0) * ld;
+  const float* p01 = base + (size_t)(ly.i0 * iw + lx.i1) * ld;
+  const float* p10 = base + (size_t)(ly.i1 * iw + lx.i0) * ld;
+  const float* p11 = base + (size_t)(ly.i1 * iw + lx.i1) * ld;
+  float* o = out + ((size_t)b * oh * ow + opix) * C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x)
+    o[c] = ly.l0 * (lx.l0 * p00[c] + lx.l1 * p01[c]) + ly.l1 * (lx.l0 * p10[c] + lx.l1 * p11[c]);
+}
+extern "C" int psam_bilinear_tokens(const float* in, long long in_bstride, int ld, int B, int ih, int iw, int C, int oh,
+                                    int ow, float* out, void* stream) {
+  if (B <= 0 || ih <= 0 || iw <= 0 || oh <= 0 || ow <= 0 || C <= 0) return PSAM_ERR_ARG;
+  hipLaunchKernelGGL(bilinear_tokens_kernel, dim3(oh * ow, B), dim3(256), 0, (hipStream_t)stream, in, (size_t)in_bstride,
+                     ld, ih, iw, C, oh, ow, out);
+  return psam_launch_status();
+}

@@ -67,19 +67,31 @@ class FewShotSeg(nn.Module):
 
     # ---- features ------------------------------------------------------------------------------------------------
     def _grid(self):
+        """(S, g): encoder input side and the side of the feature map the classifier sees (>= 32, :96-98)."""
         S = self.image_size // 14 * 14
-        g = S // 14
-        if g * g < DEFAULT_FEATURE_SIZE ** 2:
-            raise NotImplementedError("image_size < 448 needs the 32x32 feature upsample (grid_proto_fewshot.py:96-98)")
-        return S, g
+        return S, max(S // 14, DEFAULT_FEATURE_SIZE)
+
+    def _patch_tokens(self, imgs):
+        """imgs [B,3,H,W] -> token-major patch features fp32 [B, g*g, C] (view of a workspace, or the 32x32 bilinear
+        upsample of it when the encoder yields fewer patches) plus (batch stride, row stride) in elements."""
+        S, g = self._grid()
+        ge = S // 14
+        C = self.encoder.embed_dim
+        R = self.encoder.num_register_tokens
+        t = self.encoder.forward_tokens(imgs.float(), S)           # [B, 1+R+ge*ge, C]
+        B, N, _ = t.shape
+        tok = t[:, 1 + R:]
+        if ge == g:
+            return tok, N * C, C
+        up = ops.bilinear_tokens(tok, N * C, C, B, ge, ge, C, g, g)
+        return up, g * g * C, C
 
     def get_features(self, imgs_concat):
         """-> [B, C, h, w] as the reference (a permuted view of the token-major buffer)."""
         S, g = self._grid()
-        t = self.encoder.forward_tokens(imgs_concat.float(), S)
-        R = self.encoder.num_register_tokens
-        B, _, C = t.shape
-        return t[:, 1 + R:].reshape(B, g, g, C).permute(0, 3, 1, 2)
+        tok, _, C = self._patch_tokens(imgs_concat)
+        B = tok.shape[0]
+        return tok.reshape(B, g, g, C).permute(0, 3, 1, 2)
 
     def _support_bank(self, supp, fg, bg, pool_w):
         """Support features + prototype bank, cached while the support is unchanged (a small LRU: one entry per z-part
@@ -99,9 +111,8 @@ class FewShotSeg(nn.Module):
                     return bank, tok
         S, g = self._grid()
         C = self.encoder.embed_dim
-        R = self.encoder.num_register_tokens
-        t = self.encoder.forward_tokens(supp.float(), S)          # workspace buffer [1, N, C]
-        tok = t[0, 1 + R:].clone()                                # [g*g, C] kept for the cache / returned tuple
+        t, _, _ = self._patch_tokens(supp)
+        tok = t[0].clone()                                        # [g*g, C] kept for the cache / returned tuple
         fg2 = fg.reshape(fg.shape[-2], fg.shape[-1]).float().contiguous()
         bg2 = None
         if bg is not None and not bool(torch.equal(bg.float(), 1 - fg.float())):   # ProtoSAM.py:63 builds 1 - fg
@@ -124,17 +135,15 @@ class FewShotSeg(nn.Module):
         img_size = supp.shape[-2:]
         S, g = self._grid()
         C = self.encoder.embed_dim
-        R = self.encoder.num_register_tokens
         pool_w = val_wsize if (isval and val_wsize is not None) else self.cls_unit.kernel_size[0]
         bank, sup_tok = self._support_bank(supp, fg, bg, pool_w)
-        qt = self.encoder.forward_tokens(qry.float(), S)          # [B, N, C]
-        B, N, _ = qt.shape
-        qry_tok = qt[:, 1 + R:]
-        pred = self.cls_unit.scores_token_major(qry_tok, N * C, C, B, g * g, bank)   # [B, 2, g*g]
+        qry_tok, q_bstride, q_ld = self._patch_tokens(qry)        # [B, g*g, C] (strided view or upsampled copy)
+        B = qry_tok.shape[0]
+        pred = self.cls_unit.scores_token_major(qry_tok, q_bstride, q_ld, B, g * g, bank)   # [B, 2, g*g]
         self._check_bank(bank)
         output = ops.bilinear_nchw(pred.view(B, 2, g, g), img_size[0], img_size[1])   # :272-273
         supp_view = sup_tok.reshape(1, 1, 1, g, g, C).permute(0, 1, 2, 5, 3, 4)
-        qry_view = qry_tok.reshape(1, B, g, g, C).permute(0, 1, 4, 2, 3)
+        qry_view = qry_tok.unflatten(1, (g, g)).unsqueeze(0).permute(0, 1, 4, 2, 3)   # zero-copy [1,B,C,g,g]
         return output, 0.0, [None, None], None, None, supp_view, qry_view
 
     def _check_bank(self, bank):

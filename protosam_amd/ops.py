@@ -442,3 +442,13 @@ def ccl(pred_u8, pfg, ws, fg_sum=None, slot=0):
                             _ptr(fg_sum), _ptr(ws.tabs[slot]), _stream())
     _lib.check(st, "psam_ccl")
     return ws
+
+
+def bilinear_tokens(tok, in_bstride, ld, B, ih, iw, C, oh, ow, out=None):
+    """fp32 token-major [B][ih*iw, C] (strided) -> contiguous [B, oh*ow, C]."""
+    _req(tok, torch.float32, "tok")
+    if out is None:
+        out = torch.empty((B, oh * ow, C), dtype=torch.float32, device=tok.device)
+    st = _lib.lib().psam_bilinear_tokens(_ptr(tok), in_bstride, ld, B, ih, iw, C, oh, ow, _ptr(out), _stream())
+    _lib.check(st, "psam_bilinear_tokens")
+    return out

@@ -148,3 +148,26 @@ def test_dinov2_large_variants(dev, which):
     err = (out - ref).abs()
     print(f"{which}: max abs err {err.max():.3e} mean {err.mean():.3e}")
     assert err.max() < 3e-2 and err.mean() < 2e-3
+
+
+def test_fewshot_forward_small_image_upsamples_features(dev):
+    """image_size 252 -> 18x18 patches -> bilinear to 32x32 features (grid_proto_fewshot.py:96-98); checked against the
+    reference's recorded output for exactly this case (tests/golden, written from /root/reference)."""
+    import os
+    import numpy as np
+    from oracle import golden_inputs as gi
+    from protosam_amd.grid_proto_fewshot import FewShotSeg
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_outputs.npz"))
+    for size in gi.FEWSHOT_SIZES:
+        cfg = dict(CFG)
+        cfg["encoder_depth"] = gi.FEWSHOT_DEPTH
+        m = FewShotSeg(size, None, cfg)
+        sd = {"encoder." + k: v for k, v in gi.fewshot_encoder_sd().items()}
+        m.load_state_dict(sd, strict=True)
+        m = m.to(dev).eval()
+        s_img, s_m, q_img, _ = gi.fewshot_pair(size)
+        out = m([[s_img.to(dev)]], [[s_m.to(dev)]], [[(1 - s_m).to(dev)]], [q_img.to(dev)], True, 2)[0].cpu()
+        ref = torch.from_numpy(gold[f"fewshot_logits_{size}"])
+        perr = (out.softmax(1) - ref.softmax(1)).abs().max().item()
+        print(f"image_size {size}: max |dprob| vs REFERENCE golden {perr:.3e}")
+        assert out.shape == ref.shape and perr < 1e-3
