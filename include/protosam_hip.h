@@ -137,6 +137,17 @@ int psam_mask_upsample(const float* low, int planes, int IN, int MID, int varian
 int psam_mask_union(const float* low, int B, int C, int sel, int IN, int MID, int OUT, int variant, float thr,
                     float* pred, void* stream);
 
+/* Candidate statistics of SamAutomaticMaskGenerator without the full-resolution masks: for plane p (prompt p / nsel,
+ * channel first + p % nsel of low [B,C,IN,IN]) over y < H, x < W of the MID x MID up-sampling, stats int32 [B*nsel, 8] =
+ * {count(v > thr+off), count(v > thr-off), count(v > thr), min_x, min_y, max_x, max_y, 0} (empty: min = INT_MAX, max = -1).
+ * automatic_mask_generator.py:293-310; utils/amg.py:156-176 (calculate_stability_score), :303-346 (batched_mask_to_box) */
+int psam_mask_stats(const float* low, int B, int C, int first, int nsel, int IN, int MID, int H, int W, int variant,
+                    float thr, float off, int* stats, void* stream);
+/* out uint8 [n,H,W] = upsample(low plane idx[i]) > thr (automatic_mask_generator.py:305, predictor.py:238-239); with
+ * label uint8 [H,W]: counts int64 [n,3] = {tp, fp, fn} against it (models/SamWrapper.py:8-13 get_iou). */
+int psam_mask_binarize(const float* low, const int* idx, int n, int IN, int MID, int H, int W, int variant, float thr,
+                       unsigned char* out, const unsigned char* label, long long* counts, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,3 +53,17 @@ def decoder_cases():
         "pts_only": (torch.tensor([[[300.0, 410.0], [20.0, 30.0]]]), torch.tensor([[1, 0]], dtype=torch.int), None),
         "box_only": (None, None, torch.tensor([[250.0, 300.0, 700.0, 800.0]])),
     }
+
+
+AMG_SEED = 2024
+AMG_ENCODER_DEPTH = 2          # vit_b block stack truncated to [window, window] so the CPU reference runs in seconds
+AMG_ARGS = dict(points_per_side=8, points_per_batch=32, box_nms_thresh=1.0)
+
+
+def amg_case():
+    """uint8 [1024,1024,3] image (what SAMWrapperInput hands to SamWrapper.forward) and a binary label [1024,1024]."""
+    from protosam_amd.synth import synth_pair
+    _, _, q_img, q_gt = synth_pair(1024, seed=5)
+    q = q_img[0].permute(1, 2, 0).numpy()
+    img = ((q - q.min()) / (q.max() - q.min()) * 255).astype("uint8")
+    return img, q_gt[0].numpy().astype("uint8")

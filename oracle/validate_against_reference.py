@@ -40,10 +40,14 @@ def install_shims():
     tv.models = stub("torchvision.models")
     tv.models.segmentation = stub("torchvision.models.segmentation")
     tv.transforms = stub("torchvision.transforms")
-    tv.transforms.functional = stub("torchvision.transforms.functional", resize=None, to_pil_image=None, rotate=None,
+    from PIL import Image  # torchvision's resize(to_pil_image(x), size) IS PIL's bilinear resize
+    tv.transforms.functional = stub("torchvision.transforms.functional",
+                                    resize=lambda im, size: im.resize((size[1], size[0]), Image.BILINEAR),
+                                    to_pil_image=Image.fromarray, rotate=None,
                                     InterpolationMode=types.SimpleNamespace(BILINEAR=2, NEAREST=0))
     tv.ops = stub("torchvision.ops")
-    tv.ops.boxes = stub("torchvision.ops.boxes", batched_nms=None, box_area=None)
+    from oracle import amg as oamg  # torchvision.ops NMS is absent: the restated one is injected (oracle/amg.py header)
+    tv.ops.boxes = stub("torchvision.ops.boxes", batched_nms=oamg.batched_nms, box_area=None)
     stub("cv2")
     stub("kneed")
     sys.path.insert(0, os.path.join(REF, "models"))
@@ -252,6 +256,98 @@ def check_glue(gold):
     close(glue.confidence_from_logits(lg), get_confidence_from_logits(lg), 1e-6, "get_confidence_from_logits")
 
 
+def _amg_reference_model():
+    """Vendored registry's SamBatched vit_b with the encoder's block stack truncated, synthetic weights."""
+    from functools import partial
+    from segment_anything import sam_model_registry
+    from segment_anything.modeling import ImageEncoderViT
+    from oracle import golden_inputs as gi
+    from protosam_amd.synth import synth_state_dict
+    sam = sam_model_registry["vit_b"]()
+    sam.image_encoder = ImageEncoderViT(depth=gi.AMG_ENCODER_DEPTH, embed_dim=768, img_size=1024, mlp_ratio=4,
+                                        norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), num_heads=12, patch_size=16,
+                                        qkv_bias=True, use_rel_pos=True, global_attn_indexes=[2, 5, 8, 11],
+                                        window_size=14, out_chans=256)
+    sd = synth_state_dict(sam, gi.AMG_SEED)
+    sam.load_state_dict(sd)
+    return sam.eval(), sd
+
+
+def amg_thresholds(iou_all, stab_all):
+    """Synthetic weights do not produce calibrated scores, so the generator's two thresholds are placed inside the widest
+    gap of a central quantile band of each score: a good share of the candidates passes each filter and none sits on the
+    boundary (the predicted-IoU one must be > 0 to be applied at all, automatic_mask_generator.py:295)."""
+    def gap_mid(v, qlo, qhi):
+        v = np.sort(np.asarray(v, dtype=np.float64)[np.isfinite(v)])
+        lo, hi = int(qlo * len(v)), int(qhi * len(v))
+        k = lo + int(np.argmax(np.diff(v[lo:hi + 1])))
+        return float((v[k] + v[k + 1]) / 2)
+    t_iou = gap_mid(iou_all, 0.5, 0.7)
+    t_stab = gap_mid(np.asarray(stab_all)[np.asarray(iou_all) > t_iou], 0.3, 0.6)   # the filters apply in sequence
+    assert t_iou > 0 and t_stab > 0
+    return t_iou, t_stab
+
+
+def check_amg(gold):
+    from segment_anything import SamAutomaticMaskGenerator  # vendored
+    from oracle import amg as oamg
+    from oracle import golden_inputs as gi
+    print("SamAutomaticMaskGenerator.generate + SamWrapper.forward (vendored reference; NMS = injected restatement)")
+    sam, sd = _amg_reference_model()
+    img, label = gi.amg_case()
+    taps = {}
+    oamg.generate(img, sd, encoder_depth=gi.AMG_ENCODER_DEPTH, pred_iou_thresh=0.0, stability_score_thresh=0.0,
+                  taps=taps, **gi.AMG_ARGS)
+    t_iou, t_stab = amg_thresholds(taps["iou_all"].numpy(), taps["stab_all"].numpy())
+    print(f"  thresholds: pred_iou {t_iou:.6f}, stability {t_stab:.6f}")
+    kw = dict(pred_iou_thresh=t_iou, stability_score_thresh=t_stab, **gi.AMG_ARGS)
+    with torch.no_grad():
+        ref = SamAutomaticMaskGenerator(sam, **kw).generate(img)
+    ora = oamg.generate(img, sd, encoder_depth=gi.AMG_ENCODER_DEPTH, features=taps["features"], **kw)
+    assert len(ref) == len(ora) and len(ref) > 3, (len(ref), len(ora))
+    print(f"  {len(ref)} masks kept of {len(taps['iou_all'])} candidates")
+    for k in ("predicted_iou", "stability_score"):
+        close([r[k] for r in ora], [r[k] for r in ref], 2e-5, k)
+    for k in ("bbox", "area", "point_coords", "crop_box"):
+        close(np.array([r[k] for r in ora], dtype=np.float64).reshape(len(ref), -1),
+              np.array([r[k] for r in ref], dtype=np.float64).reshape(len(ref), -1), 0, k)
+    diff = max(int((a["segmentation"] != b["segmentation"]).sum()) for a, b in zip(ora, ref))
+    print(f"  [{'ok' if diff <= 4 else 'FAIL'}] segmentation: at most {diff} differing pixels per mask")
+    assert diff <= 4
+    # synthetic weights give noise-like masks whose boxes all span the image, so AMG_ARGS disables suppression
+    # (box_nms_thresh = 1.0) to compare many records; with the default 0.7 exactly the top-scoring one survives
+    kw7 = dict(kw, box_nms_thresh=0.7)
+    with torch.no_grad():
+        ref7 = SamAutomaticMaskGenerator(sam, **kw7).generate(img)
+    ora7 = oamg.generate(img, sd, encoder_depth=gi.AMG_ENCODER_DEPTH, features=taps["features"], **kw7)
+    assert len(ref7) == len(ora7) == 1 and ref7[0]["point_coords"] == ora7[0]["point_coords"] == ref[0]["point_coords"]
+    print("  [ok] box_nms_thresh=0.7: the single survivor is the top-scoring record")
+    # SamWrapper.forward on top of it
+    import models.SamWrapper as ref_sw
+    w = ref_sw.SamWrapper.__new__(ref_sw.SamWrapper)
+    torch.nn.Module.__init__(w)
+    w.sam = sam
+    w.mask_generator = SamAutomaticMaskGenerator(sam, **kw)
+    from segment_anything.utils.transforms import ResizeLongestSide
+    w.transform = ResizeLongestSide(1024)
+    with torch.no_grad():
+        best_ref = w(img, label)
+    best_ora, bi, ious, _ = oamg.sam_wrapper_forward(img, label, sd, encoder_depth=gi.AMG_ENCODER_DEPTH,
+                                                     features=taps["features"], **kw)
+    d = int((best_ref != best_ora).sum())
+    print(f"  [{'ok' if d <= 4 else 'FAIL'}] SamWrapper.forward: best mask #{bi} (IoU {float(ious[bi]):.4f}), {d} differing pixels")
+    assert d <= 4
+    gold["amg_thresholds"] = np.array([t_iou, t_stab], dtype=np.float64)
+    gold["amg_iou_all"] = taps["iou_all"].numpy().astype(np.float32)   # oracle values; the reference exposes kept ones only
+    gold["amg_pred_iou"] = np.array([r["predicted_iou"] for r in ref], dtype=np.float32)
+    gold["amg_stability"] = np.array([r["stability_score"] for r in ref], dtype=np.float32)
+    gold["amg_bbox"] = np.array([r["bbox"] for r in ref], dtype=np.int32)
+    gold["amg_area"] = np.array([r["area"] for r in ref], dtype=np.int32)
+    gold["amg_points"] = np.array([r["point_coords"][0] for r in ref], dtype=np.float64)
+    gold["amg_best_mask_bits"] = np.packbits(best_ref)
+    gold["amg_best_index"] = np.array([bi], dtype=np.int32)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--write-golden", action="store_true")
@@ -268,6 +364,7 @@ def main():
     check_sam_encoder(gold)
     check_sam_decoder(gold)
     check_glue(gold)
+    check_amg(gold)
     if args.write_golden:
         os.makedirs(GOLD, exist_ok=True)
         path = os.path.join(GOLD, "reference_outputs.npz")

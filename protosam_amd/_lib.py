@@ -45,6 +45,10 @@ SIGNATURES = {
     "psam_upscale_tail": [c_void_p] * 7 + [c_int, c_int, c_void_p],
     "psam_mask_upsample": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "psam_mask_union": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p],
+    "psam_mask_stats": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
+                        c_void_p, c_void_p],
+    "psam_mask_binarize": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
+                           c_void_p, c_void_p],
     "psam_normalize_chw": [c_void_p, c_int, c_int, c_longlong, ctypes.POINTER(c_float), ctypes.POINTER(c_float),
                            c_void_p, c_void_p],
     "psam_ccl": [c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 9 + [c_void_p],

@@ -520,3 +520,108 @@ extern "C" int psam_mask_union(const float* low, int B, int C, int sel, int IN, 
                      IN, MID, OUT, variant, thr, pred);
   return psam_launch_status();
 }
+
+// ---- automatic mask generation: statistics and binarisation straight from the low-res logits -------------------------
+// The reference materialises every candidate at full resolution ([64*3, H, W] fp32 per batch) and then reduces it to
+// three counts and a box (automatic_mask_generator.py:293-310; utils/amg.py calculate_stability_score :156-176,
+// batched_mask_to_box :303-346). Here the up-sampled value is recomputed on the fly from the 256x256 logits (256 KB per
+// plane, L2 resident) and only the statistics leave the chip.
+// plane p of the selection -> prompt p / nsel, channel first + p % nsel of low [B, C, IN, IN].
+// stats int32 [planes, 8] = {count(v > thr + off), count(v > thr - off), count(v > thr), min_x, min_y, max_x, max_y, 0}
+// over y < H, x < W of the MID x MID up-sampling (H, W = predictor.input_size: the un-padded part of the model input).
+__global__ void mask_stats_init_kernel(int* __restrict__ stats, int planes) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= planes * 8) return;
+  const int f = i & 7;
+  stats[i] = (f == 3 || f == 4) ? 0x7fffffff : ((f == 5 || f == 6) ? -1 : 0);
+}
+#define MS_ROWS 32
+__global__ __launch_bounds__(256) void mask_stats_kernel(const float* __restrict__ low, int C, int first, int nsel,
+                                                         int IN, int MID, int H, int W, int variant, float thr,
+                                                         float off, int* __restrict__ stats) {
+  const int p = blockIdx.y;
+  const float* src = low + ((size_t)(p / nsel) * C + first + p % nsel) * IN * IN;
+  const int y0 = blockIdx.x * MS_ROWS, y1 = min(y0 + MS_ROWS, H);
+  int hi = 0, lo = 0, ar = 0, mnx = 0x7fffffff, mny = 0x7fffffff, mxx = -1, mxy = -1;
+  for (int x = threadIdx.x; x < W; x += blockDim.x) {
+    for (int y = y0; y < y1; ++y) {
+      const float v = up_sample(src, IN, MID, y, x, variant);
+      hi += v > thr + off;
+      lo += v > thr - off;
+      if (v > thr) {
+        ++ar;
+        mnx = min(mnx, x); mxx = max(mxx, x);
+        mny = min(mny, y); mxy = max(mxy, y);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    hi += __shfl_xor(hi, o, 64); lo += __shfl_xor(lo, o, 64); ar += __shfl_xor(ar, o, 64);
+    mnx = min(mnx, __shfl_xor(mnx, o, 64)); mny = min(mny, __shfl_xor(mny, o, 64));
+    mxx = max(mxx, __shfl_xor(mxx, o, 64)); mxy = max(mxy, __shfl_xor(mxy, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0 && lo) {  // v > thr + off or v > thr implies v > thr - off (off >= 0)
+    int* s = stats + (size_t)p * 8;
+    if (hi) atomicAdd(s + 0, hi);
+    atomicAdd(s + 1, lo);
+    if (ar) {
+      atomicAdd(s + 2, ar);
+      atomicMin(s + 3, mnx); atomicMin(s + 4, mny); atomicMax(s + 5, mxx); atomicMax(s + 6, mxy);
+    }
+  }
+}
+extern "C" int psam_mask_stats(const float* low, int B, int C, int first, int nsel, int IN, int MID, int H, int W,
+                               int variant, float thr, float off, int* stats, void* stream) {
+  if (B <= 0 || first < 0 || nsel <= 0 || first + nsel > C || variant < 0 || variant > 2 || H <= 0 || W <= 0 ||
+      H > MID || W > MID || off < 0.f)
+    return PSAM_ERR_ARG;
+  const int planes = B * nsel;
+  hipLaunchKernelGGL(mask_stats_init_kernel, dim3((planes * 8 + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats,
+                     planes);
+  hipLaunchKernelGGL(mask_stats_kernel, dim3((H + MS_ROWS - 1) / MS_ROWS, planes), dim3(256), 0, (hipStream_t)stream,
+                     low, C, first, nsel, IN, MID, H, W, variant, thr, off, stats);
+  return psam_launch_status();
+}
+
+// out[i] (uint8 {0,1} [n, H, W]) = upsample(low plane idx[i]) > thr for the candidates that survived the filters; with a
+// label (uint8 {0,1} [H, W]) also counts[i] = {tp, fp, fn} against it (models/SamWrapper.py:8-13 get_iou).
+__global__ __launch_bounds__(256) void mask_binarize_kernel(const float* __restrict__ low, const int* __restrict__ idx,
+                                                            int IN, int MID, int H, int W, int variant, float thr,
+                                                            uint8_t* __restrict__ out,
+                                                            const uint8_t* __restrict__ label,
+                                                            unsigned long long* __restrict__ counts) {
+  const int i = blockIdx.y;
+  const float* src = low + (size_t)idx[i] * IN * IN;
+  const int y0 = blockIdx.x * MS_ROWS, y1 = min(y0 + MS_ROWS, H);
+  int tp = 0, fp = 0, fn = 0;
+  for (int y = y0; y < y1; ++y) {
+    for (int x = threadIdx.x; x < W; x += blockDim.x) {
+      const int m = up_sample(src, IN, MID, y, x, variant) > thr;
+      out[((size_t)i * H + y) * W + x] = (uint8_t)m;
+      if (label) {
+        const int l = label[(size_t)y * W + x] != 0;
+        tp += m & l; fp += m & !l; fn += !m & l;
+      }
+    }
+  }
+  if (!label) return;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    tp += __shfl_xor(tp, o, 64); fp += __shfl_xor(fp, o, 64); fn += __shfl_xor(fn, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (tp) atomicAdd(counts + (size_t)i * 3 + 0, (unsigned long long)tp);
+    if (fp) atomicAdd(counts + (size_t)i * 3 + 1, (unsigned long long)fp);
+    if (fn) atomicAdd(counts + (size_t)i * 3 + 2, (unsigned long long)fn);
+  }
+}
+extern "C" int psam_mask_binarize(const float* low, const int* idx, int n, int IN, int MID, int H, int W, int variant,
+                                  float thr, uint8_t* out, const uint8_t* label, long long* counts, void* stream) {
+  if (n <= 0 || variant < 0 || variant > 2 || H <= 0 || W <= 0 || H > MID || W > MID || (label && !counts))
+    return PSAM_ERR_ARG;
+  if (label) (void)hipMemsetAsync(counts, 0, sizeof(long long) * 3 * n, (hipStream_t)stream);
+  hipLaunchKernelGGL(mask_binarize_kernel, dim3((H + MS_ROWS - 1) / MS_ROWS, n), dim3(256), 0, (hipStream_t)stream, low,
+                     idx, IN, MID, H, W, variant, thr, out, label, (unsigned long long*)counts);
+  return psam_launch_status();
+}

@@ -392,6 +392,38 @@ def mask_union(low, sel, MID, OUT, variant, thr=0.0, pred=None):
     return pred
 
 
+def mask_stats(low, first, nsel, MID, H, W, variant, thr=0.0, off=1.0, stats=None):
+    """int32 [B*nsel, 8] = {n(v>thr+off), n(v>thr-off), n(v>thr), min_x, min_y, max_x, max_y, 0} per selected plane of
+    low [B,C,IN,IN] over the [H,W] corner of its MID x MID up-sampling."""
+    _req(low, torch.float32, "low")
+    assert low.is_contiguous() and low.dim() == 4
+    B, C, IN, _ = low.shape
+    if stats is None:
+        stats = torch.empty((B * nsel, 8), dtype=torch.int32, device=low.device)
+    st = _lib.lib().psam_mask_stats(_ptr(low), B, C, first, nsel, IN, MID, H, W, variant, float(thr), float(off),
+                                   _ptr(stats), _stream())
+    _lib.check(st, "psam_mask_stats")
+    return stats
+
+
+def mask_binarize(low, idx, MID, H, W, variant, thr=0.0, label=None, out=None):
+    """uint8 [n,H,W] = upsample(low.view(-1,IN,IN)[idx[i]]) > thr; with `label` uint8 [H,W] also int64 [n,3] {tp,fp,fn}."""
+    _req(low, torch.float32, "low"); _req(idx, torch.int32, "idx")
+    assert low.is_contiguous() and idx.is_contiguous()
+    IN, n = low.shape[-1], idx.numel()
+    if out is None:
+        out = torch.empty((n, H, W), dtype=torch.uint8, device=low.device)
+    counts = None
+    if label is not None:
+        _req(label, torch.uint8, "label")
+        assert label.is_contiguous() and tuple(label.shape) == (H, W)
+        counts = torch.empty((n, 3), dtype=torch.int64, device=low.device)
+    st = _lib.lib().psam_mask_binarize(_ptr(low), _ptr(idx), n, IN, MID, H, W, variant, float(thr), _ptr(out),
+                                      _ptr(label), _ptr(counts), _stream())
+    _lib.check(st, "psam_mask_binarize")
+    return out, counts
+
+
 def normalize_chw(x, mean3, std3, out=None):
     """(x - mean[c]) / std[c] on [B,3,H,W]; x uint8 or fp32."""
     import ctypes

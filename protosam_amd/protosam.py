@@ -27,6 +27,7 @@ import torch.nn as nn
 
 from . import ops
 from .grid_proto_fewshot import FewShotSeg
+from .sam_wrapper import SamWrapper
 from .segment_anything import SamPredictor, sam_model_registry
 from .segment_anything.utils.transforms import ResizeLongestSide
 
@@ -93,15 +94,41 @@ class ALPNetOutput(SegmentationOutput):
         return self.pred
 
 
+class SAMWrapperInput(SegmentationInput):
+    """ProtoSAM.py:94-109."""
+
+    def __init__(self, image, image_labels):
+        self.image = image
+        self.image_labels = image_labels
+
+    def set_query_images(self, query_images):
+        B, C, H, W = query_images.shape
+        if isinstance(query_images, torch.Tensor):
+            query_images = query_images.cpu().detach().numpy()
+        assert B == 1, "batch size must be 1"
+        query_images = (query_images - query_images.min()) / (query_images.max() - query_images.min()) * 255
+        self.image = np.transpose(query_images.astype(np.uint8)[0], (1, 2, 0))
+
+    def to(self, device):
+        pass
+
+
 class InputFactory(ABC):
     @staticmethod
     def create_input(input_type, query_image, support_images=None, support_labels=None, isval=False, val_wsize=None,
                      show_viz=False, supp_fts=None, original_sz=None, img_sz=None, gts=None):
         if input_type == TYPE_ALPNET:
             return ALPNetInput(support_images, support_labels, query_image, isval, val_wsize, show_viz, supp_fts)
-        elif input_type == TYPE_SAM:
-            raise NotImplementedError("TYPE_SAM inputs feed SamWrapperWrapper, which validation_protosam.get_model "
-                                      "cannot reach (validation_protosam.py:208-213)")
+        elif input_type == TYPE_SAM:                                            # ProtoSAM.py:118-128
+            qimg = query_image.detach().cpu().numpy().copy()
+            B, C, H, W = qimg.shape
+            assert B == 1, "batch size must be 1"
+            gts = gts.detach().cpu().numpy().astype(np.uint8).reshape(H, W)
+            assert np.unique(gts).shape[0] <= 2, "support labels must be binary"
+            gts[gts > 0] = 1
+            qimg = qimg.reshape(H, W, C)   # sic: a reshape, not a transpose (ProtoSAM.py:126)
+            qimg = (qimg - qimg.min()) / (qimg.max() - qimg.min()) * 255
+            return SAMWrapperInput(qimg.astype(np.uint8), gts)
         else:
             raise ValueError("input_type not supported")
 
@@ -143,6 +170,21 @@ class ALPNetWrapper(ModelWrapper):
 
     def train(self):
         self.model.encoder.train()
+
+
+class SamWrapperWrapper(ModelWrapper):
+    """ProtoSAM.py:170-182: makes SamWrapper's best mask look like 2-class logits [1, 2, H, W]. The mask never leaves
+    the device here (the reference builds the tensor on the host, :176)."""
+
+    def __init__(self, model: SamWrapper):
+        super().__init__(model)
+
+    def __call__(self, input_data: SAMWrapperInput):
+        pred = self.model(**input_data.__dict__, return_device=True).float()[None, None, ...]
+        return torch.cat([1 - pred, pred], dim=1)
+
+    def to(self, device):
+        self.model.sam.to(device)
 
 
 class ProtoSAM(nn.Module):

@@ -109,10 +109,12 @@ class MaskDecoder(nn.Module):
         return self._ws[key]
 
     # ---- the decoder ---------------------------------------------------------------------------------------------
-    def predict_masks_tokens(self, feat_tok, pe_tok, tokens, dense_vec, img_of_prompt=None):
+    def predict_masks_tokens(self, feat_tok, pe_tok, tokens, dense_vec, img_of_prompt=None, masks_out=None,
+                             iou_out=None):
         """feat_tok fp32 [Nk,256] (one image) or [n_img,Nk,256] token-major image embeddings, pe_tok fp32 [Nk,256],
         tokens fp32 [B,T,256] (output tokens ++ sparse prompts), dense_vec fp32 [256] (no-mask embedding),
         img_of_prompt int32 [B] (which image each prompt set belongs to; None = image 0).
+        masks_out / iou_out: optional contiguous destinations (else views of the workspace, overwritten by the next call).
         -> masks [B,4,256,256], iou [B,4]."""
         pk = self._packed()
         B, T, _ = tokens.shape
@@ -173,12 +175,14 @@ class MaskDecoder(nn.Module):
             wg=256 * 256, bg=256, yg=256, ldx=4 * 256, ldy=4 * 256)
         lin(ws["h2"], pk["hyp_w"][2], pk["hyp_b"][2], out=ws["hyper"], G=4, M=B, N=32, K=256, xg=256, wg=32 * 256,
             bg=32, yg=32, ldx=4 * 256, ldy=4 * 32)
-        ops.upscale_tail(ws["u1"], pk["up_lnw"], pk["up_lnb"], pk["up2_w"], pk["up2_b"], ws["hyper"], B, g,
-                         masks=ws["masks"])
+        masks = ws["masks"] if masks_out is None else masks_out
+        iou = ws["iou"] if iou_out is None else iou_out
+        assert masks.is_contiguous() and iou.is_contiguous() and masks.shape[0] == B and iou.shape[0] == B
+        ops.upscale_tail(ws["u1"], pk["up_lnw"], pk["up_lnb"], pk["up2_w"], pk["up2_b"], ws["hyper"], B, g, masks=masks)
         lin(hs[:, 0], pk["iou"][0][0], pk["iou"][0][1], out=ws["i1"], act=1, M=B, N=256, K=256, ldx=T * 256, ldy=256)
         lin(ws["i1"], pk["iou"][1][0], pk["iou"][1][1], out=ws["i2"], act=1)
-        lin(ws["i2"], pk["iou"][2][0], pk["iou"][2][1], out=ws["iou"])
-        return ws["masks"], ws["iou"], hs
+        lin(ws["i2"], pk["iou"][2][0], pk["iou"][2][1], out=iou)
+        return masks, iou, hs
 
     def build_tokens(self, sparse):
         """cat(iou_token, mask_tokens) ++ sparse prompts (mask_decoder.py:121-123)."""

@@ -1,0 +1,166 @@
+"""GPU parity of the automatic mask generator and `SamWrapper` against the CPU oracle
+(oracle/amg.py, pinned to the vendored reference by oracle/validate_against_reference.py) and the reference's recorded
+records in tests/golden/reference_outputs.npz."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_outputs.npz")
+
+
+@pytest.mark.parametrize("variant,H,W", [(0, 1024, 1024), (1, 1024, 1024), (1, 768, 1024), (2, 1024, 640)])
+def test_mask_stats_and_binarize_kernels(dev, variant, H, W):
+    """Counts / boxes / binary masks computed from the 256x256 logits equal the same reductions of the materialised
+    up-sampling (`psam_mask_upsample`, itself checked against F.interpolate in test_sam_gpu.py) EXACTLY."""
+    from protosam_amd import ops
+    g = torch.Generator().manual_seed(variant * 7 + H)
+    low = torch.randn((6, 4, 256, 256), generator=g) * 2.0
+    low = F.avg_pool2d(low, 9, 1, 4) * 6.0                      # smooth blobs with values on both sides of +-1
+    low[1, 2] = -5.0                                            # an empty mask
+    low[2, 1] = 5.0                                             # a full one
+    low[3, 3, :, :] = -5.0
+    low[3, 3, 100:103, 40:41] = 3.0                             # a tiny island
+    low = low.to(dev).contiguous()
+    thr, off = 0.0, 1.0
+    stats = ops.mask_stats(low, 1, 3, 1024, H, W, variant, thr, off).cpu().numpy()
+    up = ops.mask_upsample(low, 1024, variant)[:, 1:, :H, :W].reshape(-1, H, W)
+    assert stats.shape == (18, 8)
+    hi = (up > thr + off).sum((1, 2)).cpu().numpy()
+    lo = (up > thr - off).sum((1, 2)).cpu().numpy()
+    m = up > thr
+    area = m.sum((1, 2)).cpu().numpy()
+    np.testing.assert_array_equal(stats[:, 0], hi)
+    np.testing.assert_array_equal(stats[:, 1], lo)
+    np.testing.assert_array_equal(stats[:, 2], area)
+    for p in range(18):
+        if area[p] == 0:
+            assert stats[p, 3:7].tolist() == [2**31 - 1, 2**31 - 1, -1, -1]
+            continue
+        ys, xs = torch.nonzero(m[p], as_tuple=True)
+        assert stats[p, 3:7].tolist() == [int(xs.min()), int(ys.min()), int(xs.max()), int(ys.max())]
+    assert area[1 * 3 + 1] == 0 and area[2 * 3 + 0] == H * W
+    # binarise a subset (indices into low.view(-1, 256, 256)) and score it against a label
+    idx = torch.tensor([1, 6, 9, 15, 23], dtype=torch.int32, device=dev)
+    label = (torch.rand((H, W), generator=g) > 0.6).to(torch.uint8).to(dev)
+    out, counts = ops.mask_binarize(low, idx, 1024, H, W, variant, thr, label=label)
+    full = ops.mask_upsample(low, 1024, variant).reshape(-1, 1024, 1024)[idx.long(), :H, :W] > thr
+    assert out.dtype == torch.uint8 and torch.equal(out.bool(), full)
+    lb = label.bool()[None]
+    exp = torch.stack([(full & lb).sum((1, 2)), (full & ~lb).sum((1, 2)), (~full & lb).sum((1, 2))], 1)
+    assert torch.equal(counts, exp)
+    out2, none = ops.mask_binarize(low, idx, 1024, H, W, variant, thr)
+    assert none is None and torch.equal(out2, out)
+
+
+@pytest.fixture(scope="module")
+def amg_setup(dev):
+    """SAM vit_b (2 encoder blocks, synthetic weights) + the oracle's view of every candidate of the 8x8 grid."""
+    from oracle import amg as oamg, golden_inputs as gi
+    from protosam_amd.sam_wrapper import SamWrapper
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    gold = np.load(GOLD)
+    t_iou, t_stab = (float(v) for v in gold["amg_thresholds"])
+    args = dict(gi.AMG_ARGS, pred_iou_thresh=t_iou, stability_score_thresh=t_stab)
+    w = SamWrapper({"model_type": "vit_b", "sam_checkpoint": f"random:{gi.AMG_SEED}:{gi.AMG_ENCODER_DEPTH}",
+                    "generator_args": args}).to(dev)
+    sd = {k: v.detach().cpu() for k, v in w.sam.state_dict().items()}
+    img, label = gi.amg_case()
+    taps = {}
+    okw = dict(encoder_depth=gi.AMG_ENCODER_DEPTH, **args)
+    best, bi, ious, anns = oamg.sam_wrapper_forward(img, label, sd, taps=taps, **okw)
+    return dict(w=w, sd=sd, img=img, label=label, gold=gold, taps=taps, best=best, bi=bi, ious=ious, anns=anns, args=args)
+
+
+def test_candidates_vs_oracle(dev, amg_setup):
+    """Every candidate (no filtering, no suppression): predicted IoU, stability score, area and box vs the oracle."""
+    from protosam_amd.segment_anything import SamAutomaticMaskGenerator
+    s = amg_setup
+    g = SamAutomaticMaskGenerator(s["w"].sam, **dict(s["args"], pred_iou_thresh=0.0, stability_score_thresh=0.0))
+    cand = g._candidates(s["img"])
+    plane = cand["plane"].cpu().numpy()
+    k = (plane // 4) * 3 + plane % 4 - 1                                         # position in the oracle's flatten(0, 1)
+    assert sorted(k.tolist()) == list(range(192))
+    iou_o, stab_o = s["taps"]["iou_all"].numpy()[k], s["taps"]["stab_all"].numpy()[k]
+    e_iou = np.abs(cand["iou_preds"] - iou_o).max()
+    e_stab = np.abs(cand["stability_score"] - stab_o).max()
+    print(f"192 candidates: predicted IoU max err {e_iou:.2e}, stability max err {e_stab:.2e}")
+    assert e_iou < 5e-3 and e_stab < 5e-3
+    assert np.all(np.diff(cand["iou_preds"]) <= 0)                              # NMS order = decreasing score
+    assert (cand["boxes"] == np.array([0, 0, 1023, 1023])).all()                 # noise-like masks span the image
+
+
+def test_generate_vs_reference_records(dev, amg_setup):
+    """`generate` with the golden thresholds keeps the same candidates as the REFERENCE run recorded in the fixture."""
+    from protosam_amd.segment_anything import SamAutomaticMaskGenerator
+    s, gold = amg_setup, amg_setup["gold"]
+    g = SamAutomaticMaskGenerator(s["w"].sam, **s["args"])
+    anns = g.generate(s["img"])
+    assert len(anns) == len(gold["amg_pred_iou"]) == len(s["anns"])
+    got = {tuple(a["point_coords"][0]) for a in anns}
+    ref = {tuple(p) for p in gold["amg_points"].tolist()}
+    assert got == ref
+    # records agree one by one once both lists are ordered by (point, predicted IoU)
+    o = sorted(range(len(anns)), key=lambda i: (anns[i]["point_coords"][0], -anns[i]["predicted_iou"]))
+    r = sorted(range(len(anns)), key=lambda i: (gold["amg_points"][i].tolist(), -gold["amg_pred_iou"][i]))
+    for i, j in zip(o, r):
+        a = anns[i]
+        assert set(a) == {"segmentation", "area", "bbox", "predicted_iou", "point_coords", "stability_score", "crop_box"}
+        assert abs(a["predicted_iou"] - gold["amg_pred_iou"][j]) < 5e-3
+        assert abs(a["stability_score"] - gold["amg_stability"][j]) < 5e-3
+        assert a["bbox"] == gold["amg_bbox"][j].tolist() and a["crop_box"] == [0, 0, 1024, 1024]
+        assert abs(a["area"] - int(gold["amg_area"][j])) <= 0.004 * 1024 * 1024
+        assert a["segmentation"].dtype == bool and a["segmentation"].shape == (1024, 1024)
+        assert int(a["segmentation"].sum()) == a["area"]
+        assert isinstance(a["area"], int) and isinstance(a["predicted_iou"], float)
+    # default suppression: all boxes coincide, so only the top-scoring record survives (as in the reference run)
+    g7 = SamAutomaticMaskGenerator(s["w"].sam, **dict(s["args"], box_nms_thresh=0.7))
+    a7 = g7.generate(s["img"])
+    assert len(a7) == 1 and a7[0]["point_coords"] == [gold["amg_points"][0].tolist()]
+    # uncompressed RLE output decodes to the same mask
+    from protosam_amd.segment_anything.utils.amg import area_from_rle, rle_to_mask
+    gr = SamAutomaticMaskGenerator(s["w"].sam, **dict(s["args"], box_nms_thresh=0.7, output_mode="uncompressed_rle"))
+    ar = gr.generate(s["img"])
+    assert np.array_equal(rle_to_mask(ar[0]["segmentation"]), a7[0]["segmentation"])
+    assert area_from_rle(ar[0]["segmentation"]) == a7[0]["area"]
+
+
+def test_sam_wrapper_forward(dev, amg_setup):
+    """SamWrapper.forward: the proposal with the best IoU against the label, vs the oracle and the reference fixture."""
+    from protosam_amd.protosam import InputFactory, SamWrapperWrapper, TYPE_SAM
+    s, gold = amg_setup, amg_setup["gold"]
+    out = s["w"](s["img"], s["label"])
+    assert out.dtype == bool and out.shape == (1024, 1024)
+    st = s["w"].last_stats
+    ious_o = np.array([float(v) for v in s["ious"]])
+    srt = np.sort(ious_o)[::-1]
+    print(f"best IoU oracle {srt[0]:.5f} (runner-up {srt[1]:.5f}), GPU {st['best_iou']:.5f}, {st['n_masks']} proposals")
+    assert abs(st["best_iou"] - srt[0]) < 2e-3
+    ref_best = np.unpackbits(gold["amg_best_mask_bits"]).reshape(1024, 1024).astype(bool)
+    if srt[0] - srt[1] > 4e-3:                                                   # an unambiguous winner
+        dice = 2.0 * (out & ref_best).sum() / (out.sum() + ref_best.sum())
+        flips = int((out != ref_best).sum())
+        print(f"best mask vs reference: Dice {dice:.5f}, {flips} differing pixels")
+        assert dice > 0.995
+        assert np.array_equal(ref_best, s["best"]) or int((ref_best != s["best"]).sum()) <= 4
+    # device-side IoU counts == numpy get_iou on the downloaded masks
+    from protosam_amd.sam_wrapper import get_iou
+    cand, masks, counts = s["w"].mask_generator.generate_device(s["img"], torch.from_numpy(s["label"]).to(dev))
+    m = masks.cpu().numpy()
+    for i in range(len(m)):
+        assert abs(get_iou(m[i], s["label"]) - st["ious"][i]) < 1e-12
+    # the ModelWrapper view used by ProtoSAM: 2-class "logits" on the device
+    inp = InputFactory.create_input(TYPE_SAM, torch.zeros((1, 3, 8, 8)).add_(torch.arange(8.0)), gts=torch.zeros((8, 8)))
+    assert inp.image.shape == (8, 8, 3) and inp.image.dtype == np.uint8 and inp.image_labels.shape == (8, 8)
+    inp.image, inp.image_labels = s["img"], s["label"]
+    lg = SamWrapperWrapper(s["w"])(inp)
+    assert lg.is_cuda and lg.shape == (1, 2, 1024, 1024)
+    assert torch.equal(lg[0, 1].bool().cpu(), torch.from_numpy(out)) and torch.equal(lg[0, 0], 1 - lg[0, 1])
+    # error behaviour
+    with pytest.raises(ValueError):
+        s["w"](s["img"], np.zeros((512, 512), np.uint8))
+    with pytest.raises(ValueError):
+        s["w"](s["img"], np.full((1024, 1024), 3, np.uint8))
