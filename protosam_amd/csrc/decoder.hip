@@ -48,13 +48,77 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float* __restri
   }
 }
 
+// Many rows (the automatic mask generator decodes hundreds of prompt sets at once): the same contraction as a 64x64 tile
+// per block on the fp32 MFMA (v_mfma_f32_32x32x2f32), W as the A operand so each lane ends up with 4 consecutive output
+// columns of one row (16 B stores). x (+ x2) and W tiles are staged through LDS in 32-wide k slabs.
+#define SLM_LD 33
+__global__ __launch_bounds__(256) void small_linear_mfma_kernel(const float* __restrict__ x, const float* __restrict__ x2,
+                                                                const float* __restrict__ W, const float* __restrict__ b,
+                                                                const float* __restrict__ resid, float* __restrict__ y,
+                                                                int M, int N, int K, long long xg, long long wg,
+                                                                long long bg, long long yg, int ldx, int ldy, int act) {
+  __shared__ float Xs[64 * SLM_LD], Ws[64 * SLM_LD];
+  const int g = blockIdx.z, m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, lr = lane & 31, lk = lane >> 5;
+  const int wn = wave & 1, wm = wave >> 1;
+  const int lrow = t >> 2, lcol = (t & 3) * 8;
+  const float* xr = x + (size_t)g * xg + (size_t)(m0 + lrow) * ldx + lcol;
+  const float* x2r = x2 ? x2 + (size_t)g * xg + (size_t)(m0 + lrow) * ldx + lcol : nullptr;
+  const float* wr = W + (size_t)g * wg + (size_t)(n0 + lrow) * K + lcol;
+  const bool xin = m0 + lrow < M, win = n0 + lrow < N;
+  f32x16 acc = {0};
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    float xv[8], wv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      xv[i] = xin ? xr[k0 + i] : 0.f;
+      if (x2r && xin) xv[i] += x2r[k0 + i];
+      wv[i] = win ? wr[k0 + i] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      Xs[lrow * SLM_LD + lcol + i] = xv[i];
+      Ws[lrow * SLM_LD + lcol + i] = wv[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) {
+      const float a = Ws[(wn * 32 + lr) * SLM_LD + 2 * s2 + lk];
+      const float bq = Xs[(wm * 32 + lr) * SLM_LD + 2 * s2 + lk];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc, 0, 0, 0);
+    }
+  }
+  // acc[r]: n = n0 + wn*32 + (r&3) + 8*(r>>2) + 4*lk ; m = m0 + wm*32 + lr
+  const int m = m0 + wm * 32 + lr;
+  if (m >= M) return;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int n = n0 + wn * 32 + 8 * q + 4 * lk;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (n + i >= N) break;
+      float v = acc[q * 4 + i] + (b ? b[(size_t)g * bg + n + i] : 0.f);
+      if (act == 1) v = fmaxf(v, 0.f);
+      const size_t o = (size_t)g * yg + (size_t)m * ldy + n + i;
+      if (resid) v += resid[o];
+      y[o] = v;
+    }
+  }
+}
+
 extern "C" int psam_small_linear(const float* x, const float* x2, const float* W, const float* b, const float* resid,
                                  float* y, int G,
                                  int M, int N, int K, long long xg, long long wg, long long bg, long long yg, int ldx,
                                  int ldy, int act, void* stream) {
   if (G <= 0 || M <= 0 || N <= 0 || (K % 64) != 0) return PSAM_ERR_ARG;
-  dim3 grid((N + 3) / 4, G), block(256);
   hipStream_t s = (hipStream_t)stream;
+  if (M >= 32 && (K % 32) == 0) {
+    hipLaunchKernelGGL(small_linear_mfma_kernel, dim3((M + 63) / 64, (N + 63) / 64, G), dim3(256), 0, s, x, x2, W, b,
+                       resid, y, M, N, K, xg, wg, bg, yg, ldx, ldy, act);
+    return psam_launch_status();
+  }
+  dim3 grid((N + 3) / 4, G), block(256);
 #define SL(KV) hipLaunchKernelGGL(small_linear_kernel<KV>, grid, block, 0, s, x, x2, W, b, resid, y, M, N, xg, wg, bg, yg, ldx, ldy, act)
   switch (K / 64) {
     case 1: SL(1); break;
@@ -601,7 +665,7 @@ __global__ __launch_bounds__(256) void mask_binarize_kernel(const float* __restr
       out[((size_t)i * H + y) * W + x] = (uint8_t)m;
       if (label) {
         const int l = label[(size_t)y * W + x] != 0;
-        tp += m & l; fp += m & !l; fn += !m & l;
+        tp += m & l; fp += m & (!l); fn += (!m) & l;
       }
     }
   }

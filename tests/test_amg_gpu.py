@@ -164,3 +164,29 @@ def test_sam_wrapper_forward(dev, amg_setup):
         s["w"](s["img"], np.zeros((512, 512), np.uint8))
     with pytest.raises(ValueError):
         s["w"](s["img"], np.full((1024, 1024), 3, np.uint8))
+
+
+@pytest.mark.parametrize("M,N,K,G", [(7, 256, 256, 1), (45, 128, 256, 1), (1792, 256, 256, 1), (1792, 2048, 256, 1),
+                                     (1792, 256, 2048, 1), (100, 4, 256, 1), (256, 32, 256, 4), (33, 70, 128, 1)])
+def test_small_linear_both_paths(dev, M, N, K, G):
+    """fp32 token-side linear: the one-wave-per-column kernel (M < 32) and the fp32-MFMA tile kernel (M >= 32) against a
+    float64 matmul, with the fused x + x2, ReLU, residual and grouped (hyper-network) forms."""
+    from protosam_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn((G, M, K), generator=g)
+    x2 = torch.randn((G, M, K), generator=g)
+    W = torch.randn((G, N, K), generator=g) / K ** 0.5
+    b = torch.randn((G, N), generator=g)
+    r = torch.randn((G, M, N), generator=g)
+    xd, x2d, Wd, bd, rd = (t.to(dev).contiguous() for t in (x, x2, W, b, r))
+    for act, use_x2, use_r in ((0, False, False), (1, True, True), (0, True, False), (1, False, True)):
+        ref = (x.double() + (x2.double() if use_x2 else 0)) @ W.double().transpose(1, 2) + b.double()[:, None]
+        if act:
+            ref = ref.clamp_min(0)
+        if use_r:
+            ref = ref + r.double()
+        out = torch.full((G, M, N), float("nan"), device=dev)
+        ops.small_linear(xd, Wd, bd, out=out, act=act, resid=rd if use_r else None, x2=x2d if use_x2 else None, G=G, M=M,
+                         N=N, K=K, xg=M * K, wg=N * K, bg=N, yg=M * N, ldx=K, ldy=N)
+        err = (out.cpu().double() - ref).abs().max().item()
+        assert err < 2e-5 * (K / 256) ** 0.5 + 1e-5, (act, use_x2, use_r, err)
