@@ -20,6 +20,7 @@
 // the DMA's per-lane SOURCE address, because the LDS side of the DMA is lane-linear.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 enum { EPI_F16 = 0, EPI_GELU_F16 = 1, EPI_F32 = 2 };
 
@@ -37,6 +38,7 @@ struct GemmArgs {
   int out_seg_stride;
   int out_seg_off;
   int map_mode;  // 0: XCD-region tile map (default); 1: identity; 2: contiguous chunk per XCD
+  int dbg;       // ablation switches for tools/gemm_ablate.py (PSAM_GEMM_DBG; only the DBG instantiation reads it)
 };
 
 
@@ -609,6 +611,392 @@ __global__ __launch_bounds__(512) void gemm_ws_f16_kernel(GemmArgs p) {
       store_acc32<EPI>(acc[i][j], m0 + wm * 128 + i * 32 + lr, n0 + wn * 64 + j * 32 + 4 * lg, p);
 }
 
+
+// =====================================================================================================
+// 256 x 256 x 64, 8 waves (2 x 4, wave tile 128 x 64), "8-phase" schedule (tile 7).
+// A K-tile is consumed in four phases, one 64 x 32 quadrant of the wave tile (8 MFMA 32x32x16) each, in the order
+// (A0,B0) (A0,B1) (A1,B1) (A1,B0) so only one operand sub-tile changes per phase (12 / 4 / 8 / 0 ds_read_b128).
+// LDS = 2 buffers x 4 half-tiles (A0 A1 B0 B1) of [128][64] fp16 = 128 KiB. Half-tile Ah holds, for BOTH wave rows,
+// sub-tile h of their 128 rows (local row wr*64 + i <-> block row wr*128 + h*64 + i); Bh likewise for the four wave
+// columns (local row wc*32 + i <-> block column wc*64 + h*32 + i), so every wave finishes reading A0/B0 in phase 1, B1 in
+// phase 2 and A1 in phase 3 and the half-tile can be refilled two phases later. Each phase issues the DMA of ONE
+// half-tile (2 x global_load_lds_dwordx4 per lane), in consumption order, ~6 phases ahead of its first read:
+//     phase 1(t): B1(t+1)   phase 2(t): A1(t+1)   phase 3(t): A0(t+2)   phase 4(t): B0(t+2)
+// followed by s_waitcnt vmcnt(8): the four newest half-tiles stay in flight, everything a wave issued before them has
+// landed - which is exactly what the NEXT phase reads. The queue is never drained inside the loop.
+// The two wave rows (one wave of each per SIMD) run the same phase sequence one barrier apart, so on every SIMD one
+// wave is in its MFMA segment while the other reads fragments and issues DMA.
+// Ordering: a half-tile is read only after a barrier that every wave passed after its own counted wait for it (phase
+// p waits, phase p+1 reads; the lagging group's wait is one barrier later, its read too). A half-tile is refilled >= 2
+// phases after its last read, whose lgkmcnt(0) every wave passed before the intervening barriers.
+__device__ __forceinline__ int lds_off64(int row, int chunk) {
+  return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3);
+}
+
+template <int EPI, bool DBG = false>
+__global__ __launch_bounds__(512) void gemm8p_f16_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) half_t ring[];  // [buf 2][A0 A1 B0 B1][128][64]
+  constexpr int HT = 128 * 64;                                     // halfs per half-tile
+  const int ntn = p.N / 256;
+  const int ntm = (p.M + 255) / 256;
+  int tm, tn;
+  if (!tile_map(blockIdx.x, ntm, ntn, p.map_mode, tm, tn)) return;
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = wv >> 2, wc = wv & 3;
+  const int lr = lane & 31, lg = lane >> 5;
+
+  // DMA sources. Instruction j of a half-tile covers local rows j*64 + t/8 (8 lanes = one 128-byte row), slot t%8.
+  const half_t* asrc[2];  // half 0; half 1 = + 64 rows
+  const half_t* bsrc[2];  // half 0; half 1 = + 32 rows
+  int a_clamp[2][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int lrow = j * 64 + (t >> 3);
+    const int chunk = (t & 7) ^ ((lrow >> 1) & 7);
+    const int arow = (lrow >> 6) * 128 + (lrow & 63);       // + h*64
+    const int brow = (lrow >> 5) * 64 + (lrow & 31);        // + h*32
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int am = m0 + arow + h * 64;
+      a_clamp[j][h] = (am < p.M ? am : p.M - 1) - (m0 + arow);   // row delta actually fetched (ragged last tile)
+    }
+    asrc[j] = p.A + (size_t)(m0 + arow) * p.lda + chunk * 8;
+    bsrc[j] = p.W + (size_t)(n0 + brow) * p.ldw + chunk * 8;
+  }
+  // stage half-tile `which` (0 A0, 1 A1, 2 B0, 3 B1) of K-tile kt
+  const int dbg = DBG ? p.dbg : 0;  // 1: no DMA in the loop, 2: no fragment reads, 4: no MFMA, 8: no epilogue, 16: no barriers
+  auto stage = [&](int which, int kt) {
+    if (DBG && (dbg & 1) && kt > 1) return;
+    half_t* dst = ring + ((kt & 1) * 4 + which) * HT + wv * 512;
+    const int h = which & 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const half_t* g = which < 2 ? asrc[j] + (ptrdiff_t)a_clamp[j][h] * p.lda : bsrc[j] + (size_t)h * 32 * p.ldw;
+      glds16(g + kt * 64, dst + j * 4096);
+    }
+  };
+
+  f32x16 acc[2][2][2];  // [a][i][b]: rows m0 + wr*128 + a*64 + i*32 + lr, cols n0 + wc*64 + b*32 + ...
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][i][b][r] = 0.f;
+
+  const int nk = p.K / 64;
+  // prologue: A0 B0 B1 A1 of K-tile 0, A0 B0 of K-tile 1 (the steady schedule's phases 3/4 of "K-tile -1")
+  stage(0, 0); stage(2, 0); stage(3, 0); stage(1, 0);
+  if (nk > 1) { stage(0, 1); stage(2, 1); wait_vmcnt<8>(); } else { wait_vmcnt<4>(); }
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger the second wave row by one barrier
+  asm volatile("" ::: "memory");
+
+  half8_t fa[2][4], fb0[4], fb1[4];
+  const int arow0 = wr * 64 + lr, brow0 = wc * 32 + lr;
+
+#define PHASE_SYNC_IN()                                   \
+  if (!(DBG && (dbg & 16))) __builtin_amdgcn_s_barrier(); \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+  __builtin_amdgcn_sched_barrier(0);                      \
+  __builtin_amdgcn_s_setprio(1);
+#define PHASE_SYNC_OUT()                                  \
+  __builtin_amdgcn_s_setprio(0);                          \
+  __builtin_amdgcn_sched_barrier(0);                      \
+  if (!(DBG && (dbg & 16))) __builtin_amdgcn_s_barrier(); \
+  asm volatile("" ::: "memory");
+#define RD(dst, off) if (!(DBG && (dbg & 2))) dst = *reinterpret_cast<const half8_t*>(&buf[off])
+#define MMA(c, a_, b_) if (!(DBG && (dbg & 4))) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, c, 0, 0, 0)
+
+  if (DBG) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) fa[i][s2] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) fb0[s2] = fb1[s2] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    const half_t* buf = ring + (kt & 1) * 4 * HT;
+    const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+    // ---- phase 1: read B0, A0; stage B1(kt+1); quadrant (A0, B0) -------------------------------------------------
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2)
+      RD(fb0[s2], 2 * HT + lds_off64(brow0, s2 * 2 + lg));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2)
+        RD(fa[i][s2], 0 * HT + lds_off64(arow0 + i * 32, s2 * 2 + lg));
+    if (more1) stage(3, kt + 1);
+    if (more2) wait_vmcnt<8>(); else wait_vmcnt<0>();
+    PHASE_SYNC_IN();
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        MMA(acc[0][i][0], fb0[s2], fa[i][s2]);
+    PHASE_SYNC_OUT();
+    // ---- phase 2: read B1; stage A1(kt+1); quadrant (A0, B1) -----------------------------------------------------
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2)
+      RD(fb1[s2], 3 * HT + lds_off64(brow0, s2 * 2 + lg));
+    if (more1) stage(1, kt + 1);
+    if (more2) wait_vmcnt<8>(); else wait_vmcnt<0>();
+    PHASE_SYNC_IN();
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        MMA(acc[0][i][1], fb1[s2], fa[i][s2]);
+    PHASE_SYNC_OUT();
+    // ---- phase 3: read A1; stage A0(kt+2); quadrant (A1, B1) -----------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2)
+        RD(fa[i][s2], 1 * HT + lds_off64(arow0 + i * 32, s2 * 2 + lg));
+    if (more2) { stage(0, kt + 2); wait_vmcnt<8>(); } else { wait_vmcnt<0>(); }
+    PHASE_SYNC_IN();
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        MMA(acc[1][i][1], fb1[s2], fa[i][s2]);
+    PHASE_SYNC_OUT();
+    // ---- phase 4: no reads; stage B0(kt+2); quadrant (A1, B0) ----------------------------------------------------
+    if (more2) { stage(2, kt + 2); wait_vmcnt<8>(); } else { wait_vmcnt<0>(); }
+    PHASE_SYNC_IN();
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        MMA(acc[1][i][0], fb0[s2], fa[i][s2]);
+    PHASE_SYNC_OUT();
+  }
+#undef PHASE_SYNC_IN
+#undef PHASE_SYNC_OUT
+#undef RD
+#undef MMA
+  if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the stagger
+  if (DBG && (dbg & 8)) return;
+
+  // epilogue: every wave parks its two 64x64 slabs, one after the other, in its own 16 KiB of the (idle, fully landed,
+  // no longer read) ring and re-reads them row-contiguously: each store instruction covers 4 rows x 128/256 bytes
+  float* slab = reinterpret_cast<float*>(ring) + wv * 4096;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+    store_slab_staged<EPI, false>(acc[a][0][0], acc[a][0][1], acc[a][1][0], acc[a][1][1], slab, m0 + wr * 128 + a * 64,
+                                  n0 + wc * 64, lane, p);
+}
+
+template <int EPI, bool DBG = false>
+static void launch8p(const GemmArgs& p, hipStream_t s) {
+  constexpr int LDS = 2 * 4 * 128 * 64 * 2;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm8p_f16_kernel<EPI, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr = true;
+  }
+  const int ntm = (p.M + 255) / 256, ntn = p.N / 256;
+  hipLaunchKernelGGL((gemm8p_f16_kernel<EPI, DBG>), dim3(tile_map_grid(ntm, ntn, p.map_mode)), dim3(512), LDS, s, p);
+}
+
+
+// =====================================================================================================
+// Tile 8: the 8-phase kernel's geometry, half-tile DMA schedule and LDS image, with ONE barrier per phase instead of
+// two. The two wave rows run the same phase in the same barrier interval but in opposite order: row 0 opens the
+// interval with the phase's MFMAs (its fragments were read in the previous interval) and then reads the NEXT phase's
+// fragments; row 1 reads the phase's fragments first and then issues its MFMAs. On every SIMD one wave therefore starts
+// on the matrix pipe while the other starts on LDS, and they swap without a rendezvous. An empty barrier interval costs
+// ~270 cycles on this chip (measured: tile 7 with everything but the barriers removed), more than the 256 cycles of a
+// phase's MFMAs, so halving the barrier count matters more than any instruction placement inside a phase.
+// Row 0 reads a half-tile one interval before row 1, so the counted wait moves one phase earlier: vmcnt(6) (three
+// half-tiles in flight). Refill distance (>= 2 phases after the last read of either row) is unchanged.
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm8h_f16_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) half_t ring[];  // [buf 2][A0 A1 B0 B1][128][64]
+  constexpr int HT = 128 * 64;
+  const int ntn = p.N / 256;
+  const int ntm = (p.M + 255) / 256;
+  int tm, tn;
+  if (!tile_map(blockIdx.x, ntm, ntn, p.map_mode, tm, tn)) return;
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = wv >> 2, wc = wv & 3;
+  const int lr = lane & 31, lg = lane >> 5;
+
+  // DMA sources as 32-bit element offsets from the (wave-uniform) operand bases: instruction j of a half-tile covers
+  // local rows j*64 + t/8 (8 lanes = one 128-byte row), LDS slot t%8 <- source chunk slot ^ ((row>>1)&7)
+  unsigned aoff[2][2], boff[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int lrow = j * 64 + (t >> 3);
+    const int chunk = (t & 7) ^ ((lrow >> 1) & 7);
+    const int arow = (lrow >> 6) * 128 + (lrow & 63);       // + h*64
+    const int brow = (lrow >> 5) * 64 + (lrow & 31);        // + h*32
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int am = m0 + arow + h * 64;
+      am = am < p.M ? am : p.M - 1;                          // ragged last row tile: re-read the last row
+      aoff[j][h] = (unsigned)am * (unsigned)p.lda + chunk * 8;
+    }
+    boff[j] = (unsigned)(n0 + brow) * (unsigned)p.ldw + chunk * 8;
+  }
+  const unsigned bh = 32u * (unsigned)p.ldw;
+  auto stage = [&](int which, int kt) {  // 0 A0, 1 A1, 2 B0, 3 B1
+    half_t* dst = ring + ((kt & 1) * 4 + which) * HT + wv * 512;
+    const int h = which & 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const half_t* g = which < 2 ? p.A + (aoff[j][h] + (unsigned)kt * 64u) : p.W + (boff[j] + h * bh + (unsigned)kt * 64u);
+      glds16(g, dst + j * 4096);
+    }
+  };
+
+  f32x16 acc[2][2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][i][b][r] = 0.f;
+
+  half8_t fa[2][4], fb0[4], fb1[4];
+  const int arow0 = wr * 64 + lr, brow0 = wc * 32 + lr;
+  const int nk = p.K / 64;
+
+#define RD_A(bufp, h)                                                                                             \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int s2 = 0; s2 < 4; ++s2)                   \
+      fa[i][s2] = *reinterpret_cast<const half8_t*>(&(bufp)[(h) * HT + lds_off64(arow0 + i * 32, s2 * 2 + lg)]);
+#define RD_B(dst, bufp, h)                                                                                        \
+  _Pragma("unroll") for (int s2 = 0; s2 < 4; ++s2)                                                                 \
+      dst[s2] = *reinterpret_cast<const half8_t*>(&(bufp)[(2 + (h)) * HT + lds_off64(brow0, s2 * 2 + lg)]);
+#define MMA_Q(a, b, fb)                                                                                           \
+  __builtin_amdgcn_s_setprio(1);                                                                                  \
+  _Pragma("unroll") for (int s2 = 0; s2 < 4; ++s2) _Pragma("unroll") for (int i = 0; i < 2; ++i)                   \
+      acc[a][i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[s2], fa[i][s2], acc[a][i][b], 0, 0, 0);           \
+  __builtin_amdgcn_s_setprio(0);
+#define LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0)
+#define END_INTERVAL(more)                                                                                        \
+  if (more) wait_vmcnt<6>(); else wait_vmcnt<0>();                                                                \
+  __builtin_amdgcn_sched_barrier(0);                                                                              \
+  __builtin_amdgcn_s_barrier();                                                                                   \
+  asm volatile("" ::: "memory");                                                                                  \
+  __builtin_amdgcn_sched_barrier(0)
+
+  stage(0, 0); stage(2, 0); stage(3, 0); stage(1, 0);
+  if (nk > 1) { stage(0, 1); stage(2, 1); wait_vmcnt<8>(); } else { wait_vmcnt<4>(); }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (wr == 0) {
+    RD_B(fb0, ring, 0)
+    RD_A(ring, 0)
+  }
+  if (nk > 1) wait_vmcnt<6>(); else wait_vmcnt<2>();
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+
+  auto main_loop = [&](auto role_c) {
+  constexpr int ROLE = decltype(role_c)::value;
+  for (int kt = 0; kt < nk; ++kt) {
+    const half_t* buf = ring + (kt & 1) * 4 * HT;
+    const half_t* nbuf = ring + ((kt + 1) & 1) * 4 * HT;
+    const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+    // ---- phase 1: quadrant (A0, B0); DMA B1(kt+1) ---------------------------------------------------------------
+    if (ROLE == 0) {
+      LGKM0();
+      MMA_Q(0, 0, fb0)
+      __builtin_amdgcn_sched_barrier(0);
+      RD_B(fb1, buf, 1)
+      if (more1) stage(3, kt + 1);
+    } else {
+      RD_B(fb0, buf, 0)
+      RD_A(buf, 0)
+      if (more1) stage(3, kt + 1);
+      LGKM0();
+      MMA_Q(0, 0, fb0)
+    }
+    END_INTERVAL(more2);
+    // ---- phase 2: quadrant (A0, B1); DMA A1(kt+1) ---------------------------------------------------------------
+    if (ROLE == 0) {
+      LGKM0();
+      MMA_Q(0, 1, fb1)
+      __builtin_amdgcn_sched_barrier(0);
+      RD_A(buf, 1)
+      if (more1) stage(1, kt + 1);
+    } else {
+      RD_B(fb1, buf, 1)
+      if (more1) stage(1, kt + 1);
+      LGKM0();
+      MMA_Q(0, 1, fb1)
+    }
+    END_INTERVAL(more2);
+    // ---- phase 3: quadrant (A1, B1); DMA A0(kt+2) ---------------------------------------------------------------
+    if (ROLE == 0) {
+      LGKM0();
+      MMA_Q(1, 1, fb1)
+      __builtin_amdgcn_sched_barrier(0);
+      if (more2) stage(0, kt + 2);
+    } else {
+      RD_A(buf, 1)
+      if (more2) stage(0, kt + 2);
+      LGKM0();
+      MMA_Q(1, 1, fb1)
+    }
+    END_INTERVAL(more2);
+    // ---- phase 4: quadrant (A1, B0); DMA B0(kt+2); row 0 reads (A0, B0) of K-tile kt+1 ---------------------------
+    if (ROLE == 0) {
+      MMA_Q(1, 0, fb0)
+      __builtin_amdgcn_sched_barrier(0);
+      if (more1) {
+        RD_B(fb0, nbuf, 0)
+        RD_A(nbuf, 0)
+      }
+      if (more2) stage(2, kt + 2);
+    } else {
+      if (more2) stage(2, kt + 2);
+      MMA_Q(1, 0, fb0)
+    }
+    END_INTERVAL(more2);
+  }
+  };
+  if (wr == 0) main_loop(std::integral_constant<int, 0>{}); else main_loop(std::integral_constant<int, 1>{});
+#undef RD_A
+#undef RD_B
+#undef MMA_Q
+#undef LGKM0
+#undef END_INTERVAL
+
+  float* slab = reinterpret_cast<float*>(ring) + wv * 4096;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+    store_slab_staged<EPI, false>(acc[a][0][0], acc[a][0][1], acc[a][1][0], acc[a][1][1], slab, m0 + wr * 128 + a * 64,
+                                  n0 + wc * 64, lane, p);
+}
+
+template <int EPI>
+static void launch8h(const GemmArgs& p, hipStream_t s) {
+  constexpr int LDS = 2 * 4 * 128 * 64 * 2;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm8h_f16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr = true;
+  }
+  const int ntm = (p.M + 255) / 256, ntn = p.N / 256;
+  hipLaunchKernelGGL((gemm8h_f16_kernel<EPI>), dim3(tile_map_grid(ntm, ntn, p.map_mode)), dim3(512), LDS, s, p);
+}
+
 template <int EPI>
 static void launch_ws(const GemmArgs& p, hipStream_t s) {
   constexpr int LDS = 4 * (384 + 128) * 32 * 2;
@@ -635,7 +1023,8 @@ static void launch256(const GemmArgs& p, hipStream_t s) {
                      C::LDS_BYTES, s, p);
 }
 
-// tile choice: 0 = auto, 1 = 128x128x64 double buffer, 2 = 256x128 / 3 = 256x256 staggered ring, 5 = 256x256 plain ring
+// tile choice: 0 = auto, 1 = 128x128x64 double buffer, 2 = 256x128 / 3 = 256x256 staggered ring, 5 = 256x256 plain ring,
+// 6 = wave-specialised 384x128, 7 = 256x256x64 8-phase
 // (PSAM_GEMM_TILE env var or psam_gemm_set_tile)
 static int g_tile_override = -1;
 extern "C" int psam_gemm_set_tile(int t) {
@@ -648,13 +1037,14 @@ static int pick_tile(int M, int N, int K) {
     g_tile_override = e ? atoi(e) : 0;
   }
   if (g_tile_override > 0) return g_tile_override;
-  // measured on MI355X (tools/gemm_ablate.py, within-run A/B): the 256x256 plain DMA-ring kernel (5) beats the 128x128
-  // double-buffered kernel (1) by 5-10 % once there are >= ~2.5 full rounds of 256-tiles and either N or K is large
-  // (qkv / lin1 at >= 4 batched slices, lin2 at 8); everywhere else (single slice, DINOv2's M = 1297*B, N = 1280 with
-  // K = 1280) the 128x128 kernel with two workgroups per CU wins. 3 = staggered two-phase variant of 5 (kept for A/B).
-  if (N % 256 == 0 && M % 256 == 0) {
-    const long t256 = (long)(M / 256) * (N / 256);
-    if (t256 >= 600 && (N >= 2560 || K >= 4096)) return 5;
+  // measured on MI355X (tools/gemm_tiles.py, within-run A/B): the 256x256 8-phase kernel (7) beats the 128x128
+  // double-buffered kernel (1) by 5-20 % whenever its 256-tiles fill the 256 CUs to >= 80 % in their last round (one
+  // workgroup per CU, so a part-filled round is lost time); otherwise the 128x128 kernel with two workgroups per CU
+  // wins. 5 = plain 4-deep ring, 3 = its two-phase staggered variant, 6 = wave-specialised loaders (kept for A/B).
+  if (N % 256 == 0) {
+    const long t256 = (long)((M + 255) / 256) * (N / 256);
+    const long rounds = (t256 + 255) / 256;
+    if (t256 * 10 >= rounds * 256 * 8 && K >= 1024) return 7;
   }
   return 1;
 }
@@ -686,6 +1076,7 @@ extern "C" int psam_gemm_f16(const void* A, const void* W, const float* bias, vo
   p.out_seg_stride = out_seg_stride;
   p.out_seg_off = out_seg_off;
   { const char* e = getenv("PSAM_GEMM_MAP"); p.map_mode = e ? atoi(e) : 0; }
+  { const char* e = getenv("PSAM_GEMM_DBG"); p.dbg = e ? atoi(e) : 0; }
   const int ntm = (M + BM - 1) / BM, ntn = N / BN;
   dim3 grid(tile_map_grid(ntm, ntn, p.map_mode)), block(256);
   hipStream_t s = (hipStream_t)stream;
@@ -700,6 +1091,19 @@ extern "C" int psam_gemm_f16(const void* A, const void* W, const float* bias, vo
       else if (epilogue == EPI_GELU_F16) launch256<EPI_GELU_F16, 256, 0>(p, s);
       else launch256<EPI_F32, 256, 0>(p, s);
     }
+    return psam_launch_status();
+  }
+  if (tsel == 8 && N % 256 == 0) {
+    if (epilogue == EPI_F16) launch8h<EPI_F16>(p, s);
+    else if (epilogue == EPI_GELU_F16) launch8h<EPI_GELU_F16>(p, s);
+    else launch8h<EPI_F32>(p, s);
+    return psam_launch_status();
+  }
+  if (tsel == 7 && N % 256 == 0) {
+    if (epilogue == EPI_F16 && p.dbg) launch8p<EPI_F16, true>(p, s);
+    else if (epilogue == EPI_F16) launch8p<EPI_F16>(p, s);
+    else if (epilogue == EPI_GELU_F16) launch8p<EPI_GELU_F16>(p, s);
+    else launch8p<EPI_F32>(p, s);
     return psam_launch_status();
   }
   if (tsel == 6) {
