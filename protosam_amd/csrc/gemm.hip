@@ -153,10 +153,8 @@ __device__ __forceinline__ void prefetch_resid(const GemmArgs& p, int mbase, int
   }
 }
 
-template <int EPI, bool PRE = false>
-__device__ __forceinline__ void store_slab_staged(const f32x16 (&a00), const f32x16 (&a01), const f32x16 (&a10),
-                                                  const f32x16 (&a11), float* __restrict__ slab, int mbase, int nbase,
-                                                  int lane, const GemmArgs& p, const float4* pre = nullptr) {
+__device__ __forceinline__ void slab_park(const f32x16 (&a00), const f32x16 (&a01), const f32x16 (&a10),
+                                          const f32x16 (&a11), float* __restrict__ slab, int lane) {
   const int lr = lane & 31, lg = lane >> 5;
   const f32x16* accs[2][2] = {{&a00, &a01}, {&a10, &a11}};
 #pragma unroll
@@ -171,6 +169,11 @@ __device__ __forceinline__ void store_slab_staged(const f32x16 (&a00), const f32
         *reinterpret_cast<float4*>(&slab[row * 64 + ((chunk ^ (row & 15)) << 2)]) =
             make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
       }
+}
+
+template <int EPI, bool PRE = false>
+__device__ __forceinline__ void slab_emit(const float* __restrict__ slab, int mbase, int nbase, int lane,
+                                          const GemmArgs& p, const float4* pre = nullptr) {
   // same-wave LDS traffic is ordered; the compiler inserts the lgkmcnt wait for the reads below
   const int c4 = lane & 15;
   const int n = nbase + c4 * 4;
@@ -203,6 +206,37 @@ __device__ __forceinline__ void store_slab_staged(const f32x16 (&a00), const f32
       }
       *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + orow * p.ldo + n) = v;
     }
+  }
+}
+
+template <int EPI, bool PRE = false>
+__device__ __forceinline__ void store_slab_staged(const f32x16 (&a00), const f32x16 (&a01), const f32x16 (&a10),
+                                                  const f32x16 (&a11), float* __restrict__ slab, int mbase, int nbase,
+                                                  int lane, const GemmArgs& p, const float4* pre = nullptr) {
+  slab_park(a00, a01, a10, a11, slab, lane);
+  slab_emit<EPI, PRE>(slab, mbase, nbase, lane, p, pre);
+}
+
+// 128-row x 64-column wave tile (two slabs) with the residual rows of BOTH slabs requested before anything waits on
+// them (16 float4 loads in flight per lane, issued ahead of the LDS parking). Without this the `x += ...` epilogues (proj,
+// lin2) ran 30-40 % below the fp16-output GEMMs of the same shape (profiles/r01_f: 528 / 712 vs 830 / 1010 TFLOP/s).
+template <int EPI>
+__device__ __forceinline__ void store_wave_tile_128x64(const f32x16 (&acc)[2][2][2], float* __restrict__ slab, int mbase,
+                                                       int nbase, int lane, const GemmArgs& p) {
+  if (EPI == EPI_F32 && p.resid != nullptr) {
+    float4 r0[16];
+    prefetch_resid(p, mbase, nbase, lane, r0);
+    slab_park(acc[0][0][0], acc[0][0][1], acc[0][1][0], acc[0][1][1], slab, lane);
+    slab_emit<EPI, true>(slab, mbase, nbase, lane, p, r0);
+    __builtin_amdgcn_sched_barrier(0);
+    prefetch_resid(p, mbase + 64, nbase, lane, r0);
+    slab_park(acc[1][0][0], acc[1][0][1], acc[1][1][0], acc[1][1][1], slab, lane);
+    slab_emit<EPI, true>(slab, mbase + 64, nbase, lane, p, r0);
+  } else {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+      store_slab_staged<EPI, false>(acc[a][0][0], acc[a][0][1], acc[a][1][0], acc[a][1][1], slab, mbase + a * 64, nbase,
+                                    lane, p);
   }
 }
 
@@ -789,10 +823,7 @@ __global__ __launch_bounds__(512) void gemm8p_f16_kernel(GemmArgs p) {
   // epilogue: every wave parks its two 64x64 slabs, one after the other, in its own 16 KiB of the (idle, fully landed,
   // no longer read) ring and re-reads them row-contiguously: each store instruction covers 4 rows x 128/256 bytes
   float* slab = reinterpret_cast<float*>(ring) + wv * 4096;
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-    store_slab_staged<EPI, false>(acc[a][0][0], acc[a][0][1], acc[a][1][0], acc[a][1][1], slab, m0 + wr * 128 + a * 64,
-                                  n0 + wc * 64, lane, p);
+  store_wave_tile_128x64<EPI>(acc, slab, m0 + wr * 128, n0 + wc * 64, lane, p);
 }
 
 template <int EPI, bool DBG = false>
@@ -979,10 +1010,7 @@ __global__ __launch_bounds__(512) void gemm8h_f16_kernel(GemmArgs p) {
 #undef END_INTERVAL
 
   float* slab = reinterpret_cast<float*>(ring) + wv * 4096;
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-    store_slab_staged<EPI, false>(acc[a][0][0], acc[a][0][1], acc[a][1][0], acc[a][1][1], slab, m0 + wr * 128 + a * 64,
-                                  n0 + wc * 64, lane, p);
+  store_wave_tile_128x64<EPI>(acc, slab, m0 + wr * 128, n0 + wc * 64, lane, p);
 }
 
 template <int EPI>
@@ -1031,7 +1059,7 @@ extern "C" int psam_gemm_set_tile(int t) {
   g_tile_override = t;
   return PSAM_OK;
 }
-static int pick_tile(int M, int N, int K) {
+static int pick_tile(int M, int N, int K, int epilogue) {
   if (g_tile_override < 0) {
     const char* e = getenv("PSAM_GEMM_TILE");
     g_tile_override = e ? atoi(e) : 0;
@@ -1044,7 +1072,8 @@ static int pick_tile(int M, int N, int K) {
   if (N % 256 == 0) {
     const long t256 = (long)((M + 255) / 256) * (N / 256);
     const long rounds = (t256 + 255) / 256;
-    if (t256 * 10 >= rounds * 256 * 8 && K >= 1024) return 7;
+    // the fp32 residual epilogue with a short K (proj: 20 K-tiles) is better served by two workgroups per CU
+    if (t256 * 10 >= rounds * 256 * 8 && K >= 1024 && !(epilogue == EPI_F32 && K < 2048)) return 7;
   }
   return 1;
 }
@@ -1080,7 +1109,7 @@ extern "C" int psam_gemm_f16(const void* A, const void* W, const float* bias, vo
   const int ntm = (M + BM - 1) / BM, ntn = N / BN;
   dim3 grid(tile_map_grid(ntm, ntn, p.map_mode)), block(256);
   hipStream_t s = (hipStream_t)stream;
-  const int tsel = pick_tile(M, N, K);
+  const int tsel = pick_tile(M, N, K, epilogue);
   if ((tsel == 3 || tsel == 5) && N % 256 == 0) {
     if (tsel == 3) {
       if (epilogue == EPI_F16) launch256<EPI_F16, 256, 1>(p, s);

@@ -22,16 +22,22 @@ shapes = sys.argv[2] if len(sys.argv) > 2 else "8192x8192x8192;4096x4096x4096;32
 for sh in shapes.split(";"):
     M, N, K = (int(v) for v in sh.split("x"))
     a = torch.randn(M, K, device=dev).half(); w = (torch.randn(N, K, device=dev) * 0.05).half()
-    out = torch.empty(M, N, device=dev, dtype=torch.float16)
+    f32 = len(sys.argv) > 3 and sys.argv[3] == "f32"     # the `x += gamma * (a @ w^T + b)` epilogue, in place
+    out = torch.empty(M, N, device=dev, dtype=torch.float32 if f32 else torch.float16)
+    bias = torch.randn(N, device=dev); gamma = torch.randn(N, device=dev)
     res = []
     for rep in range(2):
         for tl in tiles:
             if tl in (3, 5, 7) and N % 256:
                 continue
             ops.gemm_set_tile(tl)
-            t = timeit(lambda: ops.gemm(a, w, None, out=out, epilogue=ops.EPI_F16))
+            if f32:
+                t = timeit(lambda: ops.gemm(a, w, bias, out=out, epilogue=ops.EPI_F32, resid=out, gamma=gamma))
+            else:
+                t = timeit(lambda: ops.gemm(a, w, None, out=out, epilogue=ops.EPI_F16))
             res.append(f"t{tl}={2*M*N*K/t/1e12:6.0f}")
-        t = timeit(lambda: torch.matmul(a, w.t(), out=out))
+        o16 = out if not f32 else torch.empty(M, N, device=dev, dtype=torch.float16)
+        t = timeit(lambda: torch.matmul(a, w.t(), out=o16))
         res.append(f"blaslt={2*M*N*K/t/1e12:6.0f}")
     print(f"{sh:>18}: " + " ".join(res), flush=True)
 ops.gemm_set_tile(0)
