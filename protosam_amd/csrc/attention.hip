@@ -25,6 +25,7 @@
 // Rel-pos bias uses the UNSCALED q (image_encoder.py:242-245): rel_h/rel_w are produced by
 // psam_relpos from the same fp16 q and added in fp32 after the scale.
 #include "common.h"
+#include <type_traits>
 
 struct AttnArgs {
   const half_t* qkv;      // [B, N, 3, H, HD]
@@ -49,13 +50,19 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
   constexpr int DT = HD / 16;
   constexpr int CH = HD / 8;       // 16-byte chunks per row
   constexpr int KLD = HDP + 8;     // Ks row stride (halfs)
-  constexpr int VLD = KT + 8;      // Vt row stride (halfs)
-  constexpr int NKL = (KT * CH + NT - 1) / NT;        // K chunk loads per thread
-  constexpr int NVL = ((KT / 2) * CH + NT - 1) / NT;  // V chunk-pair loads per thread
+  // window mode keeps the WHOLE window (196 keys in 3 x 64 + 1 x 16 MFMA key tiles; K rows zero-padded to 200, V^T columns to 224; 78.7 KB -> two
+  // workgroups per CU) resident in LDS:
+  // one load phase with every request in flight at once and one barrier, instead of a load/store/2-barrier round per
+  // 64-key tile (measured before: 40 us per window-head for ~2 us of MFMA work - latency and rendezvous bound)
+  constexpr int KRES = MODE == 2 ? 200 : KT;          // key rows resident in Ks (masked rows of the last key tile clamp to 199)
+  constexpr int VCOL = MODE == 2 ? 224 : KT;          // key columns resident in Vt
+  constexpr int VLD = VCOL + 8;    // Vt row stride (halfs)
+  constexpr int NKL = (KRES * CH + NT - 1) / NT;        // K chunk loads per thread (per load phase)
+  constexpr int NVL = ((VCOL / 2) * CH + NT - 1) / NT;  // V chunk-pair loads per thread
   const float LOG2E = 1.4426950408889634f;
   const float RESCALE_THR = 8.0f;  // log2 units
 
-  __shared__ __attribute__((aligned(16))) half_t Ks[KT * KLD];
+  __shared__ __attribute__((aligned(16))) half_t Ks[KRES * KLD];
   __shared__ __attribute__((aligned(16))) half_t Vt[HD * VLD];
   __shared__ unsigned short klut[MODE == 2 ? 256 : 1];  // window key index -> kh | (kw << 8)
   constexpr int RWLD = 68;                               // padded row (floats) of the rel_w stage
@@ -152,7 +159,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
   // zero the K pad columns once (they are never overwritten)
   if (HDP > HD) {
     constexpr int PC = (HDP - HD) / 8;
-    for (int idx = t; idx < KT * PC; idx += NT) {
+    for (int idx = t; idx < KRES * PC; idx += NT) {
       int key = idx / PC, c = idx % PC;
       *reinterpret_cast<uint4*>(&Ks[key * KLD + HD + c * 8]) = make_uint4(0, 0, 0, 0);
     }
@@ -178,7 +185,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
     for (int i = 0; i < NKL; ++i) {
       int idx = t + i * NT;
       kreg[i] = make_uint4(0, 0, 0, 0);
-      if (idx < KT * CH) {
+      if (idx < KRES * CH) {
         int key = idx / CH, c = idx % CH;
         const half_t* src = key_src(tile * KT + key, 1);
         if (src) kreg[i] = *reinterpret_cast<const uint4*>(src + c * 8);
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
       int idx = t + i * NT;
       vreg[i][0] = make_uint4(0, 0, 0, 0);
       vreg[i][1] = make_uint4(0, 0, 0, 0);
-      if (idx < (KT / 2) * CH) {
+      if (idx < (VCOL / 2) * CH) {
         int kp = idx / CH, c = idx % CH;
         const half_t* s0 = key_src(tile * KT + 2 * kp, 2);
         const half_t* s1 = key_src(tile * KT + 2 * kp + 1, 2);
@@ -203,7 +210,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
 #pragma unroll
     for (int i = 0; i < NKL; ++i) {
       int idx = t + i * NT;
-      if (idx < KT * CH) {
+      if (idx < KRES * CH) {
         int key = idx / CH, c = idx % CH;
         *reinterpret_cast<uint4*>(&Ks[key * KLD + c * 8]) = kreg[i];
       }
@@ -211,7 +218,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
 #pragma unroll
     for (int i = 0; i < NVL; ++i) {
       int idx = t + i * NT;
-      if (idx < (KT / 2) * CH) {
+      if (idx < (VCOL / 2) * CH) {
         int kp = idx / CH, c = idx % CH;
         const uint32_t a[4] = {vreg[i][0].x, vreg[i][0].y, vreg[i][0].z, vreg[i][0].w};
         const uint32_t bb[4] = {vreg[i][1].x, vreg[i][1].y, vreg[i][1].z, vreg[i][1].w};
@@ -244,9 +251,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
   store_tile();
   __syncthreads();
 
-  for (int tile = 0; tile < ntiles; ++tile) {
-    if (tile + 1 < ntiles) load_tile(tile + 1);
-
+  // one 64-key tile (NTT = 4 MFMA key tiles) or, for the window's last 4 keys, a single 16-key tile (NTT = 1);
+  // `koff` = first resident key row / V^T column of the tile
+  auto compute_tile = [&](auto ntt_c, int tile, int koff) {
+    constexpr int NTT = decltype(ntt_c)::value;
     // S^T = K Q^T
     f32x4 st[4][2];
 #pragma unroll
@@ -256,11 +264,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) st[tt][qt][r] = 0.f;
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
+    for (int tt = 0; tt < NTT; ++tt) {
       const int krow = (tt >> 1) * 32 + (li >> 2) * 8 + (tt & 1) * 4 + (li & 3);
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        half8_t kf = *reinterpret_cast<const half8_t*>(&Ks[krow * KLD + s * 32 + g * 8]);
+        const int kr = (MODE == 2 && NTT < 4) ? min(koff + krow, KRES - 1) : koff + krow;  // clamped rows are masked keys
+        half8_t kf = *reinterpret_cast<const half8_t*>(&Ks[kr * KLD + s * 32 + g * 8]);
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
           st[tt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qt][s], st[tt][qt], 0, 0, 0);
@@ -285,6 +294,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
 
     // scale + bias + mask, online softmax (base-2 domain: scale and bias are pre-multiplied by log2(e))
     half8_t pf[2][2];
+    if (NTT < 4) {
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pf[qt][s2][e] = (half_t)0.f;
+    }
     const bool last_partial = (tile == ntiles - 1) && (nkeys % KT != 0);  // wave-uniform
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
@@ -293,7 +310,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
       if (MODE == 1) bh2 = relh_q[qt][tile] * LOG2E;
       float mx = -INFINITY;
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
+      for (int tt = 0; tt < NTT; ++tt) {
         float4 rw4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (MODE == 1)
           rw4 = *reinterpret_cast<const float4*>(
@@ -330,7 +347,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
       const float moff = mref - bh2;  // exp2(sv + bh2 - mref)
       float ps = 0.f;
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
+      for (int tt = 0; tt < NTT; ++tt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float pv = __builtin_amdgcn_exp2f(st[tt][qt][r] - moff);
@@ -345,18 +362,28 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
 #pragma unroll
     for (int d = 0; d < DT; ++d) {
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        half8_t vf = *reinterpret_cast<const half8_t*>(&Vt[(d * 16 + li) * VLD + s2 * 32 + g * 8]);
+      for (int s2 = 0; s2 < (NTT + 1) / 2; ++s2) {
+        half8_t vf = *reinterpret_cast<const half8_t*>(&Vt[(d * 16 + li) * VLD + koff + s2 * 32 + g * 8]);
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
           ot[d][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qt][s2], ot[d][qt], 0, 0, 0);
       }
     }
+  };
 
-    __syncthreads();  // everyone done reading Ks/Vt
-    if (tile + 1 < ntiles) {
-      store_tile();
-      __syncthreads();
+  if (MODE == 2) {
+    // the whole window is resident: no further loads, no barriers; each wave walks the key tiles on its own
+    for (int tile = 0; tile + 1 < ntiles; ++tile) compute_tile(std::integral_constant<int, 4>{}, tile, tile * KT);
+    compute_tile(std::integral_constant<int, 1>{}, ntiles - 1, (ntiles - 1) * KT);
+  } else {
+    for (int tile = 0; tile < ntiles; ++tile) {
+      if (tile + 1 < ntiles) load_tile(tile + 1);
+      compute_tile(std::integral_constant<int, 4>{}, tile, 0);
+      __syncthreads();  // everyone done reading Ks/Vt
+      if (tile + 1 < ntiles) {
+        store_tile();
+        __syncthreads();
+      }
     }
   }
 
@@ -423,7 +450,8 @@ extern "C" int psam_attention_f16(const void* qkv, void* out, const float* rel_h
     if (gw != KT || gh * gw != N || !rel_h || !rel_w) return PSAM_ERR_ARG;
   }
   if (mode == 2) {
-    if (ws <= 0 || ws > 16 || gh * gw != N || !relq || !pad_row) return PSAM_ERR_ARG;
+    // the resident-window schedule is laid out for 14 x 14 = 3 x 64 + 4 keys (SAM's window_size, build_sam.py:73)
+    if (ws != 14 || gh * gw != N || !relq || !pad_row) return PSAM_ERR_ARG;
     p.nwx = (gw + ws - 1) / ws;
     p.nwin = p.nwx * ((gh + ws - 1) / ws);
   }
