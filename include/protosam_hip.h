@@ -148,6 +148,11 @@ int psam_mask_stats(const float* low, int B, int C, int first, int nsel, int IN,
 int psam_mask_binarize(const float* low, const int* idx, int n, int IN, int MID, int H, int W, int variant, float thr,
                        unsigned char* out, const unsigned char* label, long long* counts, void* stream);
 
+/* PromptEncoder.mask_downscaling for mask prompts: masks fp32 [n,4g,4g] -> dense embeddings fp32 token-major [n,g*g,256].
+ * wts = c1w[4][4] c1b[4] n1w[4] n1b[4] c2w[16][4][2][2] c2b[16] n2w[16] n2b[16] c3w[256][16] c3b[256] (4684 floats).
+ * prompt_encoder.py:51-59,102-105; common.py:31-43 (LayerNorm2d) */
+int psam_mask_downscale(const float* masks, const float* wts, int n, int g, float eps, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

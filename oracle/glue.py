@@ -157,9 +157,25 @@ def sam_preprocess(img_u8_hwc):
     return (x - mean) / std
 
 
+def mask_prompts(cc):
+    """ProtoSAM.get_sam_input_mask (:452-466) + the per-mask preparation of predict_w_masks (:471-479):
+    cv2.resize(mask, (256, 256), INTER_NEAREST) samples source pixel floor(dst * 4) (cv2 is absent: restated), then
+    10 / -8 are written into the float array and the array is cast with `.astype(np.uint8)`."""
+    out = []
+    for cc_id in np.unique(cc[1]):
+        if cc_id == 0:
+            continue
+        m = (cc[1] == cc_id).astype(np.float32)[::4, ::4].copy()
+        m[m == 1] = 10
+        m[m == 0] = -8
+        with np.errstate(invalid="ignore"):
+            out.append(m[None, ...].astype(np.uint8))
+    return out
+
+
 def protosam_forward(query_image, output_logits, sam_sd, sam_type="vit_b", use_bbox=True, use_points=True,
                      point_mode="both", use_cca=False, postprocess="upstream", encoder_depth=None, taps=None,
-                     features=None):
+                     features=None, use_mask=False):
     """ProtoSAM.forward (models/ProtoSAM.py:536-678) after the coarse model: `output_logits` [1,2,H,W] is what
     `self.coarse_segmentation_model(input)` returned. Returns (pred [H,W] float {0,1}, scores list)."""
     original_size = query_image.shape[-2]
@@ -184,6 +200,17 @@ def protosam_forward(query_image, output_logits, sam_sd, sam_type="vit_b", use_b
     if taps is not None:
         taps.update(bboxes=bboxes, points=points, img_u8=img_u8, features=features, low_res=[], masks=[])
     masks, scores = [], []
+    if use_mask and not (use_points or use_bbox):                                          # :468-498, 664-665
+        for in_mask in mask_prompts(cc):
+            m, sc, low = odec.predict(sam_sd, features, None, None, None, multimask_output=True,
+                                      original_size=(1024, 1024), variant=postprocess, mask_input=in_mask)
+            k = int(sc.argmax())
+            masks.append(m[k].numpy())
+            scores.append(sc[k].item())
+            if taps is not None:
+                taps["low_res"].append(low)
+                taps["masks"].append(m[k].numpy())
+        points, bboxes = [], []
     for point, box in zip(points, bboxes):                                                 # :505-527
         labels = np.array([1] * len(point)) if point is not None else None
         m, s, low = odec.predict(sam_sd, features, point, labels, box, multimask_output=not use_cca,

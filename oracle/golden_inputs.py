@@ -67,3 +67,12 @@ def amg_case():
     q = q_img[0].permute(1, 2, 0).numpy()
     img = ((q - q.min()) / (q.max() - q.min()) * 255).astype("uint8")
     return img, q_gt[0].numpy().astype("uint8")
+
+
+def mask_prompt_case():
+    """[2,1,256,256] float masks with the values ProtoSAM.predict_w_masks produces (10 inside, uint8(-8) = 248 outside)."""
+    m = torch.full((2, 1, 256, 256), 248.0)
+    m[0, 0, 60:140, 90:200] = 10.0
+    yy, xx = torch.meshgrid(torch.arange(256.0), torch.arange(256.0), indexing="ij")
+    m[1, 0][((yy - 150) / 40) ** 2 + ((xx - 100) / 70) ** 2 <= 1] = 10.0
+    return m

@@ -44,11 +44,29 @@ def embed_with_coords(coords, G):
     return pe_encoding(c, G)
 
 
-def prompt_encoder(sd, points=None, boxes=None, pre="prompt_encoder."):
-    """points = (coords [B,N,2], labels [B,N]) or None; boxes [B,4] or None; masks unsupported here.
+def _ln2d(x, w, b, eps=1e-6):
+    """common.py:31-43 (LayerNorm2d over the channel dim of NCHW)."""
+    u = x.mean(1, keepdim=True)
+    s = (x - u).pow(2).mean(1, keepdim=True)
+    return w[:, None, None] * ((x - u) / torch.sqrt(s + eps)) + b[:, None, None]
+
+
+def embed_masks(sd, masks, pre="prompt_encoder."):
+    """prompt_encoder.py:51-59,102-105: masks [B,1,256,256] -> [B,256,64,64]."""
+    m = pre + "mask_downscaling."
+    x = F.conv2d(masks.float(), sd[m + "0.weight"], sd[m + "0.bias"], stride=2)
+    x = F.gelu(_ln2d(x, sd[m + "1.weight"], sd[m + "1.bias"]))
+    x = F.conv2d(x, sd[m + "3.weight"], sd[m + "3.bias"], stride=2)
+    x = F.gelu(_ln2d(x, sd[m + "4.weight"], sd[m + "4.bias"]))
+    return F.conv2d(x, sd[m + "6.weight"], sd[m + "6.bias"])
+
+
+def prompt_encoder(sd, points=None, boxes=None, pre="prompt_encoder.", masks=None):
+    """points = (coords [B,N,2], labels [B,N]) or None; boxes [B,4] or None; masks [B,1,256,256] or None.
     Returns sparse [B,Ns,256], dense [B,256,64,64]."""
     G = sd[pre + "pe_layer.positional_encoding_gaussian_matrix"]
-    bs = points[0].shape[0] if points is not None else (boxes.shape[0] if boxes is not None else 1)
+    bs = points[0].shape[0] if points is not None else (boxes.shape[0] if boxes is not None else
+                                                        (masks.shape[0] if masks is not None else 1))
     sparse = torch.empty((bs, 0, EMBED))
     if points is not None:
         coords, labels = points
@@ -68,7 +86,10 @@ def prompt_encoder(sd, points=None, boxes=None, pre="prompt_encoder."):
         ce[:, 0, :] += sd[pre + "point_embeddings.2.weight"]
         ce[:, 1, :] += sd[pre + "point_embeddings.3.weight"]
         sparse = torch.cat([sparse, ce], dim=1)
-    dense = sd[pre + "no_mask_embed.weight"].reshape(1, -1, 1, 1).expand(bs, -1, GRID, GRID)
+    if masks is not None:
+        dense = embed_masks(sd, masks, pre)
+    else:
+        dense = sd[pre + "no_mask_embed.weight"].reshape(1, -1, 1, 1).expand(bs, -1, GRID, GRID)
     return sparse, dense
 
 
@@ -186,7 +207,8 @@ def apply_coords(coords, original_size, target=IMG):
     return c
 
 
-def predict(sd, features, point_coords, point_labels, box, multimask_output, original_size, variant="upstream"):
+def predict(sd, features, point_coords, point_labels, box, multimask_output, original_size, variant="upstream",
+            mask_input=None):
     """predictor.py:92-241 for one prompt set. Returns (masks bool [C,H,W], iou [C], low_res [C,256,256])."""
     pts = None
     if point_coords is not None:
@@ -197,7 +219,10 @@ def predict(sd, features, point_coords, point_labels, box, multimask_output, ori
     if box is not None:
         bx = torch.as_tensor(apply_coords(np.asarray(box).reshape(-1, 2, 2), original_size).reshape(-1, 4),
                              dtype=torch.float)
-    sparse, dense = prompt_encoder(sd, pts, bx)
+    mk = None
+    if mask_input is not None:                                                   # predictor.py:158-160
+        mk = torch.as_tensor(mask_input, dtype=torch.float)[None, :, :, :]
+    sparse, dense = prompt_encoder(sd, pts, bx, masks=mk)
     low, iou = mask_decoder(sd, features, dense_pe(sd), sparse, dense, multimask_output)
     masks = postprocess_masks(low, (IMG, IMG), original_size, variant)
     return (masks > 0.0)[0], iou[0], low[0]

@@ -219,6 +219,20 @@ def check_sam_decoder(gold):
                     gold[f"dec_{name}_low_res"] = low_r.numpy().astype(np.float32)
                     gold[f"dec_{name}_iou"] = iou_r.numpy().astype(np.float32)
         low = low_r
+        # mask prompts (prompt_encoder.py:102-105,163-164): two blob masks with the 10 / 248 values ProtoSAM hands over
+        mk = gi.mask_prompt_case()
+        sp_r, de_r = sam.prompt_encoder(points=None, boxes=None, masks=mk)
+        sp_o, de_o = odec.prompt_encoder(sd, None, None, masks=mk)
+        assert sp_r.shape == sp_o.shape == (2, 0, 256)
+        close(de_o, de_r, 1e-4, "mask prompt: dense embeddings (values up to ~1e2)")
+        lm_r, im_r = sam.mask_decoder(image_embeddings=feats, image_pe=pe_ref, sparse_prompt_embeddings=sp_r,
+                                      dense_prompt_embeddings=de_r, multimask_output=True)
+        lm_o, im_o = odec.mask_decoder(sd, feats, odec.dense_pe(sd), sp_o, de_o, True)
+        close(lm_o, lm_r, 5e-4, "mask prompt: low_res_masks")
+        close(im_o, im_r, 5e-5, "mask prompt: iou_predictions")
+        gold["dec_mask_dense"] = de_r[:, :, ::8, ::8].numpy().astype(np.float32)
+        gold["dec_mask_low_res"] = lm_r.numpy().astype(np.float32)
+        gold["dec_mask_iou"] = im_r.numpy().astype(np.float32)
         r_b = sam.postprocess_masks(low, (1024, 1024), (1024, 1024))           # SamBatched: align_corners=True
         close(odec.postprocess_masks(low, (1024, 1024), (1024, 1024), "batched"), r_b, 1e-5, "postprocess SamBatched")
         r_n = Sam.postprocess_masks(sam, low, (1024, 1024), (512, 512))        # vendored Sam: nearest

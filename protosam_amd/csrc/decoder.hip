@@ -689,3 +689,94 @@ extern "C" int psam_mask_binarize(const float* low, const int* idx, int n, int I
                      idx, IN, MID, H, W, variant, thr, out, label, (unsigned long long*)counts);
   return psam_launch_status();
 }
+
+// ---- mask prompts: PromptEncoder.mask_downscaling (prompt_encoder.py:51-59,102-105) as one kernel -----------------------
+// Conv2d(1->4, k2 s2) -> LayerNorm2d(4) -> GELU -> Conv2d(4->16, k2 s2) -> LayerNorm2d(16) -> GELU -> Conv2d(16->256, k1)
+// on masks fp32 [n, 4g, 4g] -> token-major dense embeddings fp32 [n, g*g, 256]. One workgroup = 16 tokens x 256 output
+// channels; the two small stages (a 4x4 input patch per token) are computed by 16 lanes per token into LDS.
+// packed weights (floats): c1w[4][4] c1b[4] n1w[4] n1b[4] c2w[16][4][2][2] c2b[16] n2w[16] n2b[16] c3w[256][16] c3b[256]
+#define MD_C1W 0
+#define MD_C1B 16
+#define MD_N1W 20
+#define MD_N1B 24
+#define MD_C2W 28
+#define MD_C2B (28 + 256)
+#define MD_N2W (MD_C2B + 16)
+#define MD_N2B (MD_N2W + 16)
+#define MD_C3W (MD_N2B + 16)
+#define MD_C3B (MD_C3W + 4096)
+#define MD_TOTAL (MD_C3B + 256)
+__global__ __launch_bounds__(256) void mask_downscale_kernel(const float* __restrict__ masks, const float* __restrict__ wts,
+                                                             int g, float eps, float* __restrict__ out) {
+  __shared__ float w[MD_C3W];       // everything but the 1x1 conv
+  __shared__ float h1[16][4][4];    // [token][c1][py*2+px] after LN + GELU
+  __shared__ float h2[16][16];      // [token][c2] after LN + GELU
+  const int t = threadIdx.x, n = blockIdx.y;
+  const int tok0 = blockIdx.x * 16;
+  for (int i = t; i < MD_C3W; i += 256) w[i] = wts[i];
+  __syncthreads();
+  const int S = 4 * g;
+  const float* m = masks + (size_t)n * S * S;
+  {  // stage 1: thread (token tl = t/16, position pp = (t%16)/4 ... ) -> 64 (token, position) pairs, 4 channels each
+    const int tl = t >> 4, sub = t & 15;
+    if (sub < 4) {
+      const int tok = tok0 + tl, ty = tok / g, tx = tok % g;
+      const int py = sub >> 1, px = sub & 1;
+      const float* ip = m + (size_t)(4 * ty + 2 * py) * S + 4 * tx + 2 * px;
+      const float i00 = ip[0], i01 = ip[1], i10 = ip[S], i11 = ip[S + 1];
+      float c[4], mu = 0.f;
+#pragma unroll
+      for (int c1 = 0; c1 < 4; ++c1) {
+        c[c1] = w[MD_C1B + c1] + w[MD_C1W + c1 * 4 + 0] * i00 + w[MD_C1W + c1 * 4 + 1] * i01 +
+                w[MD_C1W + c1 * 4 + 2] * i10 + w[MD_C1W + c1 * 4 + 3] * i11;
+        mu += c[c1];
+      }
+      mu *= 0.25f;
+      float var = 0.f;
+#pragma unroll
+      for (int c1 = 0; c1 < 4; ++c1) var += (c[c1] - mu) * (c[c1] - mu);
+      const float inv = 1.0f / sqrtf(var * 0.25f + eps);
+#pragma unroll
+      for (int c1 = 0; c1 < 4; ++c1) {
+        const float v = w[MD_N1W + c1] * ((c[c1] - mu) * inv) + w[MD_N1B + c1];
+        h1[tl][c1][sub] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+      }
+    }
+  }
+  __syncthreads();
+  {  // stage 2: thread (token t/16, channel c2 = t%16); LayerNorm over the 16 channels = the 16 lanes of the group
+    const int tl = t >> 4, c2 = t & 15;
+    float v = w[MD_C2B + c2];
+#pragma unroll
+    for (int c1 = 0; c1 < 4; ++c1)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v += w[MD_C2W + (c2 * 4 + c1) * 4 + q] * h1[tl][c1][q];
+    float mu = v;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) mu += __shfl_xor(mu, o, 64);
+    mu *= (1.0f / 16.0f);
+    float var = (v - mu) * (v - mu);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) var += __shfl_xor(var, o, 64);
+    const float inv = 1.0f / sqrtf(var * (1.0f / 16.0f) + eps);
+    const float y = w[MD_N2W + c2] * ((v - mu) * inv) + w[MD_N2B + c2];
+    h2[tl][c2] = 0.5f * y * (1.0f + erff(y * 0.70710678118654752440f));
+  }
+  __syncthreads();
+  // stage 3: thread = output channel, all 16 tokens
+  float w3[16];
+#pragma unroll
+  for (int c2 = 0; c2 < 16; ++c2) w3[c2] = wts[MD_C3W + t * 16 + c2];
+  const float b3 = wts[MD_C3B + t];
+  for (int tl = 0; tl < 16; ++tl) {
+    float v = b3;
+#pragma unroll
+    for (int c2 = 0; c2 < 16; ++c2) v += w3[c2] * h2[tl][c2];
+    out[((size_t)n * g * g + tok0 + tl) * 256 + t] = v;
+  }
+}
+extern "C" int psam_mask_downscale(const float* masks, const float* wts, int n, int g, float eps, float* out, void* stream) {
+  if (n <= 0 || g <= 0 || (g * g) % 16 != 0) return PSAM_ERR_ARG;
+  hipLaunchKernelGGL(mask_downscale_kernel, dim3(g * g / 16, n), dim3(256), 0, (hipStream_t)stream, masks, wts, g, eps, out);
+  return psam_launch_status();
+}

@@ -392,6 +392,18 @@ def mask_union(low, sel, MID, OUT, variant, thr=0.0, pred=None):
     return pred
 
 
+def mask_downscale(masks, wts, g, eps=1e-6, out=None):
+    """PromptEncoder.mask_downscaling: masks fp32 [n,4g,4g] -> dense embeddings fp32 [n, g*g, 256] (token-major)."""
+    _req(masks, torch.float32, "masks"); _req(wts, torch.float32, "wts")
+    assert masks.is_contiguous() and masks.shape[-1] == 4 * g and masks.shape[-2] == 4 * g and wts.numel() == 4684
+    n = masks.numel() // (16 * g * g)
+    if out is None:
+        out = torch.empty((n, g * g, 256), dtype=torch.float32, device=masks.device)
+    st = _lib.lib().psam_mask_downscale(_ptr(masks), _ptr(wts), n, g, float(eps), _ptr(out), _stream())
+    _lib.check(st, "psam_mask_downscale")
+    return out
+
+
 def mask_stats(low, first, nsel, MID, H, W, variant, thr=0.0, off=1.0, stats=None):
     """int32 [B*nsel, 8] = {n(v>thr+off), n(v>thr-off), n(v>thr), min_x, min_y, max_x, max_y, 0} per selected plane of
     low [B,C,IN,IN] over the [H,W] corner of its MID x MID up-sampling."""

@@ -15,7 +15,11 @@ component -> numpy -> tensor; ProtoSAM.py:602-676). Here every stage stays on th
   for the table, so the wait overlaps the encoder)  --> prompt tokens --> batched two-way decoder over all components
   --> fused upsample / threshold / union / nearest-resize --> pred.
 
-Unsupported (outside SURVEY §8's hot path, raise NotImplementedError): `use_mask=True` (mask prompts), `use_neg_points`,
+Mask prompts (`use_mask=True` with points and boxes off, ProtoSAM.py:468-498,664-665): each component's mask, nearest-
+sampled to 256x256, goes through `psam_mask_downscale` and the decoder without sparse prompts; the best-scoring of the
+three masks is kept per component. With points or boxes on, the reference overwrites the mask-prompt result (:667-668),
+so `use_mask` then changes nothing and its work is skipped.
+Unsupported (outside SURVEY §8's hot path, raise NotImplementedError): `use_neg_points`,
 `degrees_rotate != 0`, `debug` plotting, training mode.
 """
 import os
@@ -210,8 +214,13 @@ class ProtoSAM(nn.Module):
             raise ValueError(f"point mode must be one of {POINT_MODES}")
         self.debug = debug
         self.coarse_pred_only = coarse_pred_only
-        if use_mask or use_neg_points or debug or num_points_for_sam != 1:
-            raise NotImplementedError("use_mask / use_neg_points / debug / num_points_for_sam != 1 are outside the hot path")
+        if use_neg_points or debug or num_points_for_sam != 1:
+            raise NotImplementedError("use_neg_points / debug / num_points_for_sam != 1 are outside the hot path")
+        self._mask_only = self.use_mask and not (self.use_points or self.use_bbox)
+        # predict_w_masks writes 10 / -8 into a float array and hands it over `.astype(np.uint8)` (ProtoSAM.py:473-479):
+        # whatever this platform's numpy makes of -8.0 (248 on x86-64) is what SAM sees
+        with np.errstate(invalid="ignore"):
+            self._mask_vals = tuple(float(v) for v in np.array([10.0, -8.0], dtype=np.float32).astype(np.uint8))
         if tuple(self.image_size) != (1024, 1024):
             raise NotImplementedError("image_size must be (1024, 1024) as in validation_protosam.py:220")
         self._ccl = None
@@ -323,6 +332,9 @@ class ProtoSAM(nn.Module):
         cw = self._ccl
         for b in range(B):
             ops.ccl(pred[b], output_p[b, 1], cw, fg_sum=bufs["fg_sum"][b:b + 1], slot=b)
+            if self._mask_only:   # cv2.resize(mask, (256, 256), INTER_NEAREST) samples pixel (4y, 4x); labels are scratch
+                bufs.setdefault("lab256", torch.empty((B, S // 4, S // 4), dtype=torch.int32, device=dev))[b].copy_(
+                    cw.labels.view(S, S)[::4, ::4])
         cw.tabs_host[:B].copy_(cw.tabs[:B], non_blocking=True)
         bufs["event"].record()
         # 3. image hand-off: resize -> min/max -> uint8 quantise -> SAM normalise -> im2col      ProtoSAM.py:592-593,651-660
@@ -347,6 +359,14 @@ class ProtoSAM(nn.Module):
             if n == 0:                                                          # ProtoSAM.py:612-613
                 results[b] = (output_p[b].argmax(dim=0), [0])
                 continue
+            if self._mask_only:
+                # component k of the table carries label k + 1 (csrc/ccl.hip); cca keeps the most confident one
+                ids = [int(tab[3]) + 1] if self.use_cca else list(range(1, n + 1))
+                spans.append((b, len(img_idx), len(ids)))
+                labels += ids
+                img_idx += [b] * len(ids)
+                stats[b].update(n_prompts=len(ids))
+                continue
             c, l, rows = self._prompts_from_table(tab)
             spans.append((b, len(img_idx), len(l)))
             coords.append(c)
@@ -354,7 +374,30 @@ class ProtoSAM(nn.Module):
             img_idx += [b] * len(l)
             stats[b].update(n_prompts=len(l), table=rows)
         self.last_stats = stats[0] if B == 1 else dict(per_slice=stats)
-        if spans:
+        if spans and self._mask_only:
+            # 6m. mask prompts: dense embedding per component, no sparse prompts, best of the three masks
+            #     (get_sam_input_mask :452-466, predict_w_masks :468-498)
+            P = len(labels)
+            pe = sam.prompt_encoder._packed()
+            dpk = sam.mask_decoder._packed()
+            iop = torch.tensor(img_idx, dtype=torch.int64).to(dev, non_blocking=True)
+            ids = torch.tensor(labels, dtype=torch.int32).to(dev, non_blocking=True)
+            fg, bg = self._mask_vals
+            prompt = torch.where(bufs["lab256"][iop] == ids[:, None, None], fg, bg).to(torch.float32)
+            dense = sam.prompt_encoder.embed_masks_tokens(prompt[:, None])               # [P, 4096, 256]
+            src = (feat_tok[iop] + dense).contiguous()                                    # mask_decoder.py:126-127
+            tokens = dpk["out_tok"].unsqueeze(0).expand(P, -1, -1).contiguous()
+            masks, iou, _ = sam.mask_decoder.predict_masks_tokens(
+                src, pe["pe_tok"], tokens, torch.zeros(256, dtype=torch.float32, device=dev),
+                img_of_prompt=torch.arange(P, dtype=torch.int32, device=dev))
+            best = iou[:, 1:].argmax(dim=1)                                               # score.argmax(), :494
+            chosen = masks[torch.arange(P, device=dev), best + 1].unsqueeze(1).contiguous()   # [P,1,256,256]
+            iou_host = iou[:, 1:].max(dim=1).values.cpu().numpy()
+            for (b, start, cnt) in spans:
+                out = ops.mask_union(chosen[start:start + cnt], 0, S, original_size, sam.variant_id(), sam.mask_threshold)
+                results[b] = (out, [np.float32(v) for v in iou_host[start:start + cnt]])
+            self.last_stats.update(low_res=masks, iou=iou, best=best, spans=spans)
+        elif spans:
             coords = np.concatenate(coords, 0)
             labels = np.concatenate(labels, 0)
             P, Ns = labels.shape

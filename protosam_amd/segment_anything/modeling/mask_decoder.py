@@ -194,11 +194,18 @@ class MaskDecoder(nn.Module):
         if image_embeddings.shape[0] != 1:
             raise NotImplementedError("one image per call (the predictor's usage, predictor.py:229-235)")
         d = dense_prompt_embeddings
-        if not all(d.stride(i) == 0 or d.shape[i] == 1 for i in (0, 2, 3)):
-            raise NotImplementedError("dense prompts other than the broadcast no-mask embedding (mask prompts)")
         feat = image_embeddings[0].permute(1, 2, 0).reshape(-1, 256).float().contiguous()
         pe = image_pe[0].permute(1, 2, 0).reshape(-1, 256).float().contiguous()
         tokens = self.build_tokens(sparse_prompt_embeddings)
-        masks, iou, _ = self.predict_masks_tokens(feat, pe, tokens, d[0, :, 0, 0].float().contiguous())
+        if all(d.stride(i) == 0 or d.shape[i] == 1 for i in (0, 2, 3)):   # the broadcast no-mask embedding
+            masks, iou, _ = self.predict_masks_tokens(feat, pe, tokens, d[0, :, 0, 0].float().contiguous())
+        else:                                                             # mask prompts: one dense map per prompt set
+            B = tokens.shape[0]
+            if d.shape[0] != B:
+                raise ValueError("dense prompt embeddings must have one map per prompt set")
+            src = feat.unsqueeze(0) + d.permute(0, 2, 3, 1).reshape(B, -1, 256).float()   # mask_decoder.py:126-127
+            masks, iou, _ = self.predict_masks_tokens(src.contiguous(), pe, tokens,
+                                                      torch.zeros(256, dtype=torch.float32, device=feat.device),
+                                                      img_of_prompt=torch.arange(B, dtype=torch.int32, device=feat.device))
         sl = slice(1, None) if multimask_output else slice(0, 1)
         return masks[:, sl], iou[:, sl]

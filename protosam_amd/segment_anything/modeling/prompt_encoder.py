@@ -1,8 +1,8 @@
 """SAM prompt encoder (names of models/segment_anything/modeling/prompt_encoder.py:16-214).
 
 Points / boxes -> sparse tokens and the dense positional grid are produced by csrc/decoder.hip
-(`psam_prompt_tokens`, `psam_dense_pe`). Mask prompts (`mask_downscaling`, :51-59,102-105) keep their parameters for
-strict checkpoint loading but are outside the current hot-path scope.
+(`psam_prompt_tokens`, `psam_dense_pe`); mask prompts (`mask_downscaling`, :51-59,102-105) by `psam_mask_downscale`
+(the three convolutions, two LayerNorm2d and GELUs in one kernel).
 """
 import torch
 import torch.nn as nn
@@ -51,8 +51,13 @@ class PromptEncoder(nn.Module):
             G = f32(self.pe_layer.positional_encoding_gaussian_matrix)
             type_emb = torch.cat([f32(self.not_a_point_embed.weight)] + [f32(e.weight) for e in self.point_embeddings], 0)
             gh, gw = self.image_embedding_size
+            md = self.mask_downscaling
+            mask_w = torch.cat([f32(md[0].weight).reshape(-1), f32(md[0].bias), f32(md[1].weight), f32(md[1].bias),
+                                f32(md[3].weight).reshape(-1), f32(md[3].bias), f32(md[4].weight), f32(md[4].bias),
+                                f32(md[6].weight).reshape(-1), f32(md[6].bias)]).contiguous()
             self._cache = dict(G=G, type_emb=type_emb.contiguous(), pe_tok=ops.dense_pe(G, gh, gw),
-                               no_mask=f32(self.no_mask_embed.weight).reshape(-1))
+                               no_mask=f32(self.no_mask_embed.weight).reshape(-1), mask_w=mask_w,
+                               mask_eps=float(md[1].eps))
         return self._cache
 
     def get_dense_pe_tokens(self):
@@ -82,13 +87,20 @@ class PromptEncoder(nn.Module):
             return None, None
         return torch.cat(cs, dim=1).contiguous(), torch.cat(ls, dim=1).contiguous()
 
+    def embed_masks_tokens(self, masks):
+        """masks [n,1,4g,4g] (any real dtype) -> token-major dense embeddings fp32 [n, g*g, 256]."""
+        pk = self._packed()
+        gh, gw = self.image_embedding_size
+        if gh != gw or tuple(masks.shape[-2:]) != self.mask_input_size:
+            raise ValueError(f"mask prompts must be {self.mask_input_size}, got {tuple(masks.shape[-2:])}")
+        m = masks.to(device=pk["G"].device, dtype=torch.float32).reshape(-1, 4 * gh, 4 * gw).contiguous()
+        return ops.mask_downscale(m, pk["mask_w"], gh, pk["mask_eps"])
+
     def forward(self, points, boxes, masks):
-        if masks is not None:
-            raise NotImplementedError("mask prompts (mask_downscaling) are not on the accelerated path yet")
         pk = self._packed()
         dev = pk["G"].device
         coords, labels = self.prompt_arrays(points, boxes)
-        bs = 1 if coords is None else coords.shape[0]
+        bs = masks.shape[0] if (coords is None and masks is not None) else (1 if coords is None else coords.shape[0])
         if coords is None:
             sparse = torch.empty((bs, 0, self.embed_dim), device=dev)
         else:
@@ -98,5 +110,8 @@ class PromptEncoder(nn.Module):
                                     self.input_image_size[0])
             sparse = tok[:, 5:]
         gh, gw = self.image_embedding_size
-        dense = pk["no_mask"].reshape(1, -1, 1, 1).expand(bs, -1, gh, gw)
+        if masks is not None:                                                    # prompt_encoder.py:163-164
+            dense = self.embed_masks_tokens(masks).view(-1, gh, gw, self.embed_dim).permute(0, 3, 1, 2)
+        else:
+            dense = pk["no_mask"].reshape(1, -1, 1, 1).expand(bs, -1, gh, gw)
         return sparse, dense

@@ -119,3 +119,17 @@ def test_connected_components_properties():
     except ImportError:
         pass
     assert glue.connected_components_with_stats(np.zeros((5, 7), np.uint8))[0] == 1
+
+
+def test_mask_prompt_path(gold):
+    """PromptEncoder.mask_downscaling + decoder with per-prompt dense maps vs the vendored reference's outputs."""
+    from oracle import golden_inputs as gi, sam_prompt_decoder as odec
+    from protosam_amd.segment_anything import sam_model_registry
+    from protosam_amd.synth import synth_state_dict
+    sd = synth_state_dict(sam_model_registry["vit_b"](encoder_depth=1), gi.DECODER_SEED)
+    mk = gi.mask_prompt_case()
+    sparse, dense = odec.prompt_encoder(sd, None, None, masks=mk)
+    _close(dense[:, :, ::8, ::8], gold["dec_mask_dense"], 1e-4)
+    low, iou = odec.mask_decoder(sd, gi.decoder_features(), odec.dense_pe(sd), sparse, dense, True)
+    _close(low, gold["dec_mask_low_res"], 5e-4)
+    _close(iou, gold["dec_mask_iou"], 5e-5)

@@ -205,3 +205,45 @@ def test_protomedsam_forward_vs_oracle(dev):
     print(f"ProtoMedSAM: Dice {d:.5f}, flipped {(seg.cpu() != seg_ref).sum().item()}, "
           f"conf {float(conf[0].ravel()[0]):.4f} vs {float(conf_ref[0].ravel()[0]):.4f}")
     assert d > 0.995 and abs(float(conf[0].ravel()[0]) - float(conf_ref[0].ravel()[0])) < 5e-3
+
+
+@pytest.mark.parametrize("use_cca", [False, True])
+def test_protosam_mask_prompts_vs_oracle(dev, use_cca):
+    """use_mask=True with points and boxes off (ProtoSAM.py:452-498,664-665): every component's mask becomes a dense
+    prompt (nearest 256x256, values 10 / uint8(-8)), the best-scoring of the three masks is kept."""
+    from oracle import alp as oalp, dinov2 as odino, glue
+    from protosam_amd.protosam import InputFactory, TYPE_ALPNET
+    from protosam_amd.synth import synth_pair, synth_state_dict
+    sam_depth, dino_depth = 3, 12
+    model, alp_sd = _build(dev, f"random:vit_b:1234:{sam_depth}", dino_depth, use_bbox=False, use_points=False,
+                           use_mask=True, use_cca=use_cca)
+    sam_sd = {k: v.cpu() for k, v in synth_state_dict(model.sam, 1234).items()}
+    s_img, s_m, q_img, _ = synth_pair(512, seed=0)
+    inp = InputFactory.create_input(TYPE_ALPNET, q_img, support_images=[s_img], support_labels=[s_m], isval=True,
+                                    val_wsize=2)
+    inp.to(dev)
+    pred, scores = model(q_img.to(dev), inp)
+    st = model.last_stats
+    enc_sd = {k[len("encoder."):]: v for k, v in alp_sd.items() if k.startswith("encoder.")}
+    enc = lambda im: odino.forward_features(im, enc_sd, "dinov2_b14", depth=dino_depth)["x_norm_patchtokens"]  # noqa
+    logits_ref = oalp.fewshot_forward(enc, s_img, s_m, q_img, 512)
+    taps = {}
+    pred_ref, scores_ref = glue.protosam_forward(q_img, logits_ref, sam_sd, "vit_b", use_bbox=False, use_points=False,
+                                                 use_mask=True, use_cca=use_cca, encoder_depth=sam_depth, taps=taps)
+    n_ref = 1 if use_cca else taps["cc"][0] - 1
+    assert st["n_prompts"] == n_ref == len(scores) == len(scores_ref)
+    low = st["low_res"][:, 1:].cpu()
+    low_ref = torch.stack(taps["low_res"])
+    perr = (torch.sigmoid(low) - torch.sigmoid(low_ref)).abs().max().item()
+    serr = np.abs(np.array(scores, dtype=np.float64) - np.array(scores_ref)).max()
+    d = _dice(pred.cpu(), pred_ref)
+    print(f"mask prompts (use_cca={use_cca}): comps {n_ref}, max |dprob(low_res)| {perr:.3e}, scores {serr:.2e}, Dice {d:.5f}")
+    assert perr < 2e-2 and serr < 5e-3 and d > 0.995
+    # with points or boxes on, the reference overwrites the mask-prompt result (:667-668): use_mask changes nothing
+    both, _ = _build(dev, f"random:vit_b:1234:{sam_depth}", dino_depth, use_bbox=True, use_points=True, use_mask=True,
+                     point_mode="both", use_cca=use_cca)
+    plain, _ = _build(dev, f"random:vit_b:1234:{sam_depth}", dino_depth, use_bbox=True, use_points=True, use_mask=False,
+                      point_mode="both", use_cca=use_cca)
+    pa, sa = both(q_img.to(dev), inp)
+    pb, sb = plain(q_img.to(dev), inp)
+    assert torch.equal(pa, pb) and sa == sb

@@ -111,3 +111,29 @@ def test_predictor_api(dev):
     assert (torch.sigmoid(torch.from_numpy(low)) - torch.sigmoid(low_r)).abs().max() < 2e-3
     assert np.abs(iou - iou_r.numpy()).max() < 2e-3
     assert (masks != m_r.numpy()).mean() < 1e-3  # sign flips of near-zero logits only
+
+
+def test_mask_prompt_embedding_and_predict(dev):
+    """PromptEncoder.mask_downscaling (one HIP kernel) and the decoder fed with per-prompt dense maps, against the
+    REFERENCE's recorded outputs (dec_mask_* in tests/golden/reference_outputs.npz) and the oracle."""
+    import os
+    from oracle import golden_inputs as gi, sam_prompt_decoder as odec
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_outputs.npz"))
+    sam, sd = _sam(dev, "vit_b", 1, seed=gi.DECODER_SEED)
+    mk = gi.mask_prompt_case()
+    sparse, dense = sam.prompt_encoder(points=None, boxes=None, masks=mk.to(dev))
+    assert sparse.shape == (2, 0, 256) and dense.shape == (2, 256, 64, 64)
+    ref = odec.embed_masks(sd, mk)
+    err = (dense.cpu() - ref).abs().max().item()
+    print(f"mask_downscaling: max abs err {err:.3e} (|ref| max {ref.abs().max():.1f})")
+    assert err < 1e-3 * max(1.0, ref.abs().max().item())
+    np.testing.assert_allclose(dense.cpu()[:, :, ::8, ::8].numpy(), gold["dec_mask_dense"], atol=2e-3, rtol=1e-4)
+    feats = gi.decoder_features().to(dev)
+    low, iou = sam.mask_decoder(image_embeddings=feats, image_pe=sam.prompt_encoder.get_dense_pe(),
+                                sparse_prompt_embeddings=sparse, dense_prompt_embeddings=dense, multimask_output=True)
+    e_low = (torch.sigmoid(low.cpu()) - torch.sigmoid(torch.from_numpy(gold["dec_mask_low_res"]))).abs().max().item()
+    e_iou = np.abs(iou.cpu().numpy() - gold["dec_mask_iou"]).max()
+    print(f"decoder with mask prompts vs reference: max |dprob| {e_low:.3e}, iou {e_iou:.3e}")
+    assert e_low < 5e-3 and e_iou < 5e-3
+    with pytest.raises(ValueError):
+        sam.prompt_encoder(points=None, boxes=None, masks=torch.zeros((1, 1, 128, 128), device=dev))
