@@ -153,6 +153,12 @@ int psam_mask_binarize(const float* low, const int* idx, int n, int IN, int MID,
  * prompt_encoder.py:51-59,102-105; common.py:31-43 (LayerNorm2d) */
 int psam_mask_downscale(const float* masks, const float* wts, int n, int g, float eps, float* out, void* stream);
 
+/* Negative point prompts: keys[0] = most confident background pixel with p_bg >= thr (ProtoSAM.py:361-372), keys[1+k] = most
+ * confident background pixel of the ring dilate_r(component k) \ component k, r iterations of a 3x3 dilation
+ * (ProtoSAM.py:395-419; labels / tab as written by psam_ccl). key = float_bits(p_bg) << 32 | (0xFFFFFFFF - y*W - x); 0 = none. */
+int psam_neg_points(const int* labels, const float* pbg, const double* tab, int H, int W, int max_comp, int r, float thr,
+                    unsigned long long* keys, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -122,8 +122,53 @@ def most_conf_point(fg_p, comp):
     return np.array([[xs[i], ys[i]]]), [float(vals[i])]
 
 
+def dilate3x3(mask, iterations):
+    """cv2.dilate(mask, np.ones((3, 3)), iterations=n) on a 0/255 image (cv2 absent: restated; the default border of a
+    dilation never contributes). n passes of a 3x3 maximum = one (2n+1) x (2n+1) maximum; done literally here."""
+    m = np.asarray(mask) > 0
+    for _ in range(iterations):
+        p = np.pad(m, 1)
+        acc = np.zeros_like(m)
+        for dy in range(3):
+            for dx in range(3):
+                acc |= p[dy:dy + m.shape[0], dx:dx + m.shape[1]]
+        m = acc
+    return m.astype(np.uint8) * 255
+
+
+def first_argmax_point(vals_hw, region):
+    """get_most_conf_points (ProtoSAM.py:266-289) with k = 1 -> [[x, y]] or None; ties: first in raster order."""
+    ys, xs = np.nonzero(region)
+    if len(ys) == 0:
+        return None
+    i = int(np.argmax(vals_hw[ys, xs]))
+    return np.array([[xs[i], ys[i]]])
+
+
+def sam_neg_points(cc, output_p, l=1):
+    """ProtoSAM.py:361-372 (global) and :395-419 (per component ring) -> list over components of [n,2] arrays or None."""
+    assert l == 1
+    bg = output_p[0, 0].cpu().numpy().copy()
+    bg_t = bg.copy()
+    bg_t[bg_t < 0.95] = 0
+    glob = first_argmax_point(bg_t, bg_t > 0)
+    out = []
+    for cc_id in np.unique(cc[1]):
+        if cc_id == 0:
+            continue
+        pred_u8 = ((cc[1] == cc_id).astype(np.float32) * 255).astype(np.uint8)
+        boundary = (dilate3x3(pred_u8, 10) - pred_u8).astype(np.float32) / 255
+        neg = first_argmax_point(bg, boundary != 0)
+        if neg is not None and glob is not None:
+            neg = np.vstack([neg, glob])
+        else:
+            neg = glob if neg is None else neg
+        out.append(neg)
+    return out
+
+
 def sam_input_points(cc, output_p, point_mode="both"):
-    """ProtoSAM.py:349-450 (use_neg_points=False): per component [N,2] points in (x, y)."""
+    """ProtoSAM.py:349-450 (positive points): per component [N,2] points in (x, y)."""
     fg_p = output_p[0, 1].cpu().numpy()
     pts = []
     for cc_id in np.unique(cc[1]):
@@ -175,7 +220,7 @@ def mask_prompts(cc):
 
 def protosam_forward(query_image, output_logits, sam_sd, sam_type="vit_b", use_bbox=True, use_points=True,
                      point_mode="both", use_cca=False, postprocess="upstream", encoder_depth=None, taps=None,
-                     features=None, use_mask=False):
+                     features=None, use_mask=False, use_neg_points=False):
     """ProtoSAM.forward (models/ProtoSAM.py:536-678) after the coarse model: `output_logits` [1,2,H,W] is what
     `self.coarse_segmentation_model(input)` returned. Returns (pred [H,W] float {0,1}, scores list)."""
     original_size = query_image.shape[-2]
@@ -211,8 +256,15 @@ def protosam_forward(query_image, output_logits, sam_sd, sam_type="vit_b", use_b
                 taps["low_res"].append(low)
                 taps["masks"].append(m[k].numpy())
         points, bboxes = [], []
-    for point, box in zip(points, bboxes):                                                 # :505-527
+    negs = sam_neg_points(cc, output_p) if (use_neg_points and use_points) else [None] * len(points)
+    if taps is not None:
+        taps["neg_points"] = negs
+    for point, box, neg in zip(points, bboxes, negs):                                      # :505-527
         labels = np.array([1] * len(point)) if point is not None else None
+        if use_neg_points:                                                                 # :508-511
+            neg_pts = [npt for npt in neg if None not in npt]
+            point = np.vstack([point, *neg_pts])
+            labels = np.array([1] * (len(point) - len(neg_pts)) + [0] * len(neg_pts))
         m, s, low = odec.predict(sam_sd, features, point, labels, box, multimask_output=not use_cca,
                                  original_size=(1024, 1024), variant=postprocess)
         masks.append(m[0].numpy())                                                         # best_pred_idx = 0

@@ -276,3 +276,89 @@ extern "C" int psam_ccl(const void* pred, const float* pfg, int H, int W, int ca
                      (const unsigned long long*)acc_u, acc_d, fg_sum, tab);
   return psam_launch_status();
 }
+
+// ---- negative point prompts (models/ProtoSAM.py:361-372 global, :395-419 per component) ---------------------------------
+// keys[0]     = most confident background pixel among those with p_bg >= thr (the "global" negative point)
+// keys[1 + k] = most confident background pixel of the ring {dilate_r(component k) minus component k}, where dilate_r is
+//               r iterations of a 3x3 dilation = a (2r+1) x (2r+1) box (cv2.dilate(mask, ones(3,3), iterations=10), r = 10)
+// key = (float bits of p_bg) << 32 | (0xFFFFFFFF - pixel index): the maximum key is the largest p_bg, first pixel in raster
+// order on ties (torch.topk leaves tie order unspecified; same convention as the positive points); 0 = no such pixel.
+// One workgroup = one 32x32 tile of one component (blockIdx.z - 1) or of the global search (blockIdx.z == 0); tiles outside
+// the component's bounding box grown by r leave at once. Box dilation is separable: rows in LDS, then columns.
+#define NP_T 32
+#define NP_RMAX 10
+__global__ __launch_bounds__(256) void neg_points_kernel(const int* __restrict__ labels, const float* __restrict__ pbg,
+                                                         const double* __restrict__ tab, int H, int W, int r, float thr,
+                                                         unsigned long long* __restrict__ keys) {
+  constexpr int TW = NP_T + 2 * NP_RMAX;
+  __shared__ unsigned char m[TW][TW];
+  __shared__ unsigned char hd[TW][NP_T];
+  __shared__ unsigned long long red[4];
+  const int t = threadIdx.x;
+  const int x0 = blockIdx.x * NP_T, y0 = blockIdx.y * NP_T;
+  const int z = blockIdx.z;
+  unsigned long long best = 0ull;
+  if (z == 0) {
+    for (int i = t; i < NP_T * NP_T; i += 256) {
+      const int y = y0 + i / NP_T, x = x0 + i % NP_T;
+      if (y < H && x < W) {
+        const float v = pbg[(size_t)y * W + x];
+        if (v >= thr) {
+          const unsigned long long k = ((unsigned long long)__float_as_uint(v) << 32) | (0xFFFFFFFFu - (unsigned)(y * W + x));
+          best = k > best ? k : best;
+        }
+      }
+    }
+  } else {
+    const int k = z - 1;
+    if (k >= (int)tab[1]) return;
+    const double* row = tab + CC_HDR + (size_t)CC_STRIDE * k;
+    const int bx0 = (int)row[3] - r, by0 = (int)row[4] - r, bx1 = (int)row[5] + r, by1 = (int)row[6] + r;
+    if (x0 > bx1 || x0 + NP_T - 1 < bx0 || y0 > by1 || y0 + NP_T - 1 < by0) return;
+    const int c = k + 1, span = NP_T + 2 * r;
+    for (int i = t; i < span * span; i += 256) {
+      const int ly = i / span, lx = i % span;
+      const int y = y0 - r + ly, x = x0 - r + lx;
+      m[ly][lx] = (y >= 0 && y < H && x >= 0 && x < W && labels[(size_t)y * W + x] == c) ? 1 : 0;
+    }
+    __syncthreads();
+    for (int i = t; i < span * NP_T; i += 256) {
+      const int ly = i / NP_T, cx = i % NP_T;
+      unsigned char any = 0;
+      for (int d = 0; d <= 2 * r; ++d) any |= m[ly][cx + d];
+      hd[ly][cx] = any;
+    }
+    __syncthreads();
+    for (int i = t; i < NP_T * NP_T; i += 256) {
+      const int ty = i / NP_T, tx = i % NP_T;
+      const int y = y0 + ty, x = x0 + tx;
+      if (y >= H || x >= W || m[ty + r][tx + r]) continue;
+      unsigned char any = 0;
+      for (int d = 0; d <= 2 * r; ++d) any |= hd[ty + d][tx];
+      if (any) {
+        const float v = pbg[(size_t)y * W + x];
+        const unsigned long long kk = ((unsigned long long)__float_as_uint(v) << 32) | (0xFFFFFFFFu - (unsigned)(y * W + x));
+        best = kk > best ? kk : best;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long other = __shfl_xor(best, o, 64);
+    best = other > best ? other : best;
+  }
+  if ((t & 63) == 0) red[t >> 6] = best;
+  __syncthreads();
+  if (t == 0) {
+    for (int i = 1; i < 4; ++i) best = red[i] > best ? red[i] : best;
+    if (best) atomicMax(keys + z, best);
+  }
+}
+extern "C" int psam_neg_points(const int* labels, const float* pbg, const double* tab, int H, int W, int max_comp, int r,
+                               float thr, unsigned long long* keys, void* stream) {
+  if (H <= 0 || W <= 0 || max_comp < 0 || r < 0 || r > NP_RMAX) return PSAM_ERR_ARG;
+  (void)hipMemsetAsync(keys, 0, sizeof(unsigned long long) * (max_comp + 1), (hipStream_t)stream);
+  hipLaunchKernelGGL(neg_points_kernel, dim3((W + NP_T - 1) / NP_T, (H + NP_T - 1) / NP_T, max_comp + 1), dim3(256), 0,
+                     (hipStream_t)stream, labels, pbg, tab, H, W, r, thr, keys);
+  return psam_launch_status();
+}

@@ -488,6 +488,28 @@ def ccl(pred_u8, pfg, ws, fg_sum=None, slot=0):
     return ws
 
 
+def neg_points(ws, pbg, tab, max_comp, r=10, thr=0.95, keys=None):
+    """int64 keys [max_comp+1] (see psam_neg_points) from ws.labels (the CCL of the SAME image) and p_bg fp32 [H,W]."""
+    _req(pbg, torch.float32, "pbg")
+    assert pbg.is_contiguous() and tab.dtype == torch.float64
+    if keys is None:
+        keys = torch.empty(max_comp + 1, dtype=torch.int64, device=pbg.device)
+    st = _lib.lib().psam_neg_points(_ptr(ws.labels), _ptr(pbg), _ptr(tab), ws.H, ws.W, max_comp, r, float(thr), _ptr(keys),
+                                   _stream())
+    _lib.check(st, "psam_neg_points")
+    return keys
+
+
+def decode_point_key(key, W):
+    """key (python int, possibly negative from the int64 view) -> (x, y, p) or None."""
+    key &= (1 << 64) - 1
+    if key == 0:
+        return None
+    import struct
+    idx = 0xFFFFFFFF - (key & 0xFFFFFFFF)
+    return idx % W, idx // W, struct.unpack("<f", struct.pack("<I", key >> 32))[0]
+
+
 def bilinear_tokens(tok, in_bstride, ld, B, ih, iw, C, oh, ow, out=None):
     """fp32 token-major [B][ih*iw, C] (strided) -> contiguous [B, oh*ow, C]."""
     _req(tok, torch.float32, "tok")

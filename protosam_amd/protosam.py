@@ -19,7 +19,10 @@ Mask prompts (`use_mask=True` with points and boxes off, ProtoSAM.py:468-498,664
 sampled to 256x256, goes through `psam_mask_downscale` and the decoder without sparse prompts; the best-scoring of the
 three masks is kept per component. With points or boxes on, the reference overwrites the mask-prompt result (:667-668),
 so `use_mask` then changes nothing and its work is skipped.
-Unsupported (outside SURVEY §8's hot path, raise NotImplementedError): `use_neg_points`,
+Negative points (`use_neg_points=True`, ProtoSAM.py:361-372,395-419,508-511): `psam_neg_points` finds, on the device, the
+most confident background pixel of each component's 10-pixel dilation ring and the global one (p_bg >= 0.95); components
+whose prompt sets end up with different token counts are decoded in separate batches.
+Unsupported (outside SURVEY §8's hot path, raise NotImplementedError):
 `degrees_rotate != 0`, `debug` plotting, training mode.
 """
 import os
@@ -44,6 +47,7 @@ TYPE_ALPNET = "alpnet"
 TYPE_SAM = "sam"
 
 MAX_COMPONENTS = 256
+MAX_NEG_COMPONENTS = 64   # psam_neg_points launches one tile grid per component
 
 
 class SegmentationInput(ABC):
@@ -214,8 +218,8 @@ class ProtoSAM(nn.Module):
             raise ValueError(f"point mode must be one of {POINT_MODES}")
         self.debug = debug
         self.coarse_pred_only = coarse_pred_only
-        if use_neg_points or debug or num_points_for_sam != 1:
-            raise NotImplementedError("use_neg_points / debug / num_points_for_sam != 1 are outside the hot path")
+        if debug or num_points_for_sam != 1:
+            raise NotImplementedError("debug / num_points_for_sam != 1 are outside the hot path")
         self._mask_only = self.use_mask and not (self.use_points or self.use_bbox)
         # predict_w_masks writes 10 / -8 into a float array and hands it over `.astype(np.uint8)` (ProtoSAM.py:473-479):
         # whatever this platform's numpy makes of -8.0 (248 on x86-64) is what SAM sees
@@ -255,16 +259,26 @@ class ProtoSAM(nn.Module):
         self.sam_trans = sam_trans
 
     # ---- host-side prompt assembly from the component table -----------------------------------------------------------
-    def _prompts_from_table(self, tab):
-        """tab: fp64 numpy table of csrc/ccl.hip. Returns coords fp32 [n, Ns, 2], labels int32 [n, Ns] in the prompt
-        kernel's convention (1 = positive point, 2/3 = box corners, -1 = padding point) following
-        get_sam_input_points (:349-450), get_bbox_per_cc (:242-264) and PromptEncoder's padding rule."""
+    def _prompts_from_table(self, tab, neg_keys=None):
+        """tab: fp64 numpy table of csrc/ccl.hip; neg_keys: int64 numpy keys of psam_neg_points (use_neg_points).
+        Returns per kept component a list of (x, y) and a list of labels in the prompt kernel's convention (1 = positive
+        point, 0 = negative point, 2/3 = box corners, -1 = padding point) following get_sam_input_points (:349-450),
+        get_bbox_per_cc (:242-264), predict_w_points_bbox (:505-511) and PromptEncoder's padding rule; plus the rows."""
         n = int(tab[1])
         rows = tab[ops.CC_HDR:ops.CC_HDR + ops.CC_STRIDE * n].reshape(n, ops.CC_STRIDE)
+        first = 0
         if self.use_cca:  # util/utils.py:496-541: keep the most confident component only
-            rows = rows[int(tab[3]):int(tab[3]) + 1]
+            first = int(tab[3])
+            rows = rows[first:first + 1]
+        glob = None
+        if self.use_neg_points:
+            if not self.use_points:
+                raise TypeError("'NoneType' object is not iterable")   # ProtoSAM.py:509 iterates sam_neg_input_points[i] = None
+            if n > MAX_NEG_COMPONENTS:
+                raise NotImplementedError(f"use_neg_points with more than {MAX_NEG_COMPONENTS} components")
+            glob = ops.decode_point_key(int(neg_keys[0]), 1024)
         coords, labels = [], []
-        for r in rows:
+        for k, r in enumerate(rows):
             c, lab = [], []
             if self.use_points:
                 if self.point_mode in (CONF_MODE, BOTH_MODE):
@@ -273,6 +287,14 @@ class ProtoSAM(nn.Module):
                 if self.point_mode in (CENTROID_MODE, BOTH_MODE):
                     c.append([r[1] / r[0], r[2] / r[0]])  # cv2 centroid: float64 mean of x, mean of y
                     lab.append(1)
+                if self.use_neg_points:                     # ring point first, then the global one (:414-418)
+                    ring = ops.decode_point_key(int(neg_keys[1 + first + k]), 1024)
+                    if ring is None and glob is None:
+                        raise TypeError("'NoneType' object is not iterable")   # neg_point is None at :509
+                    for pt in (ring, glob):
+                        if pt is not None:
+                            c.append([float(pt[0]), float(pt[1])])
+                            lab.append(0)
                 if not self.use_bbox:
                     c.append([0.0, 0.0])
                     lab.append(-1)
@@ -282,7 +304,7 @@ class ProtoSAM(nn.Module):
             coords.append(c)
             labels.append(lab)
         # predictor.predict: apply_coords with original_size == 1024 is the identity; torch.as_tensor(dtype=float)
-        return np.asarray(coords, dtype=np.float64).astype(np.float32), np.asarray(labels, dtype=np.int32), rows
+        return coords, labels, rows
 
     def _work_buffers(self, dev, B):
         key = (str(dev), B)
@@ -332,10 +354,16 @@ class ProtoSAM(nn.Module):
         cw = self._ccl
         for b in range(B):
             ops.ccl(pred[b], output_p[b, 1], cw, fg_sum=bufs["fg_sum"][b:b + 1], slot=b)
+            if self.use_neg_points:   # labels are per-call scratch: reduce them now
+                nk = bufs.setdefault("neg_keys", torch.empty((B, MAX_NEG_COMPONENTS + 1), dtype=torch.int64, device=dev))
+                ops.neg_points(cw, output_p[b, 0], cw.tabs[b], MAX_NEG_COMPONENTS, keys=nk[b])
             if self._mask_only:   # cv2.resize(mask, (256, 256), INTER_NEAREST) samples pixel (4y, 4x); labels are scratch
                 bufs.setdefault("lab256", torch.empty((B, S // 4, S // 4), dtype=torch.int32, device=dev))[b].copy_(
                     cw.labels.view(S, S)[::4, ::4])
         cw.tabs_host[:B].copy_(cw.tabs[:B], non_blocking=True)
+        if self.use_neg_points:
+            nkh = bufs.setdefault("neg_keys_host", torch.empty((B, MAX_NEG_COMPONENTS + 1), dtype=torch.int64).pin_memory())
+            nkh.copy_(bufs["neg_keys"], non_blocking=True)
         bufs["event"].record()
         # 3. image hand-off: resize -> min/max -> uint8 quantise -> SAM normalise -> im2col      ProtoSAM.py:592-593,651-660
         q = query_images.float().contiguous()
@@ -367,12 +395,12 @@ class ProtoSAM(nn.Module):
                 img_idx += [b] * len(ids)
                 stats[b].update(n_prompts=len(ids))
                 continue
-            c, l, rows = self._prompts_from_table(tab)
+            c, l, rows = self._prompts_from_table(tab, bufs["neg_keys_host"][b].numpy() if self.use_neg_points else None)
             spans.append((b, len(img_idx), len(l)))
-            coords.append(c)
-            labels.append(l)
+            coords += c
+            labels += l
             img_idx += [b] * len(l)
-            stats[b].update(n_prompts=len(l), table=rows)
+            stats[b].update(n_prompts=len(l), table=rows, prompts=(c, l))
         self.last_stats = stats[0] if B == 1 else dict(per_slice=stats)
         if spans and self._mask_only:
             # 6m. mask prompts: dense embedding per component, no sparse prompts, best of the three masks
@@ -398,18 +426,34 @@ class ProtoSAM(nn.Module):
                 results[b] = (out, [np.float32(v) for v in iou_host[start:start + cnt]])
             self.last_stats.update(low_res=masks, iou=iou, best=best, spans=spans)
         elif spans:
-            coords = np.concatenate(coords, 0)
-            labels = np.concatenate(labels, 0)
-            P, Ns = labels.shape
+            P = len(labels)
             pe = sam.prompt_encoder._packed()
             dpk = sam.mask_decoder._packed()
-            tokens = ops.prompt_tokens(torch.from_numpy(coords).to(dev, non_blocking=True),
-                                       torch.from_numpy(labels).to(dev, non_blocking=True), pe["G"], pe["type_emb"],
-                                       dpk["out_tok"], P, Ns, float(S))
-            iop = torch.tensor(img_idx, dtype=torch.int32).to(dev, non_blocking=True)
-            # 6. batched two-way decoder over all components of all slices           ProtoSAM.py:500-527
-            masks, iou, _ = sam.mask_decoder.predict_masks_tokens(feat_tok, pe["pe_tok"], tokens, pe["no_mask"],
-                                                                  img_of_prompt=iop)
+            iop_all = torch.tensor(img_idx, dtype=torch.int32).to(dev, non_blocking=True)
+            # 6. batched two-way decoder over all components of all slices (ProtoSAM.py:500-527); prompt sets of equal
+            #    length share a batch (they differ only when some component has no ring / no global negative point)
+            groups = {}
+            for i, lab in enumerate(labels):
+                groups.setdefault(len(lab), []).append(i)
+            masks = iou = None
+            for Ns, idx in groups.items():
+                cg = np.asarray([coords[i] for i in idx], dtype=np.float64).astype(np.float32).reshape(len(idx), Ns, 2)
+                lg = np.asarray([labels[i] for i in idx], dtype=np.int32).reshape(len(idx), Ns)
+                tokens = ops.prompt_tokens(torch.from_numpy(cg).to(dev, non_blocking=True),
+                                           torch.from_numpy(lg).to(dev, non_blocking=True), pe["G"], pe["type_emb"],
+                                           dpk["out_tok"], len(idx), Ns, float(S))
+                if len(groups) == 1:
+                    masks, iou, _ = sam.mask_decoder.predict_masks_tokens(feat_tok, pe["pe_tok"], tokens, pe["no_mask"],
+                                                                          img_of_prompt=iop_all)
+                else:
+                    if masks is None:
+                        masks = torch.empty((P, 4, 256, 256), dtype=torch.float32, device=dev)
+                        iou = torch.empty((P, 4), dtype=torch.float32, device=dev)
+                    it = torch.tensor(idx, dtype=torch.int64, device=dev)
+                    m_g, i_g, _ = sam.mask_decoder.predict_masks_tokens(feat_tok, pe["pe_tok"], tokens, pe["no_mask"],
+                                                                        img_of_prompt=iop_all[it].contiguous())
+                    masks[it] = m_g
+                    iou[it] = i_g
             sel = 0 if self.use_cca else 1                                      # multimask_output = not use_cca; index 0
             iou_host = iou[:, sel].cpu().numpy()
             for (b, start, cnt) in spans:

@@ -133,3 +133,23 @@ def test_mask_prompt_path(gold):
     low, iou = odec.mask_decoder(sd, gi.decoder_features(), odec.dense_pe(sd), sparse, dense, True)
     _close(low, gold["dec_mask_low_res"], 5e-4)
     _close(iou, gold["dec_mask_iou"], 5e-5)
+
+
+def test_dilation_restatement_matches_scipy():
+    """cv2.dilate(mask, ones(3,3), iterations=10) (cv2 absent, PARITY UNPINNED) restated in oracle/glue.py equals scipy's
+    binary dilation and a 21x21 maximum filter; key decoding of the product's negative-point reduction."""
+    import scipy.ndimage as ndi
+    from oracle import glue
+    from protosam_amd.ops import decode_point_key
+    rng = np.random.RandomState(0)
+    m = (ndi.gaussian_filter(rng.randn(90, 130), 4) > 0.05).astype(np.uint8) * 255
+    m[0, :5] = 255
+    a = glue.dilate3x3(m, 10)
+    assert np.array_equal(a > 0, ndi.binary_dilation(m > 0, structure=np.ones((3, 3)), iterations=10))
+    assert np.array_equal(a, ndi.maximum_filter(m, size=21, mode="constant", cval=0))
+    import struct
+    bits = struct.unpack("<I", struct.pack("<f", 0.96875))[0]
+    key = (bits << 32) | (0xFFFFFFFF - (7 * 1024 + 5))
+    assert decode_point_key(key, 1024) == (5, 7, 0.96875)
+    assert decode_point_key(key - (1 << 64), 1024) == (5, 7, 0.96875)      # the int64 view of the same key
+    assert decode_point_key(0, 1024) is None

@@ -247,3 +247,81 @@ def test_protosam_mask_prompts_vs_oracle(dev, use_cca):
     pa, sa = both(q_img.to(dev), inp)
     pb, sb = plain(q_img.to(dev), inp)
     assert torch.equal(pa, pb) and sa == sb
+
+
+def test_neg_points_kernel_vs_oracle(dev):
+    """psam_neg_points: ring (10 x 3x3 dilation minus the component) and global (p_bg >= 0.95) negative points, exact."""
+    import scipy.ndimage as ndi
+    from oracle import glue
+    from protosam_amd import ops
+    rng = np.random.RandomState(4)
+    H = W = 1024
+    for trial, thr in enumerate((0.05, 0.3, 0.6)):
+        field = ndi.gaussian_filter(rng.randn(H, W), 18 + 6 * trial)
+        field /= np.abs(field).max()
+        pred = (field > thr).astype(np.uint8)
+        pred[:6, :40] = 1                                    # a component touching the border
+        pred[500:503, 500:503] = 1                           # a tiny one
+        pfg = np.clip(0.5 + 0.5 * field + 0.02 * rng.randn(H, W), 0.0, 1.0).astype(np.float32)
+        prob = torch.from_numpy(np.stack([1.0 - pfg, pfg])[None]).float()
+        ws = ops.CclWorkspace(H, W, 256, dev)
+        ops.ccl(torch.from_numpy(pred).to(dev), prob[0, 1].to(dev).contiguous(), ws)
+        keys = ops.neg_points(ws, prob[0, 0].to(dev).contiguous(), ws.tabs[0], 64).cpu().numpy()
+        n = int(ws.tabs[0][1].item())
+        lab = ws.labels.view(H, W).cpu().numpy()
+        cc = (n + 1, lab, None, None)
+        ref = glue.sam_neg_points(cc, prob)
+        assert 2 <= n <= 64 and len(ref) == n
+        bg = prob[0, 0].numpy()
+        glob = ops.decode_point_key(int(keys[0]), W)
+        for k in range(n):
+            got = [p for p in (ops.decode_point_key(int(keys[1 + k]), W), glob) if p is not None]
+            exp = ref[k]
+            assert exp is not None and len(got) == len(exp)
+            for g, e in zip(got, exp):
+                assert (g[0], g[1]) == (int(e[0]), int(e[1])), (trial, k, g, e)
+                assert g[2] == bg[g[1], g[0]]
+        assert np.all(keys[n + 1:] == 0)
+    assert ops.decode_point_key(0, W) is None
+
+
+def test_protosam_neg_points_vs_oracle(dev):
+    """use_neg_points=True (ProtoSAM.py:361-372,395-419,508-511): positive points + ring / global negative points + box."""
+    from oracle import alp as oalp, dinov2 as odino, glue
+    from protosam_amd.protosam import InputFactory, TYPE_ALPNET
+    from protosam_amd.synth import synth_pair, synth_state_dict
+    sam_depth, dino_depth = 3, 12
+    kw = dict(use_bbox=True, use_points=True, point_mode="both", use_cca=False, use_neg_points=True)
+    model, alp_sd = _build(dev, f"random:vit_b:1234:{sam_depth}", dino_depth, **kw)
+    sam_sd = {k: v.cpu() for k, v in synth_state_dict(model.sam, 1234).items()}
+    s_img, s_m, q_img, _ = synth_pair(512, seed=0)
+    inp = InputFactory.create_input(TYPE_ALPNET, q_img, support_images=[s_img], support_labels=[s_m], isval=True,
+                                    val_wsize=2)
+    inp.to(dev)
+    pred, scores = model(q_img.to(dev), inp)
+    st = model.last_stats
+    enc_sd = {k[len("encoder."):]: v for k, v in alp_sd.items() if k.startswith("encoder.")}
+    enc = lambda im: odino.forward_features(im, enc_sd, "dinov2_b14", depth=dino_depth)["x_norm_patchtokens"]  # noqa
+    logits_ref = oalp.fewshot_forward(enc, s_img, s_m, q_img, 512)
+    taps = {}
+    pred_ref, scores_ref = glue.protosam_forward(q_img, logits_ref, sam_sd, "vit_b", use_bbox=True, use_points=True,
+                                                 point_mode="both", use_cca=False, use_neg_points=True,
+                                                 encoder_depth=sam_depth, taps=taps)
+    coords, labels = st["prompts"]
+    assert len(coords) == len(taps["neg_points"]) == taps["cc"][0] - 1
+    for c, l, neg in zip(coords, labels, taps["neg_points"]):
+        got = [tuple(int(v) for v in xy) for xy, lab in zip(c, l) if lab == 0]
+        # the fp16 coarse map can move an arg-max by a pixel on a plateau; the labels and counts must agree exactly
+        assert len(got) == len(neg) and l.count(0) == len(neg) and l[:2] == [1, 1] and l[-2:] == [2, 3]
+        for g, e in zip(got, neg):
+            assert abs(g[0] - int(e[0])) <= 2 and abs(g[1] - int(e[1])) <= 2, (got, neg)
+    low = st["low_res"][:, st["sel"]].cpu()
+    low_ref = torch.stack([l[0] for l in taps["low_res"]])
+    perr = (torch.sigmoid(low) - torch.sigmoid(low_ref)).abs().max().item()
+    d = _dice(pred.cpu(), pred_ref)
+    print(f"neg points: comps {len(coords)}, max |dprob(low_res)| {perr:.3e}, Dice {d:.5f}, "
+          f"scores {np.abs(np.array(scores) - np.array(scores_ref)).max():.2e}")
+    assert d > 0.995 and perr < 2e-2
+    with pytest.raises(TypeError):
+        bad, _ = _build(dev, f"random:vit_b:1234:1", 1, use_bbox=True, use_points=False, use_neg_points=True)
+        bad(q_img.to(dev), inp)
