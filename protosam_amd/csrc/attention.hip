@@ -37,6 +37,7 @@ struct AttnArgs {
   int B, N, H;
   float scale;
   int gh, gw, ws, nwx, nwin;  // token grid, window size, windows per row, windows per image
+  int nqb;                    // query blocks per (batch, head) (global modes)
 };
 
 #define KT 64  // keys per tile
@@ -71,15 +72,29 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
   const int t = threadIdx.x;
   const int lane = t & 63, wv = t >> 6;
   const int li = lane & 15, g = lane >> 4;
-  const int h = blockIdx.y;
-  int b, win = 0, wy = 0, wx = 0;
-  if (MODE == 2) {
-    b = blockIdx.z / p.nwin;
-    win = blockIdx.z % p.nwin;
-    wy = win / p.nwx;
-    wx = win % p.nwx;
-  } else {
-    b = blockIdx.z;
+  // Workgroup -> (query block, head, batch/window) with XCD locality (block i runs on XCD i % 8, each XCD has its own L2):
+  // the workgroups that touch the same cache lines are given ids that differ by a multiple of 8.
+  //   window mode: the 16 heads of one window read interleaved 160-byte slices of the same qkv rows (2.25 lines fetched
+  //   per slice when alone) -> all heads of a window on one XCD;  global mode: the N/QB query blocks of one (batch, head)
+  //   stream the same K/V -> all query blocks of a head on one XCD (one K/V fetch per head instead of one per XCD).
+  int h, b, qblk = 0, win = 0, wy = 0, wx = 0;
+  {
+    const int per = MODE == 2 ? p.H : p.nqb;                     // workgroups that share lines
+    const int nshare = MODE == 2 ? p.B * p.nwin : p.B * p.H;     // independent groups
+    const int g = blockIdx.x / (8 * per), r = blockIdx.x % (8 * per);
+    const int grp = g * 8 + (r & 7), idx = r >> 3;
+    if (grp >= nshare) return;
+    if (MODE == 2) {
+      h = idx;
+      b = grp / p.nwin;
+      win = grp % p.nwin;
+      wy = win / p.nwx;
+      wx = win % p.nwx;
+    } else {
+      qblk = idx;
+      h = grp % p.H;
+      b = grp / p.H;
+    }
   }
   const int N = p.N, H = p.H;
   const size_t rs = (size_t)3 * H * HD;  // qkv row stride (halfs)
@@ -95,7 +110,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
   };
 
   // ---- query fragments (B operand of S^T = K Q^T), kept in registers -----------------------
-  const int qrow_blk = blockIdx.x * QB + wv * 32;  // first query row (global or window-local) of this wave
+  const int qrow_blk = qblk * QB + wv * 32;  // first query row (global or window-local) of this wave
   int qtok[2];
   bool qvalid[2];
   half8_t qf[2][KS];
@@ -132,7 +147,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
       relh_q[qt] = p.rel_h + (((size_t)b * H + h) * N + qtok[qt]) * (size_t)p.gw;
     for (int idx = t; idx < QB * 16; idx += NT) {
       const int qr = idx >> 4, c4 = idx & 15;
-      int q = blockIdx.x * QB + qr;
+      int q = qblk * QB + qr;
       q = q < N ? q : N - 1;
       float4 v = *reinterpret_cast<const float4*>(p.rel_w + (((size_t)b * H + h) * N + q) * (size_t)p.gw + c4 * 4);
       v.x *= LOG2E; v.y *= LOG2E; v.z *= LOG2E; v.w *= LOG2E;
@@ -407,15 +422,17 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
 }
 
 template <int HD>
-static int launch_attn(const AttnArgs& p, int mode, hipStream_t s) {
+static int launch_attn(AttnArgs p, int mode, hipStream_t s) {
   if (mode == 2) {
     constexpr int NW = 7;
-    int nq = p.ws * p.ws;
-    dim3 grid((nq + NW * 32 - 1) / (NW * 32), p.H, p.B * p.nwin), block(NW * 64);
-    hipLaunchKernelGGL((attn_kernel<HD, 2, NW>), grid, block, 0, s, p);
+    p.nqb = 1;
+    const int groups8 = (p.B * p.nwin + 7) / 8;
+    hipLaunchKernelGGL((attn_kernel<HD, 2, NW>), dim3(groups8 * 8 * p.H), dim3(NW * 64), 0, s, p);
   } else {
     constexpr int NW = 4;
-    dim3 grid((p.N + NW * 32 - 1) / (NW * 32), p.H, p.B), block(NW * 64);
+    p.nqb = (p.N + NW * 32 - 1) / (NW * 32);
+    const int groups8 = (p.B * p.H + 7) / 8;
+    dim3 grid(groups8 * 8 * p.nqb), block(NW * 64);
     if (mode == 1)
       hipLaunchKernelGGL((attn_kernel<HD, 1, NW>), grid, block, 0, s, p);
     else
