@@ -159,6 +159,16 @@ int psam_mask_downscale(const float* masks, const float* wts, int n, int g, floa
 int psam_neg_points(const int* labels, const float* pbg, const double* tab, int H, int W, int max_comp, int r, float thr,
                     unsigned long long* keys, void* stream);
 
+/* Slice hand-off from a scan volume (raw NIfTI voxels [Z,H,W]; vol_dtype 0 int16, 1 float32, 2 uint8, 3 int32).
+ * psam_volume_stats: out[0] = sum(x), out[1] = sum(x^2) in fp64, x = voxel*slope + inter  (MR_normalize / get_CT_statistics,
+ *   dataloaders/dataset_utils.py:76-108).
+ * psam_volume_slices: out fp32 [Z,tile,S,S] = tile copies of cv2.resize((x - mean) * inv_std, (S,S), INTER_LINEAR) per slice
+ *   (mode 0), or cv2.INTER_NEAREST of the raw values for label volumes (mode 1).
+ *   dataloaders/ManualAnnoDatasetv2.py:165-187 (read_dataset), :317-327 (tile_z_dim). */
+int psam_volume_stats(const void* vol, int vol_dtype, long long n, float slope, float inter, double* out, void* stream);
+int psam_volume_slices(const void* vol, int vol_dtype, int Z, int H, int W, float slope, float inter, float mean,
+                       float inv_std, int S, int tile, int mode, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

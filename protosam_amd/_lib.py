@@ -47,6 +47,9 @@ SIGNATURES = {
     "psam_mask_union": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p],
     "psam_mask_stats": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
                         c_void_p, c_void_p],
+    "psam_volume_stats": [c_void_p, c_int, ctypes.c_longlong, c_float, c_float, c_void_p, c_void_p],
+    "psam_volume_slices": [c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_int, c_int, c_int,
+                           c_void_p, c_void_p],
     "psam_neg_points": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p],
     "psam_mask_downscale": [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p],
     "psam_mask_binarize": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p,

@@ -324,3 +324,90 @@ extern "C" int psam_bilinear_tokens(const float* in, long long in_bstride, int l
                      ld, ih, iw, C, oh, ow, out);
   return psam_launch_status();
 }
+
+// ---- slice hand-off: scan volume -> normalised, resized, z-tiled query / support slices ------------------------------
+// Replaces the host chain of dataloaders/ManualAnnoDatasetv2.py:165-187,317-327 (np.float32 -> norm_func -> cv2.resize
+// INTER_LINEAR per slice -> repeat(tile_z_dim)) and dataset_utils.py:101-108 (MR_normalize / CT_normalize).
+// vol_dtype: 0 int16, 1 float32, 2 uint8, 3 int32 (raw voxels as stored in the NIfTI file, [Z, H, W], x fastest).
+__device__ __forceinline__ float vox(const void* __restrict__ v, int dt, size_t i) {
+  switch (dt) {
+    case 0: return (float)reinterpret_cast<const short*>(v)[i];
+    case 1: return reinterpret_cast<const float*>(v)[i];
+    case 2: return (float)reinterpret_cast<const unsigned char*>(v)[i];
+    default: return (float)reinterpret_cast<const int*>(v)[i];
+  }
+}
+
+// out[0] = sum(x), out[1] = sum(x^2) over the whole volume in fp64 (x after slope / intercept scaling)
+__global__ __launch_bounds__(256) void volume_stats_kernel(const void* __restrict__ vol, int dt, size_t n, float slope,
+                                                           float inter, double* __restrict__ out) {
+  double s = 0.0, q = 0.0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const double x = (double)(vox(vol, dt, i) * slope + inter);
+    s += x;
+    q += x * x;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o, 64);
+    q += __shfl_xor(q, o, 64);
+  }
+  __shared__ double rs[4], rq[4];
+  if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = s; rq[threadIdx.x >> 6] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(out + 0, rs[0] + rs[1] + rs[2] + rs[3]);
+    atomicAdd(out + 1, rq[0] + rq[1] + rq[2] + rq[3]);
+  }
+}
+extern "C" int psam_volume_stats(const void* vol, int vol_dtype, long long n, float slope, float inter, double* out,
+                                 void* stream) {
+  if (n <= 0 || vol_dtype < 0 || vol_dtype > 3) return PSAM_ERR_ARG;
+  (void)hipMemsetAsync(out, 0, 2 * sizeof(double), (hipStream_t)stream);
+  const int blocks = (int)((n + 256 * 16 - 1) / (256 * 16) < 2048 ? (n + 256 * 16 - 1) / (256 * 16) : 2048);
+  hipLaunchKernelGGL(volume_stats_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, vol, vol_dtype, (size_t)n, slope,
+                     inter, out);
+  return psam_launch_status();
+}
+
+// out [Z, tile, S, S] fp32 = tile copies of resize_linear((x*slope + inter - mean) * inv_std) with cv2.INTER_LINEAR's
+// float rule: source coordinate (d + 0.5) * in/out - 0.5, floor, clamp (weight collapses onto the edge pixel), horizontal
+// pass then vertical pass. mode 1 = cv2.INTER_NEAREST for label volumes (floor(d * in/out), no normalisation).
+__global__ __launch_bounds__(256) void volume_slices_kernel(const void* __restrict__ vol, int dt, int H, int W, float slope,
+                                                            float inter, float mean, float inv_std, int S, int tile,
+                                                            int mode, float* __restrict__ out) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, z = blockIdx.z;
+  if (x >= S) return;
+  const size_t base = (size_t)z * H * W;
+  float v;
+  if (mode == 1) {
+    int sx = (int)floor((double)x * ((double)W / (double)S)), sy = (int)floor((double)y * ((double)H / (double)S));
+    sx = sx < W - 1 ? sx : W - 1;
+    sy = sy < H - 1 ? sy : H - 1;
+    v = vox(vol, dt, base + (size_t)sy * W + sx) * slope + inter;
+  } else {
+    const double scx = (double)W / (double)S, scy = (double)H / (double)S;
+    float fx = (float)(((double)x + 0.5) * scx - 0.5), fy = (float)(((double)y + 0.5) * scy - 0.5);
+    int sx = (int)floorf(fx), sy = (int)floorf(fy);
+    fx -= (float)sx;
+    fy -= (float)sy;
+    int sx1 = sx + 1, sy1 = sy + 1;
+    if (sx < 0) { sx = 0; sx1 = 0; fx = 0.f; }
+    if (sx >= W - 1) { sx = W - 1; sx1 = W - 1; fx = 0.f; }
+    if (sy < 0) { sy = 0; sy1 = 0; fy = 0.f; }
+    if (sy >= H - 1) { sy = H - 1; sy1 = H - 1; fy = 0.f; }
+    auto nv = [&](int yy, int xx) { return ((vox(vol, dt, base + (size_t)yy * W + xx) * slope + inter) - mean) * inv_std; };
+    const float r0 = nv(sy, sx) * (1.f - fx) + nv(sy, sx1) * fx;
+    const float r1 = nv(sy1, sx) * (1.f - fx) + nv(sy1, sx1) * fx;
+    v = r0 * (1.f - fy) + r1 * fy;
+  }
+  for (int c = 0; c < tile; ++c) out[(((size_t)z * tile + c) * S + y) * S + x] = v;
+}
+extern "C" int psam_volume_slices(const void* vol, int vol_dtype, int Z, int H, int W, float slope, float inter, float mean,
+                                  float inv_std, int S, int tile, int mode, float* out, void* stream) {
+  if (Z <= 0 || H <= 0 || W <= 0 || S <= 0 || tile <= 0 || vol_dtype < 0 || vol_dtype > 3 || mode < 0 || mode > 1)
+    return PSAM_ERR_ARG;
+  hipLaunchKernelGGL(volume_slices_kernel, dim3((S + 255) / 256, S, Z), dim3(256), 0, (hipStream_t)stream, vol, vol_dtype, H,
+                     W, slope, inter, mean, inv_std, S, tile, mode, out);
+  return psam_launch_status();
+}

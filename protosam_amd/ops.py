@@ -510,6 +510,26 @@ def decode_point_key(key, W):
     return idx % W, idx // W, struct.unpack("<f", struct.pack("<I", key >> 32))[0]
 
 
+def volume_stats(vol, vol_dtype, slope=1.0, inter=0.0):
+    """fp64 [2] = {sum(x), sum(x^2)} of x = voxel*slope + inter over a raw device volume (psam_volume_stats)."""
+    assert vol.is_cuda and vol.is_contiguous()
+    out = torch.empty(2, dtype=torch.float64, device=vol.device)
+    st = _lib.lib().psam_volume_stats(_ptr(vol), vol_dtype, vol.numel(), float(slope), float(inter), _ptr(out), _stream())
+    _lib.check(st, "psam_volume_stats")
+    return out
+
+
+def volume_slices(vol, vol_dtype, Z, H, W, slope, inter, mean, inv_std, S, tile, mode, out=None):
+    """fp32 [Z,tile,S,S]: normalise + cv2-style resize (mode 0 linear, 1 nearest) + channel tiling (psam_volume_slices)."""
+    assert vol.is_cuda and vol.is_contiguous()
+    if out is None:
+        out = torch.empty((Z, tile, S, S), dtype=torch.float32, device=vol.device)
+    st = _lib.lib().psam_volume_slices(_ptr(vol), vol_dtype, Z, H, W, float(slope), float(inter), float(mean), float(inv_std),
+                                      S, tile, mode, _ptr(out), _stream())
+    _lib.check(st, "psam_volume_slices")
+    return out
+
+
 def bilinear_tokens(tok, in_bstride, ld, B, ih, iw, C, oh, ow, out=None):
     """fp32 token-major [B][ih*iw, C] (strided) -> contiguous [B, oh*ow, C]."""
     _req(tok, torch.float32, "tok")
