@@ -19,6 +19,8 @@ extern "C" {
 /* ---- contraction engine --------------------------------------------------------------------------------------
  * out[M,N] = epi(A[M,K] . W[N,K]^T + bias[N]); A, W half (K contiguous), fp32 accumulate on MFMA.
  * epilogue 0: half out;  1: half out = gelu_erf(.);  2: fp32 out = (resid ? resid[r,:] : 0) + (gamma ? gamma : 1)*(.)
+ *   3: half out = relu(. + resid16[m,:]) with `resid` pointing at a HALF [*, ldr] map or null (conv + folded BatchNorm
+ *   (+ identity) + ReLU of a torchvision ResNet Bottleneck; models/backbone/torchvision_backbones.py:19-23)
  *   resid row r = resid_mod ? m % resid_mod : m.  out row = out_seg ? (m/out_seg)*out_seg_stride + out_seg_off + m%out_seg : m.
  * N % 128 == 0, K % 64 == 0. Replaces every nn.Linear / 1x1 conv / patch-embed conv / ConvTranspose2d(2,2) GEMM:
  *   models/segment_anything/modeling/image_encoder.py:223-249 (qkv, proj), modeling/common.py:13-26 (MLPBlock),
@@ -168,6 +170,15 @@ int psam_neg_points(const int* labels, const float* pbg, const double* tab, int 
 int psam_volume_stats(const void* vol, int vol_dtype, long long n, float slope, float inter, double* out, void* stream);
 int psam_volume_slices(const void* vol, int vol_dtype, int Z, int H, int W, float slope, float inter, float mean,
                        float inv_std, int S, int tile, int mode, float* out, void* stream);
+
+/* Convolution front-end of the ResNet-101 encoder (models/backbone/torchvision_backbones.py:12-52; torchvision's
+ * deeplabv3_resnet101 backbone, output stride 8): im2col on token-major (NHWC) half maps for any kernel / stride / dilation /
+ * padding, the 7x7 stride-2 stem straight from the fp32 NCHW image, and MaxPool2d(3, 2, 1). The convolutions themselves are
+ * psam_gemm_f16 with BatchNorm folded into weights and bias (epilogue 3). */
+int psam_im2col(const void* in, int B, int H, int W, int C, int kh, int kw, int stride, int dil, int pad, int ldo, void* out,
+                void* stream);
+int psam_im2col_stem(const float* img, int B, int H, int W, int ldo, void* out, void* stream);
+int psam_maxpool3x3s2(const void* in, int B, int H, int W, int C, void* out, void* stream);
 
 #ifdef __cplusplus
 }

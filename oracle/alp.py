@@ -104,3 +104,18 @@ def fewshot_forward(encode_fn, supp_img, fg_mask, qry_img, image_size, proto_gri
     if taps is not None:
         taps["pred_grid"] = pred
     return F.interpolate(pred, size=supp_img.shape[-2:], mode="bilinear")             # :272-273
+
+
+def fewshot_forward_resnet(encode_map_fn, supp_img, fg_mask, qry_img, image_size, proto_grid_size=8, val_wsize=2, taps=None):
+    """FewShotSeg.forward with `which_model = 'dlfcn_res101'` (grid_proto_fewshot.py:49-53,84-85): no resize to a patch
+    multiple, features [B,256,ceil(S/8),ceil(S/8)] straight from the encoder. encode_map_fn(imgs[B,3,S,S]) -> [B,C,h,w]."""
+    import math
+    imgs = torch.cat([supp_img, qry_img], dim=0)
+    fm = encode_map_fn(imgs)
+    feature_hw = math.ceil(image_size / 8)
+    assert fm.shape[-1] == feature_hw
+    ks = feature_hw // proto_grid_size
+    if taps is not None:
+        taps["img_fts"] = fm
+    pred = fewshot_scores(fm[1:2], fm[0:1], fg_mask, ks, val_wsize, taps)
+    return F.interpolate(pred, size=supp_img.shape[-2:], mode="bilinear")

@@ -47,6 +47,9 @@ SIGNATURES = {
     "psam_mask_union": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p],
     "psam_mask_stats": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
                         c_void_p, c_void_p],
+    "psam_im2col": [c_void_p] + [c_int] * 10 + [c_void_p, c_void_p],
+    "psam_im2col_stem": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "psam_maxpool3x3s2": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "psam_volume_stats": [c_void_p, c_int, ctypes.c_longlong, c_float, c_float, c_void_p, c_void_p],
     "psam_volume_slices": [c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_int, c_int, c_int,
                            c_void_p, c_void_p],

@@ -22,14 +22,14 @@
 #include <stdlib.h>
 #include <type_traits>
 
-enum { EPI_F16 = 0, EPI_GELU_F16 = 1, EPI_F32 = 2 };
+enum { EPI_F16 = 0, EPI_GELU_F16 = 1, EPI_F32 = 2, EPI_RELU_F16 = 3 };
 
 struct GemmArgs {
   const half_t* A;
   const half_t* W;
   const float* bias;   // [N] or null
   void* out;           // half or float [*, ldo]
-  const float* resid;  // float [*, ldr] or null (EPI_F32 only)
+  const float* resid;  // EPI_F32: float [*, ldr] or null; EPI_RELU_F16: HALF [*, ldr] or null (out = relu(acc + bias + resid))
   const float* gamma;  // [N] or null (EPI_F32 only): out = resid + gamma * (acc + bias)
   int M, N, K;
   int lda, ldw, ldo, ldr;
@@ -193,6 +193,13 @@ __device__ __forceinline__ void slab_emit(const float* __restrict__ slab, int mb
       *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(p.out) + orow * p.ldo + n) = h;
     } else if (EPI == EPI_GELU_F16) {
       half4_t h = {(half_t)gelu_erf(v.x), (half_t)gelu_erf(v.y), (half_t)gelu_erf(v.z), (half_t)gelu_erf(v.w)};
+      *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(p.out) + orow * p.ldo + n) = h;
+    } else if (EPI == EPI_RELU_F16) {  // conv + folded BatchNorm (+ identity) + ReLU of a ResNet bottleneck
+      if (p.resid) {
+        const half4_t r = *reinterpret_cast<const half4_t*>(reinterpret_cast<const half_t*>(p.resid) + (size_t)m * p.ldr + n);
+        v.x += (float)r[0]; v.y += (float)r[1]; v.z += (float)r[2]; v.w += (float)r[3];
+      }
+      half4_t h = {(half_t)fmaxf(v.x, 0.f), (half_t)fmaxf(v.y, 0.f), (half_t)fmaxf(v.z, 0.f), (half_t)fmaxf(v.w, 0.f)};
       *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(p.out) + orow * p.ldo + n) = h;
     } else {
       v.x *= gv.x; v.y *= gv.y; v.z *= gv.z; v.w *= gv.w;
@@ -1085,7 +1092,7 @@ extern "C" int psam_gemm_f16(const void* A, const void* W, const float* bias, vo
   if (M <= 0 || N <= 0 || K <= 0 || (N % BN) != 0 || (K % BK) != 0 || (lda % 8) != 0 || (ldw % 8) != 0 ||
       (ldo % 4) != 0 || (resid && (ldr % 4) != 0))
     return PSAM_ERR_ARG;
-  if (epilogue < 0 || epilogue > 2) return PSAM_ERR_ARG;
+  if (epilogue < 0 || epilogue > 3) return PSAM_ERR_ARG;
   GemmArgs p;
   p.A = (const half_t*)A;
   p.W = (const half_t*)W;
@@ -1109,7 +1116,7 @@ extern "C" int psam_gemm_f16(const void* A, const void* W, const float* bias, vo
   const int ntm = (M + BM - 1) / BM, ntn = N / BN;
   dim3 grid(tile_map_grid(ntm, ntn, p.map_mode)), block(256);
   hipStream_t s = (hipStream_t)stream;
-  const int tsel = pick_tile(M, N, K, epilogue);
+  const int tsel = epilogue == EPI_RELU_F16 ? 1 : pick_tile(M, N, K, epilogue);  // the ReLU epilogue lives in the 128x128 kernel
   if ((tsel == 3 || tsel == 5) && N % 256 == 0) {
     if (tsel == 3) {
       if (epilogue == EPI_F16) launch256<EPI_F16, 256, 1>(p, s);
@@ -1150,6 +1157,7 @@ extern "C" int psam_gemm_f16(const void* A, const void* W, const float* bias, vo
   switch (epilogue) {
     case EPI_F16: hipLaunchKernelGGL(gemm_f16_kernel<EPI_F16>, grid, block, 0, s, p); break;
     case EPI_GELU_F16: hipLaunchKernelGGL(gemm_f16_kernel<EPI_GELU_F16>, grid, block, 0, s, p); break;
+    case EPI_RELU_F16: hipLaunchKernelGGL(gemm_f16_kernel<EPI_RELU_F16>, grid, block, 0, s, p); break;
     default: hipLaunchKernelGGL(gemm_f16_kernel<EPI_F32>, grid, block, 0, s, p); break;
   }
   return psam_launch_status();

@@ -411,3 +411,82 @@ extern "C" int psam_volume_slices(const void* vol, int vol_dtype, int Z, int H, 
                      W, slope, inter, mean, inv_std, S, tile, mode, out);
   return psam_launch_status();
 }
+
+// ---- convolution front-end for the ResNet-101 encoder (models/backbone/torchvision_backbones.py:12-52) -----------------
+// General im2col on token-major (NHWC) half maps: in [B, H*W, C] -> out [B*Ho*Wo, ldo] with column (ky*kw + kx)*C + c =
+// in[b, (y*stride - pad + ky*dil), (x*stride - pad + kx*dil), c] or 0 outside; columns kh*kw*C .. ldo-1 are zero (K padding
+// for the GEMM). C % 8 == 0. The 1x1 / stride-2 "downsample" conv is the same kernel with kh = kw = 1.
+__global__ void im2col_kernel(const half_t* __restrict__ in, int H, int W, int C, int kh, int kw, int stride, int dil,
+                              int pad, int Ho, int Wo, int ldo, half_t* __restrict__ out) {
+  const int pix = blockIdx.x, b = blockIdx.y;
+  const int y = pix / Wo, x = pix % Wo;
+  const int cv = C / 8, taps = kh * kw, nv = ldo / 8;
+  uint4* o = reinterpret_cast<uint4*>(out + ((size_t)b * Ho * Wo + pix) * ldo);
+  for (int i = threadIdx.x; i < nv; i += blockDim.x) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    const int tap = i / cv, c = i % cv;
+    if (tap < taps) {
+      const int yy = y * stride - pad + (tap / kw) * dil, xx = x * stride - pad + (tap % kw) * dil;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+        v = reinterpret_cast<const uint4*>(in + ((size_t)b * H * W + (size_t)yy * W + xx) * C)[c];
+    }
+    o[i] = v;
+  }
+}
+extern "C" int psam_im2col(const void* in, int B, int H, int W, int C, int kh, int kw, int stride, int dil, int pad, int ldo,
+                           void* out, void* stream) {
+  if (B <= 0 || (C % 8) != 0 || (ldo % 8) != 0 || ldo < kh * kw * C || stride <= 0 || dil <= 0) return PSAM_ERR_ARG;
+  const int Ho = (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
+  if (Ho <= 0 || Wo <= 0) return PSAM_ERR_ARG;
+  hipLaunchKernelGGL(im2col_kernel, dim3(Ho * Wo, B), dim3(256), 0, (hipStream_t)stream, (const half_t*)in, H, W, C, kh, kw,
+                     stride, dil, pad, Ho, Wo, ldo, (half_t*)out);
+  return psam_launch_status();
+}
+
+// Stem: im2col of the 7x7 / stride 2 / pad 3 conv straight from the fp32 NCHW image: out [B*Ho*Wo, ldo] half with
+// column (c*7 + ky)*7 + kx (the weight's own [Cout, Cin, 7, 7] order), zero beyond 147.
+__global__ void im2col_stem_kernel(const float* __restrict__ img, int H, int W, int Ho, int Wo, int ldo,
+                                   half_t* __restrict__ out) {
+  const int pix = blockIdx.x, b = blockIdx.y;
+  const int y = pix / Wo, x = pix % Wo;
+  half_t* o = out + ((size_t)b * Ho * Wo + pix) * ldo;
+  for (int i = threadIdx.x; i < ldo; i += blockDim.x) {
+    float v = 0.f;
+    if (i < 147) {
+      const int c = i / 49, ky = (i % 49) / 7, kx = i % 7;
+      const int yy = y * 2 - 3 + ky, xx = x * 2 - 3 + kx;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = img[(((size_t)b * 3 + c) * H + yy) * W + xx];
+    }
+    o[i] = (half_t)v;
+  }
+}
+extern "C" int psam_im2col_stem(const float* img, int B, int H, int W, int ldo, void* out, void* stream) {
+  if (B <= 0 || ldo < 147 || (ldo % 8) != 0) return PSAM_ERR_ARG;
+  const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+  hipLaunchKernelGGL(im2col_stem_kernel, dim3(Ho * Wo, B), dim3(64), 0, (hipStream_t)stream, img, H, W, Ho, Wo, ldo,
+                     (half_t*)out);
+  return psam_launch_status();
+}
+
+// MaxPool2d(3, stride 2, padding 1) on a token-major half map [B, H*W, C] -> [B, Ho*Wo, C]
+__global__ void maxpool3x3s2_kernel(const half_t* __restrict__ in, int H, int W, int C, int Ho, int Wo,
+                                    half_t* __restrict__ out) {
+  const int pix = blockIdx.x, b = blockIdx.y;
+  const int y = pix / Wo, x = pix % Wo;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float m = -INFINITY;
+    for (int ky = 0; ky < 3; ++ky)
+      for (int kx = 0; kx < 3; ++kx) {
+        const int yy = 2 * y - 1 + ky, xx = 2 * x - 1 + kx;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) m = fmaxf(m, (float)in[((size_t)b * H * W + (size_t)yy * W + xx) * C + c]);
+      }
+    out[((size_t)b * Ho * Wo + pix) * C + c] = (half_t)m;
+  }
+}
+extern "C" int psam_maxpool3x3s2(const void* in, int B, int H, int W, int C, void* out, void* stream) {
+  if (B <= 0 || C <= 0) return PSAM_ERR_ARG;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(Ho * Wo, B), dim3(128), 0, (hipStream_t)stream, (const half_t*)in, H, W, C,
+                     Ho, Wo, (half_t*)out);
+  return psam_launch_status();
+}

@@ -9,6 +9,7 @@ results:
   * the support image's features and prototype bank are cached across calls while the support tensors are
     unchanged (the reference re-encodes the support on every slice, :181-184; same values).
     `cache_support=False` reproduces the reference's per-call cost.
+`which_model = 'dlfcn_res101'` selects the ResNet-101 encoder of `protosam_amd/backbone.py` (feature map ceil(S/8)).
 Out of scope here (training only): alignLoss, dino losses, LoRA injection (`lora` must be 0).
 """
 import math
@@ -36,6 +37,7 @@ class FewShotSeg(nn.Module):
         self.pretrained_path = pretrained_path
         self.config = cfg or {"align": False, "debug": False}
         self.cache_support = cache_support
+        self._is_vit = self.config["which_model"] in _HUB_NAME
         self.get_encoder()
         self.get_cls()
         self._sup_cache = []
@@ -49,10 +51,12 @@ class FewShotSeg(nn.Module):
             self.encoder = DinoVisionTransformer(_HUB_NAME[which], depth=self.config.get("encoder_depth"))
             s = max(self.image_size // 14, DEFAULT_FEATURE_SIZE)
             self.config["feature_hw"] = [s, s]
-        elif which in ("dlfcn_res101", "default"):
-            raise NotImplementedError(
-                "dlfcn_res101 (torchvision DeepLabV3-ResNet101, models/backbone/torchvision_backbones.py) is the "
-                "reference's CPU-only baseline backbone and is not part of the MI355X hot path")
+        elif which in ("dlfcn_res101", "default"):                              # :49-53
+            from .backbone import TVDeeplabRes101Encoder
+            self.encoder = TVDeeplabRes101Encoder(self.config.get("use_coco_init", False),
+                                                  layers=self.config.get("resnet_layers", (3, 4, 23, 3)))
+            s = math.ceil(self.image_size / 8)
+            self.config["feature_hw"] = [s, s]
         else:
             raise NotImplementedError(f"Backbone network {which} not implemented")
         if self.config.get("lora", 0) > 0:
@@ -68,6 +72,8 @@ class FewShotSeg(nn.Module):
     # ---- features ------------------------------------------------------------------------------------------------
     def _grid(self):
         """(S, g): encoder input side and the side of the feature map the classifier sees (>= 32, :96-98)."""
+        if not self._is_vit:
+            return self.image_size, math.ceil(self.image_size / 8)
         S = self.image_size // 14 * 14
         return S, max(S // 14, DEFAULT_FEATURE_SIZE)
 
@@ -75,6 +81,12 @@ class FewShotSeg(nn.Module):
         """imgs [B,3,H,W] -> token-major patch features fp32 [B, g*g, C] (view of a workspace, or the 32x32 bilinear
         upsample of it when the encoder yields fewer patches) plus (batch stride, row stride) in elements."""
         S, g = self._grid()
+        if not self._is_vit:
+            if self.config["which_model"] != "dlfcn_res101":                    # get_features has no 'default' branch (:99-101)
+                raise NotImplementedError(f'Backbone network {self.config["which_model"]} not implemented')
+            tok, h, w = self.encoder.forward_tokens(imgs.float())
+            assert h == g and w == g, (h, w, g)
+            return tok, g * g * self.encoder.embed_dim, self.encoder.embed_dim
         ge = S // 14
         C = self.encoder.embed_dim
         R = self.encoder.num_register_tokens

@@ -4,7 +4,7 @@ import torch
 
 from . import _lib
 
-EPI_F16, EPI_GELU_F16, EPI_F32 = 0, 1, 2
+EPI_F16, EPI_GELU_F16, EPI_F32, EPI_RELU_F16 = 0, 1, 2, 3
 
 
 def _stream():
@@ -56,7 +56,8 @@ def gemm(a, w, bias=None, out=None, epilogue=EPI_F16, resid=None, gamma=None, re
          out_seg_stride=0, out_seg_off=0, M=None):
     """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias). a/w fp16 (K contiguous); out fp16 or fp32 by epilogue."""
     _req(a, torch.float16, "a"); _req(w, torch.float16, "w")
-    _req(bias, torch.float32, "bias"); _req(resid, torch.float32, "resid"); _req(gamma, torch.float32, "gamma")
+    _req(bias, torch.float32, "bias"); _req(gamma, torch.float32, "gamma")
+    _req(resid, torch.float16 if epilogue == EPI_RELU_F16 else torch.float32, "resid")   # epilogue 3 adds a half map
     a2 = a.reshape(-1, a.shape[-1]) if a.dim() != 2 else a
     if M is None:
         M = a2.shape[0]
@@ -85,6 +86,45 @@ def gemm(a, w, bias=None, out=None, epilogue=EPI_F16, resid=None, gamma=None, re
 def gemm_set_tile(tile):
     """0 auto, 1 = 128x128, 2 = 256x128, 3 = 256x256 (see csrc/gemm.hip)."""
     _lib.check(_lib.lib().psam_gemm_set_tile(int(tile)), "psam_gemm_set_tile")
+
+
+def im2col(x, B, H, W, C, kh, kw, stride, dil, pad, ldo=None, out=None):
+    """token-major half map [B, H*W, C] -> half [B*Ho*Wo, ldo] (column (ky*kw+kx)*C + c; zero K padding up to ldo)."""
+    _req(x, torch.float16, "x")
+    assert x.is_contiguous()
+    Ho = (H + 2 * pad - dil * (kh - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+    if ldo is None:
+        ldo = kh * kw * C
+    if out is None:
+        out = torch.empty((B * Ho * Wo, ldo), dtype=torch.float16, device=x.device)
+    st = _lib.lib().psam_im2col(_ptr(x), B, H, W, C, kh, kw, stride, dil, pad, ldo, _ptr(out), _stream())
+    _lib.check(st, "psam_im2col")
+    return out, Ho, Wo
+
+
+def im2col_stem(img, ldo=192, out=None):
+    """fp32 NCHW [B,3,H,W] -> half [B*Ho*Wo, ldo] patches of the 7x7 / stride 2 / pad 3 stem conv."""
+    _req(img, torch.float32, "img")
+    assert img.is_contiguous() and img.shape[1] == 3
+    B, _, H, W = img.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if out is None:
+        out = torch.empty((B * Ho * Wo, ldo), dtype=torch.float16, device=img.device)
+    st = _lib.lib().psam_im2col_stem(_ptr(img), B, H, W, ldo, _ptr(out), _stream())
+    _lib.check(st, "psam_im2col_stem")
+    return out, Ho, Wo
+
+
+def maxpool3x3s2(x, B, H, W, C, out=None):
+    _req(x, torch.float16, "x")
+    assert x.is_contiguous()
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if out is None:
+        out = torch.empty((B * Ho * Wo, C), dtype=torch.float16, device=x.device)
+    st = _lib.lib().psam_maxpool3x3s2(_ptr(x), B, H, W, C, _ptr(out), _stream())
+    _lib.check(st, "psam_maxpool3x3s2")
+    return out, Ho, Wo
 
 
 def layernorm(x, weight, bias, eps, out=None, out_dtype=torch.float16, out2=None, zero_tail_rows=0, M=None):

@@ -36,6 +36,10 @@ def synth_tensor(name, shape, seed):
         return torch.rand(shape, generator=g) * 0.5 + 0.5
     if last == "positional_encoding_gaussian_matrix":
         return n(1.0)
+    if last == "running_var":
+        return torch.rand(shape, generator=g) * 0.5 + 0.75   # BatchNorm statistics: strictly positive
+    if last == "num_batches_tracked":
+        return torch.zeros(shape)
     if last == "bias":
         return n(0.1)
     if last == "weight":

@@ -171,3 +171,71 @@ def test_fewshot_forward_small_image_upsamples_features(dev):
         perr = (out.softmax(1) - ref.softmax(1)).abs().max().item()
         print(f"image_size {size}: max |dprob| vs REFERENCE golden {perr:.3e}")
         assert out.shape == ref.shape and perr < 1e-3
+
+
+def test_conv_frontend_kernels(dev):
+    """psam_im2col (any kernel / stride / dilation / padding), the 7x7 stem im2col and MaxPool2d(3,2,1) against torch's
+    unfold / max_pool2d, and the conv + folded-BN + identity + ReLU GEMM epilogue (epilogue 3)."""
+    import torch.nn.functional as F
+    from protosam_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, H, W, C = 2, 19, 23, 64
+    x = torch.randn((B, C, H, W), generator=g).half()
+    tok = x.permute(0, 2, 3, 1).reshape(B, H * W, C).contiguous().to(dev)
+    for (k, stride, dil, pad) in ((3, 1, 1, 1), (3, 2, 1, 1), (3, 1, 2, 2), (3, 1, 4, 4), (1, 2, 1, 0)):
+        cols, Ho, Wo = ops.im2col(tok, B, H, W, C, k, k, stride, dil, pad, ldo=k * k * C + 64)
+        ref = F.unfold(x.float(), k, dilation=dil, padding=pad, stride=stride)          # [B, C*k*k, L], (c, ky, kx) order
+        ref = ref.view(B, C, k * k, Ho * Wo).permute(0, 3, 2, 1).reshape(B * Ho * Wo, k * k * C)
+        got = cols.cpu().float()
+        assert torch.equal(got[:, :k * k * C], ref) and float(got[:, k * k * C:].abs().max()) == 0.0
+    img = torch.randn((B, 3, 37, 41), generator=g)
+    cols, Ho, Wo = ops.im2col_stem(img.to(dev), 192)
+    ref = F.unfold(img, 7, padding=3, stride=2).permute(0, 2, 1).reshape(B * Ho * Wo, 147)
+    assert torch.equal(cols.cpu()[:, :147], ref.half()) and float(cols.cpu()[:, 147:].abs().max()) == 0.0
+    mp, Ho, Wo = ops.maxpool3x3s2(tok, B, H, W, C)
+    ref = F.max_pool2d(x.float(), 3, 2, 1).permute(0, 2, 3, 1).reshape(B * Ho * Wo, C)
+    assert torch.equal(mp.cpu().float(), ref)
+    # epilogue 3: relu(a @ w^T + bias + resid16)
+    M, N, K = 300, 256, 192
+    a = torch.randn((M, K), generator=g).half().to(dev)
+    w = (torch.randn((N, K), generator=g) / K ** 0.5).half().to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    r = torch.randn((M, N), generator=g).half().to(dev)
+    for resid in (None, r):
+        out = ops.gemm(a, w, bias, epilogue=ops.EPI_RELU_F16, resid=resid)
+        ref = a.float() @ w.float().t() + bias + (resid.float() if resid is not None else 0)
+        assert out.dtype == torch.float16 and (out.float() - ref.clamp_min(0)).abs().max().item() < 2e-2
+
+
+def test_resnet101_encoder_and_config1_fewshot(dev):
+    """BASELINE config 1's coarse model on the GPU: ResNet-101 (output stride 8) + localconv features and the ALPNet logits
+    of a 256x256 support / query pair, against the oracle's restatement (torchvision absent: parity unpinned)."""
+    from oracle import alp as oalp, resnet as ores
+    from protosam_amd.grid_proto_fewshot import FewShotSeg
+    from protosam_amd.synth import synth_pair, synth_state_dict
+    cfg = {"which_model": "dlfcn_res101", "cls_name": "grid_proto", "proto_grid_size": 8, "lora": 0, "use_coco_init": False,
+           "align": False, "debug": False}
+    alp = FewShotSeg(256, None, cfg)
+    sd = synth_state_dict(alp, 1234)
+    alp.load_state_dict(sd, strict=True)
+    alp = alp.to(dev).eval()
+    assert alp.config["feature_hw"] == [32, 32] and alp.cls_unit.kernel_size[0] == 4
+    s_img, s_m, q_img, _ = synth_pair(256, seed=0)
+    enc_sd = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+    imgs = torch.cat([s_img, q_img])
+    ref = ores.encoder(imgs, enc_sd)                                            # [2,256,32,32]
+    got = alp.get_features(imgs.to(dev)).cpu()
+    scale = ref.abs().max().item()
+    err = (got - ref).abs().max().item()
+    cos = torch.nn.functional.cosine_similarity(got.flatten(1), ref.flatten(1)).min().item()
+    print(f"ResNet-101 features: max abs err {err:.3e} on values up to {scale:.1f} (rms {ref.pow(2).mean().sqrt():.2f}), cos {cos:.6f}")
+    assert err < 1e-2 * scale and cos > 0.9999
+    out = alp([[s_img.to(dev)]], [[s_m.to(dev)]], [[(1 - s_m).to(dev)]], [q_img.to(dev)], isval=True, val_wsize=2)[0]
+    logits_ref = oalp.fewshot_forward_resnet(lambda im: ores.encoder(im, enc_sd), s_img, s_m, q_img, 256)
+    assert out.shape == (1, 2, 256, 256)
+    perr = (out.cpu().softmax(1) - logits_ref.softmax(1)).abs().max().item()
+    print(f"config 1 coarse probability map: max abs err {perr:.3e}")
+    assert perr < 5e-3
+    with pytest.raises(NotImplementedError):                                    # get_features has no 'default' branch
+        bad = FewShotSeg(256, None, dict(cfg, which_model="default", resnet_layers=(1, 1, 1, 1))).to(dev).eval()
+        bad.get_features(imgs.to(dev))
