@@ -27,6 +27,17 @@ PATCH = 14
 LN_EPS = 1e-6
 
 
+def _linear(sd, pre, x, lora_scale=1.0):
+    """nn.Linear, or util/lora.py's LoraInjectedLinear (:34-59) when the state dict carries an injected layer
+    (`<pre>linear.{weight,bias}`, `<pre>lora_down.weight` [r,in], `<pre>lora_up.weight` [out,r]; eval: dropout is the
+    identity, selector is nn.Identity, scale = 1.0 as inject_trainable_lora's default, :265):
+    linear(x) + lora_up(lora_down(x)) * scale."""
+    if pre + "linear.weight" in sd:
+        y = F.linear(x, sd[pre + "linear.weight"], sd.get(pre + "linear.bias"))
+        return y + F.linear(F.linear(x, sd[pre + "lora_down.weight"]), sd[pre + "lora_up.weight"]) * lora_scale
+    return F.linear(x, sd[pre + "weight"], sd[pre + "bias"])
+
+
 def interpolate_pos_encoding(pos_embed, npatch_side_w, npatch_side_h, antialias=False, offset=0.1):
     """Bicubic resample of the (M x M) patch part of pos_embed to (w0 x h0); cls part untouched.
     With offset != 0 the hub passes scale_factor=((w0+offset)/M, (h0+offset)/M) (so the sampling
@@ -52,12 +63,12 @@ def interpolate_pos_encoding(pos_embed, npatch_side_w, npatch_side_h, antialias=
 def attention(x, sd, pre, num_heads):
     B, N, C = x.shape
     hd = C // num_heads
-    qkv = F.linear(x, sd[pre + "qkv.weight"], sd[pre + "qkv.bias"]).reshape(B, N, 3, num_heads, hd)
+    qkv = _linear(sd, pre + "qkv.", x).reshape(B, N, 3, num_heads, hd)
     qkv = qkv.permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0] * hd ** -0.5, qkv[1], qkv[2]
     a = (q @ k.transpose(-2, -1)).softmax(dim=-1)
     o = (a @ v).transpose(1, 2).reshape(B, N, C)
-    return F.linear(o, sd[pre + "proj.weight"], sd[pre + "proj.bias"])
+    return _linear(sd, pre + "proj.", o)
 
 
 def block(x, sd, pre, num_heads):
@@ -65,8 +76,8 @@ def block(x, sd, pre, num_heads):
     y = F.layer_norm(x, (C,), sd[pre + "norm1.weight"], sd[pre + "norm1.bias"], LN_EPS)
     x = x + sd[pre + "ls1.gamma"] * attention(y, sd, pre + "attn.", num_heads)
     y = F.layer_norm(x, (C,), sd[pre + "norm2.weight"], sd[pre + "norm2.bias"], LN_EPS)
-    y = F.linear(y, sd[pre + "mlp.fc1.weight"], sd[pre + "mlp.fc1.bias"])
-    y = F.linear(F.gelu(y), sd[pre + "mlp.fc2.weight"], sd[pre + "mlp.fc2.bias"])
+    y = _linear(sd, pre + "mlp.fc1.", y)
+    y = _linear(sd, pre + "mlp.fc2.", F.gelu(y))
     return x + sd[pre + "ls2.gamma"] * y
 
 

@@ -10,7 +10,8 @@ results:
     unchanged (the reference re-encodes the support on every slice, :181-184; same values).
     `cache_support=False` reproduces the reference's per-call cost.
 `which_model = 'dlfcn_res101'` selects the ResNet-101 encoder of `protosam_amd/backbone.py` (feature map ceil(S/8)).
-Out of scope here (training only): alignLoss, dino losses, LoRA injection (`lora` must be 0).
+Checkpoints trained with `lora > 0` load through `collapse_lora_state_dict` (the low-rank update is folded into the base
+weights; util/lora.py:638-672). Out of scope here (training only): alignLoss, dino losses, LoRA training.
 """
 import math
 
@@ -28,6 +29,25 @@ FG_THRESH = 0.95
 BG_THRESH = 0.95
 
 _HUB_NAME = {"dinov2_b14": "dinov2_vitb14", "dinov2_l14": "dinov2_vitl14", "dinov2_l14_reg": "dinov2_vitl14_reg"}
+
+
+def collapse_lora_state_dict(sd, scale=1.0):
+    """LoraInjectedLinear keys -> plain nn.Linear keys with the low-rank update folded in (fp32)."""
+    if not any(k.endswith(".lora_up.weight") for k in sd):
+        return sd
+    out = {}
+    for k, v in sd.items():
+        if k.endswith(".linear.weight"):
+            p = k[:-len("linear.weight")]
+            up, down = sd[p + "lora_up.weight"].float(), sd[p + "lora_down.weight"].float()
+            out[p + "weight"] = v.float() + scale * (up @ down)
+        elif k.endswith(".linear.bias"):
+            out[k[:-len("linear.bias")] + "bias"] = v
+        elif k.endswith(".lora_up.weight") or k.endswith(".lora_down.weight") or ".selector." in k:
+            continue
+        else:
+            out[k] = v
+    return out
 
 
 class FewShotSeg(nn.Module):
@@ -59,8 +79,8 @@ class FewShotSeg(nn.Module):
             self.config["feature_hw"] = [s, s]
         else:
             raise NotImplementedError(f"Backbone network {which} not implemented")
-        if self.config.get("lora", 0) > 0:
-            raise NotImplementedError("LoRA injection is a fine-tuning feature (util/lora.py); inference uses lora=0")
+        # lora > 0 (util/lora.py:258-312 replaces every nn.Linear of the DINOv2 blocks by LoraInjectedLinear): inference needs
+        # no second path - `load_state_dict` folds `lora_up @ lora_down` into the base weight (collapse_lora, :638-672)
 
     def get_cls(self):
         proto_hw = self.config["proto_grid_size"]
@@ -68,6 +88,12 @@ class FewShotSeg(nn.Module):
             raise NotImplementedError(f'Classifier {self.config["cls_name"]} not implemented')
         self.cls_unit = MultiProtoAsConv(proto_grid=[proto_hw, proto_hw], feature_hw=self.config["feature_hw"],
                                          embed_dim=self.encoder.embed_dim)
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        """Accepts the reference's checkpoints, including those trained with `lora > 0`: the injected layers' keys
+        (`<p>.linear.weight`, `<p>.linear.bias`, `<p>.lora_down.weight`, `<p>.lora_up.weight`) are collapsed to
+        `<p>.weight = W + scale * up @ down` (scale = 1.0, inject_trainable_lora's default; util/lora.py:34-59,638-672)."""
+        return super().load_state_dict(collapse_lora_state_dict(state_dict), strict=strict, **kw)
 
     # ---- features ------------------------------------------------------------------------------------------------
     def _grid(self):

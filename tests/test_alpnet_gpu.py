@@ -239,3 +239,43 @@ def test_resnet101_encoder_and_config1_fewshot(dev):
     with pytest.raises(NotImplementedError):                                    # get_features has no 'default' branch
         bad = FewShotSeg(256, None, dict(cfg, which_model="default", resnet_layers=(1, 1, 1, 1))).to(dev).eval()
         bad.get_features(imgs.to(dev))
+
+
+def test_lora_checkpoint_collapses(dev):
+    """A checkpoint written by the reference with lora > 0 (LoraInjectedLinear keys, util/lora.py:34-59) loads into
+    FewShotSeg; features equal the oracle's two-path evaluation linear(x) + lora_up(lora_down(x))."""
+    from oracle import dinov2 as odino
+    from protosam_amd.grid_proto_fewshot import FewShotSeg
+    from protosam_amd.synth import synth_pair, synth_state_dict
+    cfg = dict(CFG, encoder_depth=2, lora=4)
+    alp = FewShotSeg(252, None, cfg)
+    base = synth_state_dict(alp, 77)
+    g = torch.Generator().manual_seed(5)
+    lora_sd = {}
+    for k, v in base.items():
+        if k.startswith("encoder.blocks.") and k.endswith(".weight") and v.dim() == 2:
+            p = k[:-len("weight")]
+            lora_sd[p + "linear.weight"] = v
+            lora_sd[p + "linear.bias"] = base[p + "bias"]
+            lora_sd[p + "lora_down.weight"] = torch.randn((4, v.shape[1]), generator=g) / 4
+            lora_sd[p + "lora_up.weight"] = torch.randn((v.shape[0], 4), generator=g) * 0.05
+        elif k.startswith("encoder.blocks.") and k.endswith(".bias") and (k[:-4] + "weight") in base and base[k[:-4] + "weight"].dim() == 2:
+            continue
+        else:
+            lora_sd[k] = v
+    assert any(k.endswith("lora_up.weight") for k in lora_sd) and len(lora_sd) > len(base)
+    alp.load_state_dict(lora_sd, strict=True)
+    alp = alp.to(dev).eval()
+    _, _, q_img, _ = synth_pair(252, seed=1)
+    got = alp.get_features(q_img.to(dev)).cpu()                                  # [1, C, 32, 32] (upsampled from 18x18)
+    enc_sd = {k[len("encoder."):]: v for k, v in lora_sd.items() if k.startswith("encoder.")}
+    import torch.nn.functional as F
+    tok = odino.forward_features(F.interpolate(q_img, size=(252, 252), mode="bilinear"), enc_sd, "dinov2_b14", depth=2)
+    ref = tok["x_norm_patchtokens"].permute(0, 2, 1).reshape(1, -1, 18, 18)
+    ref = F.interpolate(ref, size=(32, 32), mode="bilinear")
+    base_alp = FewShotSeg(252, None, dict(CFG, encoder_depth=2))
+    base_alp.load_state_dict(base)
+    plain = base_alp.to(dev).eval().get_features(q_img.to(dev)).cpu()
+    err = (got - ref).abs().max().item()
+    print(f"LoRA-collapsed features vs two-path oracle: max abs err {err:.3e}; LoRA effect {(got - plain).abs().max():.3f}")
+    assert err < 2e-2 and (got - plain).abs().max().item() > 0.05
