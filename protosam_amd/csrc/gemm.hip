@@ -1079,8 +1079,10 @@ static int pick_tile(int M, int N, int K, int epilogue) {
   if (N % 256 == 0) {
     const long t256 = (long)((M + 255) / 256) * (N / 256);
     const long rounds = (t256 + 255) / 256;
-    // the fp32 residual epilogue with a short K (proj: 20 K-tiles) is better served by two workgroups per CU
-    if (t256 * 10 >= rounds * 256 * 8 && K >= 1024 && !(epilogue == EPI_F32 && K < 2048)) return 7;
+    // the fp32 residual epilogue with a short K (proj: 20 K-tiles) is better served by two workgroups per CU unless the
+    // 256-tiles fill their rounds completely (65536x1280x1280: 603 vs 525 TFLOP/s; 32768x1280x1280, 2.5 rounds: 653 vs 689)
+    const bool short_f32 = epilogue == EPI_F32 && K < 2048;
+    if (K >= 1024 && t256 * 100 >= rounds * 256 * (short_f32 ? 95 : 80)) return 7;
   }
   return 1;
 }
