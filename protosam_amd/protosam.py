@@ -230,6 +230,9 @@ class ProtoSAM(nn.Module):
         self._ccl = None
         self._bufs = {}
         self.last_stats = {}
+        # measured on MI355X (tools/ab_env.sh PSAM_OVERLAP_STREAMS "1 0", 16-slice steps): 107.0 / 110.3 vs 108.2 / 107.8 slices/s -
+        # no gain (the encoder's GEMMs already fill the chip), and concurrent kernels blur per-kernel timing: off by default
+        self.overlap_streams = os.environ.get("PSAM_OVERLAP_STREAMS", "0") != "0"
 
     def get_sam(self, checkpoint_path, use_sam_trans):
         """ProtoSAM.py:205-220. `random:<vit_b|vit_l|vit_h>[:seed[:depth]]` builds seeded synthetic weights instead of reading a
@@ -316,10 +319,27 @@ class ProtoSAM(nn.Module):
                 q1024=torch.empty((B, 3, 1024, 1024), dtype=torch.float32, device=dev),
                 mm=torch.empty(2 * B, dtype=torch.int32, device=dev),
                 patches=torch.empty((B * 4096, 768), dtype=torch.float16, device=dev),
-                event=torch.cuda.Event())
+                event=torch.cuda.Event(), sam_done=torch.cuda.Event())
         if self._ccl is None or self._ccl.slots < B:
             self._ccl = ops.CclWorkspace(1024, 1024, MAX_COMPONENTS, dev, slots=max(B, 1))
         return self._bufs[key]
+
+    def _side_stream(self, dev):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=dev)
+        return self._side
+
+    def _sam_features(self, query_images, bufs, B, S):
+        """resize -> min/max -> uint8 quantise -> SAM normalise -> im2col -> image encoder (ProtoSAM.py:592-593,651-660,
+        predictor.set_image) on the current stream. -> token-major embeddings [B, 4096, 256]."""
+        sam = self.sam
+        q = query_images.float().contiguous()
+        if tuple(q.shape[-2:]) != (S, S):
+            q = ops.bilinear_nchw(q, S, S, out=bufs["q1024"])
+        ops.minmax(q, B, mm=bufs["mm"])
+        ops.sam_patchify(q, bufs["mm"], S, sam.image_encoder.patch_size, sam._mean_host, sam._std_host, True,
+                         out=bufs["patches"])
+        return sam.image_encoder.encode_patches(bufs["patches"], B)
 
     def forward(self, query_image, coarse_model_input, degrees_rotate=0):
         """Reference contract (ProtoSAM.py:536-678): one query slice [1,3,H,W] -> (pred [H,W] float {0,1}, scores)."""
@@ -341,11 +361,21 @@ class ProtoSAM(nn.Module):
         B = query_images.shape[0]
         original_size = query_images.shape[-2]
         dev = query_images.device
-        coarse_model_input.set_query_images(query_images)
-        output_logits = self.coarse_segmentation_model(coarse_model_input)      # [B,2,H,W]
         bufs = self._work_buffers(dev, B)
         sam = self.sam
         S = sam.image_encoder.img_size
+        # 0. The SAM image encoder depends on the query image only, not on the coarse model: with `overlap_streams` it is
+        #    enqueued on a second HIP stream so the two ViTs share the GPU (optional, see __init__)
+        main = torch.cuda.current_stream(dev)
+        side = self._side_stream(dev) if self.overlap_streams else None
+        feat_tok = None
+        if side is not None:
+            side.wait_stream(main)                                              # inputs / earlier work on `main` are visible
+            with torch.cuda.stream(side):
+                feat_tok = self._sam_features(query_images, bufs, B, S)
+                bufs["sam_done"].record(side)
+        coarse_model_input.set_query_images(query_images)
+        output_logits = self.coarse_segmentation_model(coarse_model_input)      # [B,2,H,W]
         # 1. (bilinear to 1024) -> softmax -> argmax                               ProtoSAM.py:592-602
         bufs["fg_sum"].zero_()
         output_p, pred = ops.prob_argmax(output_logits.float().contiguous(), S, S, prob=bufs["prob"], pred=bufs["pred"],
@@ -365,17 +395,15 @@ class ProtoSAM(nn.Module):
             nkh = bufs.setdefault("neg_keys_host", torch.empty((B, MAX_NEG_COMPONENTS + 1), dtype=torch.int64).pin_memory())
             nkh.copy_(bufs["neg_keys"], non_blocking=True)
         bufs["event"].record()
-        # 3. image hand-off: resize -> min/max -> uint8 quantise -> SAM normalise -> im2col      ProtoSAM.py:592-593,651-660
-        q = query_images.float().contiguous()
-        if tuple(q.shape[-2:]) != (S, S):
-            q = ops.bilinear_nchw(q, S, S, out=bufs["q1024"])
-        ops.minmax(q, B, mm=bufs["mm"])
-        ops.sam_patchify(q, bufs["mm"], S, sam.image_encoder.patch_size, sam._mean_host, sam._std_host, True,
-                         out=bufs["patches"])
-        # 4. SAM image encoder (enqueued before the host looks at the component tables)
-        feat_tok = sam.image_encoder.encode_patches(bufs["patches"], B)         # [B, 4096, 256] token-major
+        # 3./4. image hand-off + SAM image encoder (already running on the side stream, or enqueued here before the host looks
+        #       at the component tables)
+        if feat_tok is None:
+            feat_tok = self._sam_features(query_images, bufs, B, S)
         # 5. host: number of components and prompts per slice
         bufs["event"].synchronize()
+        if side is not None:
+            main.wait_event(bufs["sam_done"])                                   # the decoder below consumes feat_tok on `main`
+            feat_tok.record_stream(main)
         tabs = cw.tabs_host[:B].numpy()
         results = [None] * B
         coords, labels, img_idx, spans = [], [], [], []
