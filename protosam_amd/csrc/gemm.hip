@@ -1032,6 +1032,153 @@ static void launch8h(const GemmArgs& p, hipStream_t s) {
   hipLaunchKernelGGL((gemm8h_f16_kernel<EPI>), dim3(tile_map_grid(ntm, ntn, p.map_mode)), dim3(512), LDS, s, p);
 }
 
+
+// =====================================================================================================
+// Tile 9 (experimental): 256 x 256 x 64, FOUR waves (2 x 2), wave tile 128 x 128 = 4 x 4 MFMA 32x32x16 tiles (256
+// accumulator registers, one wave per SIMD), operands staged through REGISTERS (global_load_dwordx4 -> ds_write_b128) into
+// two 64 KiB LDS buffers. Rationale: with one wave per SIMD nothing else can cover an issue stall, so the cheap-to-issue
+// plain loads (the data lands asynchronously) replace the direct-to-LDS DMA (tens of cycles of issue each), and the
+// 128 x 128 wave tile needs a third less LDS read traffic per FLOP than 128 x 64. One barrier per K-tile.
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm4w_f16_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) half_t ring[];  // [buf 2][A | B][256][64]
+  constexpr int TE = 256 * 64;                                     // halfs per operand tile
+  const int ntn = p.N / 256;
+  const int ntm = (p.M + 255) / 256;
+  int tm, tn;
+  if (!tile_map(blockIdx.x, ntm, ntn, p.map_mode, tm, tn)) return;
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = wv >> 1, wc = wv & 1;
+  const int lr = lane & 31, lg = lane >> 5;
+
+  // staging: piece j (0..7) of an operand tile = rows j*32 + t/8, 16-byte slot t%8 of the 128-byte row; the LDS image is
+  // XOR-swizzled on the write (slot ^ ((row>>1)&7)) exactly as the fragment reads expect
+  const int srow = t >> 3, sslot = t & 7;
+  unsigned aoff[8], boff[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    int am = m0 + j * 32 + srow;
+    am = am < p.M ? am : p.M - 1;
+    aoff[j] = (unsigned)am * (unsigned)p.lda + sslot * 8;
+    boff[j] = (unsigned)(n0 + j * 32 + srow) * (unsigned)p.ldw + sslot * 8;
+  }
+  int soff[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) soff[j] = lds_off64(j * 32 + srow, sslot);
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.K / 64;
+  // The staging loads are inline asm: written as plain C++ loads hipcc either sinks them next to their ds_writes (latency
+  // fully exposed) or, when pinned at the top with a sched_barrier, parks them in scratch. As asm the 16 requests are issued
+  // at the top of the iteration, fly under the 64 MFMAs, and one explicit s_waitcnt ahead of the LDS writes orders them.
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 ra[8], rb[8];
+  unsigned abyte[8], bbyte[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { abyte[j] = aoff[j] * 2u; bbyte[j] = boff[j] * 2u; }
+  // The staging loads are inline asm: written as plain C++ loads hipcc either sinks them next to their ds_writes (latency
+  // fully exposed) or, when pinned with a sched_barrier, parks them in scratch. Each request produces a fresh value that is
+  // consumed (s_waitcnt, ds_write) in the SAME iteration: a value in flight across the loop back-edge can be "copied" by a
+  // compiler-inserted v_mov before it has landed (tried: requests re-issued right after the LDS writes = one full iteration
+  // of cover and 3-4 % faster, but wrong results).
+#define G4W_LD(j, kb)                                                                                              \
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(ra[j]) : "v"(abyte[j] + (kb)), "s"(p.A) : "memory");       \
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(rb[j]) : "v"(bbyte[j] + (kb)), "s"(p.W) : "memory");
+#define G4W_WAIT()                                                                                                 \
+  asm volatile("s_waitcnt vmcnt(0)"                                                                                \
+               : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(ra[6]), "+v"(ra[7]),  \
+                 "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(rb[4]), "+v"(rb[5]), "+v"(rb[6]), "+v"(rb[7])   \
+               :: "memory")
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { G4W_LD(j, 0u) }
+  G4W_WAIT();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    *reinterpret_cast<u32x4*>(ring + soff[j]) = ra[j];
+    *reinterpret_cast<u32x4*>(ring + TE + soff[j]) = rb[j];
+  }
+  __syncthreads();
+  const int arow = wr * 128 + lr, brow = wc * 128 + lr;
+  for (int kt = 0; kt < nk; ++kt) {
+    const half_t* sa = ring + (kt & 1) * 2 * TE;
+    const half_t* sb = sa + TE;
+    half_t* da = ring + ((kt + 1) & 1) * 2 * TE;
+    // next K-tile -> registers (the last iteration re-reads its own tile: no branch around the loads). The 16 requests are
+    // issued in the shadows of k-substep 0's MFMAs, the 16 LDS writes in those of k-substep 3 (by then the data has had
+    // ~1500 cycles to land): with one wave per SIMD an instruction only costs matrix-pipe time if no MFMA follows it soon
+    // enough. Fragments of k-substep s2+1 are requested before the 16 MFMAs of s2 (two register sets).
+    const unsigned kb = (unsigned)(kt + 1 < nk ? kt + 1 : kt) * 128u;
+    half8_t fa[2][4], fb[2][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      fa[0][i] = *reinterpret_cast<const half8_t*>(&sa[lds_off64(arow + i * 32, lg)]);
+      fb[0][i] = *reinterpret_cast<const half8_t*>(&sb[lds_off64(brow + i * 32, lg)]);
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+      if (s2 < 3) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          fa[(s2 + 1) & 1][i] = *reinterpret_cast<const half8_t*>(&sa[lds_off64(arow + i * 32, (s2 + 1) * 2 + lg)]);
+          fb[(s2 + 1) & 1][i] = *reinterpret_cast<const half8_t*>(&sb[lds_off64(brow + i * 32, (s2 + 1) * 2 + lg)]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (s2 == 3) G4W_WAIT();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (s2 == 0) {
+#pragma unroll
+          for (int j = 2 * i; j < 2 * i + 2; ++j) { G4W_LD(j, kb) }
+        }
+        if (s2 == 3) {
+#pragma unroll
+          for (int j = 2 * i; j < 2 * i + 2; ++j) {
+            *reinterpret_cast<u32x4*>(da + soff[j]) = ra[j];
+            *reinterpret_cast<u32x4*>(da + TE + soff[j]) = rb[j];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[s2 & 1][j], fa[s2 & 1][i], acc[i][j], 0, 0, 0);  // D^T
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();
+  }
+#undef G4W_LD
+#undef G4W_WAIT
+
+  float* slab = reinterpret_cast<float*>(ring) + wv * 4096;
+#pragma unroll
+  for (int i = 0; i < 4; i += 2)
+#pragma unroll
+    for (int j = 0; j < 4; j += 2)
+      store_slab_staged<EPI, false>(acc[i][j], acc[i][j + 1], acc[i + 1][j], acc[i + 1][j + 1], slab,
+                                    m0 + wr * 128 + i * 32, n0 + wc * 128 + j * 32, lane, p);
+}
+
+template <int EPI>
+static void launch4w(const GemmArgs& p, hipStream_t s) {
+  constexpr int LDS = 2 * 2 * 256 * 64 * 2;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm4w_f16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr = true;
+  }
+  const int ntm = (p.M + 255) / 256, ntn = p.N / 256;
+  hipLaunchKernelGGL((gemm4w_f16_kernel<EPI>), dim3(tile_map_grid(ntm, ntn, p.map_mode)), dim3(256), LDS, s, p);
+}
+
 template <int EPI>
 static void launch_ws(const GemmArgs& p, hipStream_t s) {
   constexpr int LDS = 4 * (384 + 128) * 32 * 2;
@@ -1059,7 +1206,8 @@ static void launch256(const GemmArgs& p, hipStream_t s) {
 }
 
 // tile choice: 0 = auto, 1 = 128x128x64 double buffer, 2 = 256x128 / 3 = 256x256 staggered ring, 5 = 256x256 plain ring,
-// 6 = wave-specialised 384x128, 7 = 256x256x64 8-phase
+// 6 = wave-specialised 384x128, 7 = 256x256x64 8-phase, 8 = 7 with one barrier per phase, 9 = four waves with 128x128
+// wave tiles and register staging (experimental)
 // (PSAM_GEMM_TILE env var or psam_gemm_set_tile)
 static int g_tile_override = -1;
 extern "C" int psam_gemm_set_tile(int t) {
@@ -1129,6 +1277,12 @@ extern "C" int psam_gemm_f16(const void* A, const void* W, const float* bias, vo
       else if (epilogue == EPI_GELU_F16) launch256<EPI_GELU_F16, 256, 0>(p, s);
       else launch256<EPI_F32, 256, 0>(p, s);
     }
+    return psam_launch_status();
+  }
+  if (tsel == 9 && N % 256 == 0) {
+    if (epilogue == EPI_F16) launch4w<EPI_F16>(p, s);
+    else if (epilogue == EPI_GELU_F16) launch4w<EPI_GELU_F16>(p, s);
+    else launch4w<EPI_F32>(p, s);
     return psam_launch_status();
   }
   if (tsel == 8 && N % 256 == 0) {
