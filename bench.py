@@ -137,7 +137,7 @@ def main():
             traffic = json.load(f)["all_gemm_launches"]["bytes_per_launch_avg"]
     except Exception:
         pass
-    roofline = {"bound": "mfma", "kernel": "psam_gemm_f16 (gemm8p_f16_kernel 256x256x64 / gemm_f16_kernel 128x128x64)",
+    roofline = {"bound": "mfma", "kernel": "psam_gemm_f16 (gemm8k_f16_kernel 256x256x64 8-phase / gemm_f16_kernel 128x128x64)",
                 "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic, "launches": nl,
                 "avg_launch_us": round(tg / max(nl, 1) * 1e6, 2), "flop_per_launch_avg": round(fl / max(nl, 1)),

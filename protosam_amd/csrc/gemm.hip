@@ -1179,6 +1179,157 @@ static void launch4w(const GemmArgs& p, hipStream_t s) {
   hipLaunchKernelGGL((gemm4w_f16_kernel<EPI>), dim3(tile_map_grid(ntm, ntn, p.map_mode)), dim3(256), LDS, s, p);
 }
 
+
+// =====================================================================================================
+// Tile 10: the 8-phase kernel (tile 7: geometry, LDS image, staggered wave rows, two barriers per phase) with the K-tile cut
+// the other way: a phase is one 64-row x 64-column half of the wave tile over HALF the K-tile (2 k-substeps), i.e. 8 MFMAs on
+// FOUR independent accumulators (tile 7: two accumulators x 4 k-substeps, every MFMA depending on the one two slots earlier),
+// and the fragment reads are 8 / 8 / 4 / 4 per phase instead of 12 / 4 / 8 / 0:
+//   phase 1: (A0 k01) x (B0 B1 k01)   phase 2: (A0 k23) x (B0 B1 k23)   phase 3: (A1 k01) x kept B k01   phase 4: (A1 k23) x kept B k23
+// Half-tiles A0, B0, B1 are last read in phase 2, A1 in phase 4; DMA (one half-tile per phase, >= 2 phases after its last
+// read, consumption order):  phase 1(t): B0(t+1)   phase 2(t): B1(t+1)   phase 3(t): A1(t+1)   phase 4(t): A0(t+2)
+// Waits: phase 4 leaves the two newest half-tiles in flight (vmcnt 4: A0 B0 B1 of t+1 have landed for phase 1),
+// phases 1-3 leave three (vmcnt 6: by phase 2 this retires A1(t) for phase 3).
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm8k_f16_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) half_t ring[];  // [buf 2][A0 A1 B0 B1][128][64]
+  constexpr int HT = 128 * 64;
+  const int ntn = p.N / 256;
+  const int ntm = (p.M + 255) / 256;
+  int tm, tn;
+  if (!tile_map(blockIdx.x, ntm, ntn, p.map_mode, tm, tn)) return;
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = wv >> 2, wc = wv & 3;
+  const int lr = lane & 31, lg = lane >> 5;
+
+  unsigned aoff[2][2], boff[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int lrow = j * 64 + (t >> 3);
+    const int chunk = (t & 7) ^ ((lrow >> 1) & 7);
+    const int arow = (lrow >> 6) * 128 + (lrow & 63);
+    const int brow = (lrow >> 5) * 64 + (lrow & 31);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int am = m0 + arow + h * 64;
+      am = am < p.M ? am : p.M - 1;
+      aoff[j][h] = (unsigned)am * (unsigned)p.lda + chunk * 8;
+    }
+    boff[j] = (unsigned)(n0 + brow) * (unsigned)p.ldw + chunk * 8;
+  }
+  const unsigned bh = 32u * (unsigned)p.ldw;
+  auto stage = [&](int which, int kt) {  // 0 A0, 1 A1, 2 B0, 3 B1
+    half_t* dst = ring + ((kt & 1) * 4 + which) * HT + wv * 512;
+    const int h = which & 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const half_t* g = which < 2 ? p.A + (aoff[j][h] + (unsigned)kt * 64u) : p.W + (boff[j] + h * bh + (unsigned)kt * 64u);
+      glds16(g, dst + j * 4096);
+    }
+  };
+
+  f32x16 acc[2][2][2];  // [a][i][b]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][i][b][r] = 0.f;
+
+  half8_t fa[2][2];      // [i][k within the half]
+  half8_t fb[2][2][2];   // [k half][b][k within the half]: both halves stay resident for phases 3 / 4
+  const int arow0 = wr * 64 + lr, brow0 = wc * 32 + lr;
+  const int nk = p.K / 64;
+
+#define RD_A(bufp, h, kh)                                                                                         \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int k2 = 0; k2 < 2; ++k2)                   \
+      fa[i][k2] = *reinterpret_cast<const half8_t*>(&(bufp)[(h) * HT + lds_off64(arow0 + i * 32, ((kh) * 2 + k2) * 2 + lg)]);
+#define RD_B(bufp, kh)                                                                                            \
+  _Pragma("unroll") for (int b = 0; b < 2; ++b) _Pragma("unroll") for (int k2 = 0; k2 < 2; ++k2)                   \
+      fb[kh][b][k2] = *reinterpret_cast<const half8_t*>(&(bufp)[(2 + b) * HT + lds_off64(brow0, ((kh) * 2 + k2) * 2 + lg)]);
+#define MMA_H(a, kh)                                                                                              \
+  _Pragma("unroll") for (int k2 = 0; k2 < 2; ++k2) _Pragma("unroll") for (int i = 0; i < 2; ++i)                   \
+      _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                               \
+          acc[a][i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[kh][b][k2], fa[i][k2], acc[a][i][b], 0, 0, 0);
+#define PHASE_SYNC_IN()                                   \
+  __builtin_amdgcn_s_barrier();                           \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+  __builtin_amdgcn_sched_barrier(0);                      \
+  __builtin_amdgcn_s_setprio(1);
+#define PHASE_SYNC_OUT()                                  \
+  __builtin_amdgcn_s_setprio(0);                          \
+  __builtin_amdgcn_sched_barrier(0);                      \
+  __builtin_amdgcn_s_barrier();                           \
+  asm volatile("" ::: "memory");
+
+  stage(0, 0); stage(2, 0); stage(3, 0); stage(1, 0);
+  if (nk > 1) { stage(0, 1); wait_vmcnt<4>(); } else { wait_vmcnt<2>(); }
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger the second wave row by one barrier
+  asm volatile("" ::: "memory");
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const half_t* buf = ring + (kt & 1) * 4 * HT;
+    const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+    // ---- phase 1 ---------------------------------------------------------------------------------------------------
+    RD_B(buf, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    RD_A(buf, 0, 0)
+    if (more1) stage(2, kt + 1);
+    if (more1) wait_vmcnt<6>(); else wait_vmcnt<0>();
+    PHASE_SYNC_IN();
+    MMA_H(0, 0)
+    PHASE_SYNC_OUT();
+    // ---- phase 2 ---------------------------------------------------------------------------------------------------
+    RD_B(buf, 1)
+    __builtin_amdgcn_sched_barrier(0);
+    RD_A(buf, 0, 1)
+    if (more1) stage(3, kt + 1);
+    if (more1) wait_vmcnt<6>(); else wait_vmcnt<0>();
+    PHASE_SYNC_IN();
+    MMA_H(0, 1)
+    PHASE_SYNC_OUT();
+    // ---- phase 3 ---------------------------------------------------------------------------------------------------
+    RD_A(buf, 1, 0)
+    if (more1) stage(1, kt + 1);
+    if (more1) wait_vmcnt<6>(); else wait_vmcnt<0>();
+    PHASE_SYNC_IN();
+    MMA_H(1, 0)
+    PHASE_SYNC_OUT();
+    // ---- phase 4 ---------------------------------------------------------------------------------------------------
+    RD_A(buf, 1, 1)
+    if (more2) { stage(0, kt + 2); wait_vmcnt<4>(); } else if (more1) { wait_vmcnt<2>(); } else { wait_vmcnt<0>(); }
+    PHASE_SYNC_IN();
+    MMA_H(1, 1)
+    PHASE_SYNC_OUT();
+  }
+#undef RD_A
+#undef RD_B
+#undef MMA_H
+#undef PHASE_SYNC_IN
+#undef PHASE_SYNC_OUT
+  if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the stagger
+
+  float* slab = reinterpret_cast<float*>(ring) + wv * 4096;
+  store_wave_tile_128x64<EPI>(acc, slab, m0 + wr * 128, n0 + wc * 64, lane, p);
+}
+
+template <int EPI>
+static void launch8k(const GemmArgs& p, hipStream_t s) {
+  constexpr int LDS = 2 * 4 * 128 * 64 * 2;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm8k_f16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr = true;
+  }
+  const int ntm = (p.M + 255) / 256, ntn = p.N / 256;
+  hipLaunchKernelGGL((gemm8k_f16_kernel<EPI>), dim3(tile_map_grid(ntm, ntn, p.map_mode)), dim3(512), LDS, s, p);
+}
+
 template <int EPI>
 static void launch_ws(const GemmArgs& p, hipStream_t s) {
   constexpr int LDS = 4 * (384 + 128) * 32 * 2;
@@ -1207,7 +1358,7 @@ static void launch256(const GemmArgs& p, hipStream_t s) {
 
 // tile choice: 0 = auto, 1 = 128x128x64 double buffer, 2 = 256x128 / 3 = 256x256 staggered ring, 5 = 256x256 plain ring,
 // 6 = wave-specialised 384x128, 7 = 256x256x64 8-phase, 8 = 7 with one barrier per phase, 9 = four waves with 128x128
-// wave tiles and register staging (experimental)
+// wave tiles and register staging (experimental), 10 = 8-phase with K-split phases (the default large tile)
 // (PSAM_GEMM_TILE env var or psam_gemm_set_tile)
 static int g_tile_override = -1;
 extern "C" int psam_gemm_set_tile(int t) {
@@ -1230,7 +1381,7 @@ static int pick_tile(int M, int N, int K, int epilogue) {
     // the fp32 residual epilogue with a short K (proj: 20 K-tiles) is better served by two workgroups per CU unless the
     // 256-tiles fill their rounds completely (65536x1280x1280: 603 vs 525 TFLOP/s; 32768x1280x1280, 2.5 rounds: 653 vs 689)
     const bool short_f32 = epilogue == EPI_F32 && K < 2048;
-    if (K >= 1024 && t256 * 100 >= rounds * 256 * (short_f32 ? 95 : 80)) return 7;
+    if (K >= 1024 && t256 * 100 >= rounds * 256 * (short_f32 ? 95 : 80)) return 10;   // (7 = its quadrant-phase predecessor)
   }
   return 1;
 }
@@ -1277,6 +1428,12 @@ extern "C" int psam_gemm_f16(const void* A, const void* W, const float* bias, vo
       else if (epilogue == EPI_GELU_F16) launch256<EPI_GELU_F16, 256, 0>(p, s);
       else launch256<EPI_F32, 256, 0>(p, s);
     }
+    return psam_launch_status();
+  }
+  if (tsel == 10 && N % 256 == 0) {
+    if (epilogue == EPI_F16) launch8k<EPI_F16>(p, s);
+    else if (epilogue == EPI_GELU_F16) launch8k<EPI_GELU_F16>(p, s);
+    else launch8k<EPI_F32>(p, s);
     return psam_launch_status();
   }
   if (tsel == 9 && N % 256 == 0) {

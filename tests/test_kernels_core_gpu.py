@@ -38,7 +38,7 @@ def test_gemm(dev, M, N, K, epi):
         torch.testing.assert_close(out, resid + gamma * ref, rtol=1e-4, atol=2e-4)
 
 
-@pytest.mark.parametrize("tile", [2, 3, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("tile", [2, 3, 5, 6, 7, 8, 9, 10])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (1297, 768, 768), (4096, 1280, 1280), (1000, 512, 192)])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_gemm_large_tiles(dev, tile, M, N, K, epi):
