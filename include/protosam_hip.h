@@ -30,6 +30,12 @@ extern "C" {
 int psam_gemm_f16(const void* A, const void* W, const float* bias, void* out, const float* resid, const float* gamma,
                   int M, int N, int K, int lda, int ldw, int ldo, int ldr, int resid_mod, int out_seg,
                   int out_seg_stride, int out_seg_off, int epilogue, void* stream);
+/* The packed qkv projection with a head-major result: out half [N / hd planes][M][hd] (plane = which*H + h of
+ * `self.qkv(x).reshape(B, N, 3, H, hd)`, image_encoder.py:236-238), read by psam_attention_f16 / psam_relpos with
+ * head_major = 1: a head's Q / K / V rows are then contiguous hd-vectors. Same arithmetic as epilogue 0. */
+int psam_gemm_f16_heads(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int lda, int ldw,
+                        int hd, void* stream);
+
 
 /* Tile override for psam_gemm_f16: 0 auto (default; also env PSAM_GEMM_TILE), 1 = 128x128x64 double-buffered,
  * 2 = 256x128x32 / 3 = 256x256x32 (two staggered wave groups) and 5 = 256x256x32 (plain) with a 4-deep direct-to-LDS
@@ -46,17 +52,18 @@ int psam_layernorm(const float* x, const float* w, const float* b, void* y, floa
  * mode 0 global (DINOv2 Attention); mode 1 global + decomposed rel-pos (rel_h/rel_w fp32, gw == 64); mode 2 ws x ws
  * windows with the reference's zero padding (pad_row half [3,H,hd] = qkv bias) + rel-pos folded into the score MFMA
  * as 32 extra k-slots (relq half [B,H,N,2,32] from psam_relpos).
+ * head_major = 0: qkv is token-major [B,N,3,H,hd]; 1: head-major [3,H,B*N,hd] as written by psam_gemm_f16_heads.
  * image_encoder.py:235-251 (Attention.forward), :254-300 (window_partition / unpartition), :337-372. */
 int psam_attention_f16(const void* qkv, void* out, const float* rel_h, const float* rel_w, const void* relq,
                        const void* pad_row, int B, int N, int H, int hd, float scale, int mode, int gh, int gw, int ws,
-                       void* stream);
+                       int head_major, void* stream);
 
 /* rel_h[b,h,n,k] = q . Rh[qy - k + K-1], rel_w likewise (UNSCALED q), as an MFMA GEMM against the whole table followed by
  * a scatter. Rpack half [2 (h,w)][2 (hi,lo)][RP][HDP] (RP = 128 global / 32 windowed, zero padded).
  * global: rel_h, rel_w fp32 [B,H,N,64]. windowed: relq half [B,H,N,2,32] = hi/lo of (rel_h | rel_w | 0) / scale.
  * image_encoder.py:303-372 (get_rel_pos, add_decomposed_rel_pos). */
 int psam_relpos(const void* qkv, const void* Rpack, float* rel_h, float* rel_w, void* relq, int B, int N, int H, int hd,
-                int gw, int K, int windowed, float scale, void* stream);
+                int gw, int K, int windowed, float scale, int head_major, void* stream);
 
 /* ---- ALP module ------------------------------------------------------------------------------------------------
  * Prototype bank from token-major support features sup fp32 [h*w, C] (row stride ld) and the foreground mask fp32

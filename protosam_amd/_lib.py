@@ -18,12 +18,13 @@ c_void_p, c_int, c_float, c_longlong = ctypes.c_void_p, ctypes.c_int, ctypes.c_f
 # name -> argtypes; every entry point returns int (0 = ok). Kept in the same order as the header.
 SIGNATURES = {
     "psam_gemm_f16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p],
+    "psam_gemm_f16_heads": [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p],
     "psam_gemm_set_tile": [c_int],
     "psam_layernorm": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                        c_int, c_int, c_void_p],
     "psam_attention_f16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                           c_float, c_int, c_int, c_int, c_int, c_void_p],
-    "psam_relpos": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_float, c_void_p],
+                           c_float, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "psam_relpos": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_float, c_int, c_void_p],
     "psam_alp_bank": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float,
                       c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "psam_alp_sim": [c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_float, c_float,

@@ -38,6 +38,8 @@ struct AttnArgs {
   float scale;
   int gh, gw, ws, nwx, nwin;  // token grid, window size, windows per row, windows per image
   int nqb;                    // query blocks per (batch, head) (global modes)
+  long long ts, hs, ws_;      // qkv strides in halfs: token, head, which (q/k/v). token-major [B,N,3,H,hd]: 3*H*hd, hd, H*hd;
+                              // head-major [3,H,B*N,hd] (psam_gemm_f16_heads): hd, B*N*hd, H*B*N*hd
 };
 
 #define KT 64  // keys per tile
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
     }
   }
   const int N = p.N, H = p.H;
-  const size_t rs = (size_t)3 * H * HD;  // qkv row stride (halfs)
+  const size_t rs = (size_t)p.ts;  // qkv token stride (halfs)
   const half_t* qkv_b = p.qkv + (size_t)b * N * rs;
   const int nkeys = MODE == 2 ? p.ws * p.ws : N;
   const int ntiles = (nkeys + KT - 1) / KT;
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
     }
     qvalid[qt] = tok >= 0;
     qtok[qt] = tok >= 0 ? tok : 0;
-    const half_t* qp = qkv_b + (size_t)qtok[qt] * rs + (size_t)h * HD;
+    const half_t* qp = qkv_b + (size_t)qtok[qt] * rs + (size_t)h * p.hs;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       int c0 = s * 32 + g * 8;
@@ -190,9 +192,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
     if (MODE == 2) {
       int tok = win_token(kidx);
       if (tok < 0) return p.pad_row + ((size_t)which * H + h) * HD;
-      return qkv_b + (size_t)tok * rs + ((size_t)which * H + h) * HD;
+      return qkv_b + (size_t)tok * rs + (size_t)which * p.ws_ + (size_t)h * p.hs;
     }
-    return qkv_b + (size_t)kidx * rs + ((size_t)which * H + h) * HD;
+    return qkv_b + (size_t)kidx * rs + (size_t)which * p.ws_ + (size_t)h * p.hs;
   };
 
   auto load_tile = [&](int tile) {
@@ -446,9 +448,14 @@ static int launch_attn(AttnArgs p, int mode, hipStream_t s) {
 //         (relq = psam_relpos' windowed output).
 extern "C" int psam_attention_f16(const void* qkv, void* out, const float* rel_h, const float* rel_w,
                                   const void* relq, const void* pad_row, int B, int N, int H, int hd, float scale,
-                                  int mode, int gh, int gw, int ws, void* stream) {
+                                  int mode, int gh, int gw, int ws, int head_major, void* stream) {
   if (B <= 0 || N <= 0 || H <= 0 || mode < 0 || mode > 2) return PSAM_ERR_ARG;
   AttnArgs p;
+  if (head_major) {
+    p.ts = hd; p.hs = (long long)B * N * hd; p.ws_ = (long long)H * B * N * hd;
+  } else {
+    p.ts = 3LL * H * hd; p.hs = hd; p.ws_ = (long long)H * hd;
+  }
   p.qkv = (const half_t*)qkv;
   p.out = (half_t*)out;
   p.rel_h = rel_h;
@@ -496,7 +503,7 @@ template <int HD>
 __global__ __launch_bounds__(256) void relpos_mfma_kernel(const half_t* __restrict__ qkv, const half_t* __restrict__ Rpack,
                                                           float* __restrict__ rel_h, float* __restrict__ rel_w,
                                                           half_t* __restrict__ relq, int N, int H, int gw, int K, int RP,
-                                                          int windowed, float inv_scale) {
+                                                          int windowed, float inv_scale, long long ts, long long hs) {
   constexpr int HDP = (HD + 31) / 32 * 32;
   constexpr int KS = HDP / 32;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -506,7 +513,7 @@ __global__ __launch_bounds__(256) void relpos_mfma_kernel(const half_t* __restri
   // A operand: 16 query rows
   half8_t qf[KS];
   {
-    const half_t* qp = qkv + ((size_t)b * N + n0 + li) * ((size_t)3 * H * HD) + (size_t)h * HD;
+    const half_t* qp = qkv + ((size_t)b * N + n0 + li) * (size_t)ts + (size_t)h * (size_t)hs;   // q = which 0
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int c0 = s * 32 + g * 8;
@@ -560,19 +567,20 @@ __global__ __launch_bounds__(256) void relpos_mfma_kernel(const half_t* __restri
 }
 
 extern "C" int psam_relpos(const void* qkv, const void* Rpack, float* rel_h, float* rel_w, void* relq, int B, int N,
-                           int H, int hd, int gw, int K, int windowed, float scale, void* stream) {
+                           int H, int hd, int gw, int K, int windowed, float scale, int head_major, void* stream) {
   if (B <= 0 || N <= 0 || (N % 64) != 0 || K <= 0 || K > 64) return PSAM_ERR_ARG;
   if (windowed ? (K > 16 || !relq) : (!rel_h || !rel_w)) return PSAM_ERR_ARG;
   const int RP = windowed ? 32 : 128;
   dim3 grid(N / 64, H, B), block(256);
   hipStream_t s = (hipStream_t)stream;
   const float inv = 1.0f / scale;
+  const long long ts = head_major ? hd : 3LL * H * hd, hs = head_major ? (long long)B * N * hd : hd;
   if (hd == 64)
     hipLaunchKernelGGL(relpos_mfma_kernel<64>, grid, block, 0, s, (const half_t*)qkv, (const half_t*)Rpack, rel_h, rel_w,
-                       (half_t*)relq, N, H, gw, K, RP, windowed, inv);
+                       (half_t*)relq, N, H, gw, K, RP, windowed, inv, ts, hs);
   else if (hd == 80)
     hipLaunchKernelGGL(relpos_mfma_kernel<80>, grid, block, 0, s, (const half_t*)qkv, (const half_t*)Rpack, rel_h, rel_w,
-                       (half_t*)relq, N, H, gw, K, RP, windowed, inv);
+                       (half_t*)relq, N, H, gw, K, RP, windowed, inv, ts, hs);
   else
     return PSAM_ERR_ARG;
   return psam_launch_status();

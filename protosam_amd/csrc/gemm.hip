@@ -38,6 +38,7 @@ struct GemmArgs {
   int out_seg_stride;
   int out_seg_off;
   int map_mode;  // 0: XCD-region tile map (default); 1: identity; 2: contiguous chunk per XCD
+  int head_hd;   // > 0: head-major output, out[(n / head_hd), m, n % head_hd] (planes of [M, head_hd]); EPI_F16 only
   int dbg;       // ablation switches for tools/gemm_ablate.py (PSAM_GEMM_DBG; only the DBG instantiation reads it)
 };
 
@@ -190,7 +191,12 @@ __device__ __forceinline__ void slab_emit(const float* __restrict__ slab, int mb
     const size_t orow = p.out_seg ? (size_t)(m / p.out_seg) * p.out_seg_stride + p.out_seg_off + (m % p.out_seg) : (size_t)m;
     if (EPI == EPI_F16) {
       half4_t h = {(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
-      *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(p.out) + orow * p.ldo + n) = h;
+      if (p.head_hd) {  // packed qkv written head-major: plane (which*H + h) of [M, hd], 4 columns never straddle a head
+        const int pl = n / p.head_hd;
+        *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(p.out) + ((size_t)pl * p.M + m) * p.head_hd + (n - pl * p.head_hd)) = h;
+      } else {
+        *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(p.out) + orow * p.ldo + n) = h;
+      }
     } else if (EPI == EPI_GELU_F16) {
       half4_t h = {(half_t)gelu_erf(v.x), (half_t)gelu_erf(v.y), (half_t)gelu_erf(v.z), (half_t)gelu_erf(v.w)};
       *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(p.out) + orow * p.ldo + n) = h;
@@ -1386,10 +1392,10 @@ static int pick_tile(int M, int N, int K, int epilogue) {
   return 1;
 }
 
-extern "C" int psam_gemm_f16(const void* A, const void* W, const float* bias, void* out, const float* resid,
-                             const float* gamma, int M, int N, int K, int lda, int ldw, int ldo, int ldr,
-                             int resid_mod, int out_seg, int out_seg_stride, int out_seg_off, int epilogue,
-                             void* stream) {
+static int gemm_dispatch(const void* A, const void* W, const float* bias, void* out, const float* resid,
+                         const float* gamma, int M, int N, int K, int lda, int ldw, int ldo, int ldr,
+                         int resid_mod, int out_seg, int out_seg_stride, int out_seg_off, int epilogue, int head_hd,
+                         void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || (N % BN) != 0 || (K % BK) != 0 || (lda % 8) != 0 || (ldw % 8) != 0 ||
       (ldo % 4) != 0 || (resid && (ldr % 4) != 0))
     return PSAM_ERR_ARG;
@@ -1414,10 +1420,12 @@ extern "C" int psam_gemm_f16(const void* A, const void* W, const float* bias, vo
   p.out_seg_off = out_seg_off;
   { const char* e = getenv("PSAM_GEMM_MAP"); p.map_mode = e ? atoi(e) : 0; }
   { const char* e = getenv("PSAM_GEMM_DBG"); p.dbg = e ? atoi(e) : 0; }
+  p.head_hd = head_hd;
   const int ntm = (M + BM - 1) / BM, ntn = N / BN;
   dim3 grid(tile_map_grid(ntm, ntn, p.map_mode)), block(256);
   hipStream_t s = (hipStream_t)stream;
-  const int tsel = epilogue == EPI_RELU_F16 ? 1 : pick_tile(M, N, K, epilogue);  // the ReLU epilogue lives in the 128x128 kernel
+  int tsel = epilogue == EPI_RELU_F16 ? 1 : pick_tile(M, N, K, epilogue);
+  if (head_hd && tsel != 1 && tsel != 7 && tsel != 8 && tsel != 10) tsel = 1;   // the head-major store lives in the staged epilogue  // the ReLU epilogue lives in the 128x128 kernel
   if ((tsel == 3 || tsel == 5) && N % 256 == 0) {
     if (tsel == 3) {
       if (epilogue == EPI_F16) launch256<EPI_F16, 256, 1>(p, s);
@@ -1474,4 +1482,22 @@ extern "C" int psam_gemm_f16(const void* A, const void* W, const float* bias, vo
     default: hipLaunchKernelGGL(gemm_f16_kernel<EPI_F32>, grid, block, 0, s, p); break;
   }
   return psam_launch_status();
+}
+
+extern "C" int psam_gemm_f16(const void* A, const void* W, const float* bias, void* out, const float* resid,
+                             const float* gamma, int M, int N, int K, int lda, int ldw, int ldo, int ldr,
+                             int resid_mod, int out_seg, int out_seg_stride, int out_seg_off, int epilogue,
+                             void* stream) {
+  return gemm_dispatch(A, W, bias, out, resid, gamma, M, N, K, lda, ldw, ldo, ldr, resid_mod, out_seg, out_seg_stride,
+                       out_seg_off, epilogue, 0, stream);
+}
+
+// The packed qkv projection with a HEAD-MAJOR result: out half [N / hd planes][M][hd] (plane = which*H + h), so that the
+// attention kernels read each head's Q / K / V rows as contiguous hd-vectors (a window row is 14 x 160 contiguous bytes)
+// instead of 160-byte slices 7680 bytes apart. Same arithmetic as psam_gemm_f16 with epilogue 0.
+extern "C" int psam_gemm_f16_heads(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int lda,
+                                   int ldw, int hd, void* stream) {
+  if (hd <= 0 || (hd % 4) != 0 || (N % hd) != 0) return PSAM_ERR_ARG;
+  return gemm_dispatch(A, W, bias, out, nullptr, nullptr, M, N, K, lda, ldw, /*ldo (checked only)*/ N, 0, 0, 0, 0, 0, EPI_F16,
+                       hd, stream);
 }

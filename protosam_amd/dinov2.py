@@ -198,8 +198,11 @@ class DinoVisionTransformer(nn.Module):
         x2 = x.view(B * N, D)
         for bp in pk["blocks"]:
             ops.layernorm(x2, bp["n1w"], bp["n1b"], LN_EPS, out=ws["ln"])
-            ops.gemm(ws["ln"], bp["qkv_w"], bp["qkv_b"], out=ws["qkv"], epilogue=ops.EPI_F16)
-            ops.attention(ws["qkv"], B, N, H, hd, hd ** -0.5, out=ws["att"])
+            if ops.QKV_HEAD_MAJOR:
+                ops.gemm_heads(ws["ln"], bp["qkv_w"], bp["qkv_b"], hd, out=ws["qkv"])   # [3,H,B*N,hd]
+            else:
+                ops.gemm(ws["ln"], bp["qkv_w"], bp["qkv_b"], out=ws["qkv"], epilogue=ops.EPI_F16)
+            ops.attention(ws["qkv"], B, N, H, hd, hd ** -0.5, out=ws["att"], head_major=ops.QKV_HEAD_MAJOR)
             ops.gemm(ws["att"], bp["proj_w"], bp["proj_b"], out=x2, epilogue=ops.EPI_F32, resid=x2, gamma=bp["g1"])
             ops.layernorm(x2, bp["n2w"], bp["n2b"], LN_EPS, out=ws["ln"])
             ops.gemm(ws["ln"], bp["fc1_w"], bp["fc1_b"], out=ws["hid"], epilogue=ops.EPI_GELU_F16)

@@ -36,6 +36,12 @@ class KernelTimer:
 
 GEMM_TIMER = None  # set to a KernelTimer to time psam_gemm_f16 launches
 
+# packed qkv layout between the projection GEMM and the attention kernels: the reference's token-major [B,N,3,H,hd]
+# (default) or head-major [3,H,B*N,hd] (PSAM_QKV_HEAD_MAJOR=1: contiguous per-head rows for the attention kernels, but
+# scattered 160-byte stores for the GEMM; measured on MI355X at 16 slices: 108.8 / 109.2 vs 109.8 / 109.2 slices/s - a wash)
+import os as _os
+QKV_HEAD_MAJOR = _os.environ.get("PSAM_QKV_HEAD_MAJOR", "0") != "0"
+
 
 def _ptr(t):
     return 0 if t is None else t.data_ptr()
@@ -80,6 +86,27 @@ def gemm(a, w, bias=None, out=None, epilogue=EPI_F16, resid=None, gamma=None, re
     if t0 is not None:
         GEMM_TIMER.stop(t0, 2.0 * M * N * K)
     _lib.check(st, "psam_gemm_f16")
+    return out
+
+
+def gemm_heads(a, w, bias, hd, out=None, M=None):
+    """The packed qkv projection written head-major: half [N/hd, M, hd] (plane = which*H + h). a/w fp16, K contiguous."""
+    _req(a, torch.float16, "a"); _req(w, torch.float16, "w"); _req(bias, torch.float32, "bias")
+    a2 = a.reshape(-1, a.shape[-1]) if a.dim() != 2 else a
+    if M is None:
+        M = a2.shape[0]
+    K, N = a2.shape[1], w.shape[0]
+    assert w.shape[1] == K and N % hd == 0
+    if out is None:
+        out = torch.empty((N // hd, M, hd), dtype=torch.float16, device=a.device)
+    _req(out, torch.float16, "out")
+    assert out.is_contiguous() and out.numel() == M * N
+    t0 = GEMM_TIMER.start() if GEMM_TIMER is not None else None
+    st = _lib.lib().psam_gemm_f16_heads(_ptr(a2), _ptr(w), _ptr(bias), _ptr(out), M, N, K, a2.stride(0), w.stride(0), hd,
+                                       _stream())
+    if t0 is not None:
+        GEMM_TIMER.stop(t0, 2.0 * M * N * K)
+    _lib.check(st, "psam_gemm_f16_heads")
     return out
 
 
@@ -145,15 +172,16 @@ def layernorm(x, weight, bias, eps, out=None, out_dtype=torch.float16, out2=None
 
 
 def attention(qkv, B, N, H, hd, scale, out=None, mode=0, rel_h=None, rel_w=None, relq=None, pad_row=None, gh=0, gw=0,
-              ws=0):
-    """qkv fp16 [B,N,3,H,hd] (packed as nn.Linear(dim,3*dim) emits it) -> fp16 [B,N,H*hd]."""
+              ws=0, head_major=False):
+    """qkv fp16 [B,N,3,H,hd] (packed as nn.Linear(dim,3*dim) emits it) or, head_major, [3,H,B*N,hd] (gemm_heads)
+    -> fp16 [B,N,H*hd]."""
     _req(qkv, torch.float16, "qkv"); _req(rel_h, torch.float32, "rel_h"); _req(rel_w, torch.float32, "rel_w")
     _req(pad_row, torch.float16, "pad_row"); _req(relq, torch.float16, "relq")
     assert qkv.is_contiguous()
     if out is None:
         out = torch.empty((B, N, H * hd), dtype=torch.float16, device=qkv.device)
     st = _lib.lib().psam_attention_f16(_ptr(qkv), _ptr(out), _ptr(rel_h), _ptr(rel_w), _ptr(relq), _ptr(pad_row), B, N,
-                                      H, hd, float(scale), mode, gh, gw, ws, _stream())
+                                      H, hd, float(scale), mode, gh, gw, ws, 1 if head_major else 0, _stream())
     _lib.check(st, "psam_attention_f16")
     return out
 
@@ -173,7 +201,7 @@ def pack_rel_tables(rel_pos_h, rel_pos_w, windowed, hd):
     return out.contiguous()
 
 
-def relpos(qkv, rpack, B, N, H, hd, gw, K, windowed, scale, rel_h=None, rel_w=None, relq=None):
+def relpos(qkv, rpack, B, N, H, hd, gw, K, windowed, scale, rel_h=None, rel_w=None, relq=None, head_major=False):
     """global: returns (rel_h, rel_w) fp32 [B,H,N,64]; windowed: returns relq fp16 [B,H,N,2,32] (zero-initialised once)."""
     _req(qkv, torch.float16, "qkv"); _req(rpack, torch.float16, "rpack")
     assert rpack.is_contiguous()
@@ -186,7 +214,7 @@ def relpos(qkv, rpack, B, N, H, hd, gw, K, windowed, scale, rel_h=None, rel_w=No
         if rel_w is None:
             rel_w = torch.empty((B, H, N, 64), dtype=torch.float32, device=qkv.device)
     st = _lib.lib().psam_relpos(_ptr(qkv), _ptr(rpack), _ptr(rel_h), _ptr(rel_w), _ptr(relq), B, N, H, hd, gw, K,
-                               1 if windowed else 0, float(scale), _stream())
+                               1 if windowed else 0, float(scale), 1 if head_major else 0, _stream())
     _lib.check(st, "psam_relpos")
     return relq if windowed else (rel_h, rel_w)
 

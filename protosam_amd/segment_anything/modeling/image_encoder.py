@@ -136,16 +136,19 @@ class ImageEncoderViT(nn.Module):
         ops.gemm(patches, pk["patch_w"], pk["patch_b"], out=x, epilogue=ops.EPI_F32, resid=pk["pos"], resid_mod=N)
         for bp in pk["blocks"]:
             ops.layernorm(x, bp["n1w"], bp["n1b"], LN_EPS, out=ws["ln"])
-            ops.gemm(ws["ln"], bp["qkv_w"], bp["qkv_b"], out=ws["qkv"], epilogue=ops.EPI_F16)
+            if ops.QKV_HEAD_MAJOR:
+                ops.gemm_heads(ws["ln"], bp["qkv_w"], bp["qkv_b"], hd, out=ws["qkv"])   # [3,H,B*N,hd]
+            else:
+                ops.gemm(ws["ln"], bp["qkv_w"], bp["qkv_b"], out=ws["qkv"], epilogue=ops.EPI_F16)
             if bp["ws"] > 0:
-                ops.relpos(ws["qkv"], bp["rpack"], B, N, H, hd, g, bp["ws"], True, hd ** -0.5, relq=ws["relq"])
+                ops.relpos(ws["qkv"], bp["rpack"], B, N, H, hd, g, bp["ws"], True, hd ** -0.5, relq=ws["relq"], head_major=ops.QKV_HEAD_MAJOR)
                 ops.attention(ws["qkv"], B, N, H, hd, hd ** -0.5, out=ws["att"], mode=2, relq=ws["relq"],
-                              pad_row=bp["pad_row"], gh=g, gw=g, ws=bp["ws"])
+                              pad_row=bp["pad_row"], gh=g, gw=g, ws=bp["ws"], head_major=ops.QKV_HEAD_MAJOR)
             else:
                 ops.relpos(ws["qkv"], bp["rpack"], B, N, H, hd, g, g, False, hd ** -0.5, rel_h=ws["relh"],
-                           rel_w=ws["relw"])
+                           rel_w=ws["relw"], head_major=ops.QKV_HEAD_MAJOR)
                 ops.attention(ws["qkv"], B, N, H, hd, hd ** -0.5, out=ws["att"], mode=1, rel_h=ws["relh"],
-                              rel_w=ws["relw"], gh=g, gw=g)
+                              rel_w=ws["relw"], gh=g, gw=g, head_major=ops.QKV_HEAD_MAJOR)
             ops.gemm(ws["att"], bp["proj_w"], bp["proj_b"], out=x, epilogue=ops.EPI_F32, resid=x)
             ops.layernorm(x, bp["n2w"], bp["n2b"], LN_EPS, out=ws["ln"])
             ops.gemm(ws["ln"], bp["l1w"], bp["l1b"], out=ws["hid"], epilogue=ops.EPI_GELU_F16)

@@ -191,3 +191,40 @@ def test_attention_window_relpos(dev, H, hd):
     o = (att.softmax(-1) @ v).view(nW, H, ws, ws, hd).permute(0, 2, 3, 1, 4).reshape(nW, ws, ws, C)
     ref = window_unpartition(o, ws, pad_hw, (g, g)).reshape(B, N, C)
     torch.testing.assert_close(out.float().cpu(), ref, rtol=2e-3, atol=2e-3)
+
+
+def test_head_major_qkv_layout(dev):
+    """psam_gemm_f16_heads writes the packed qkv projection as [3,H,B*N,hd]; attention / relpos with head_major=1 give
+    bit-identical results to the token-major [B,N,3,H,hd] path (same arithmetic, different addresses)."""
+    from protosam_amd import ops
+    B, g, H, hd, ws = 1, 64, 16, 80, 14
+    N, D = g * g, H * hd
+    x = _rand((B * N, D), dev, 1.0, 41).half()
+    w = _rand((3 * D, D), dev, 0.05, 42).half()
+    bias = _rand((3 * D,), dev, 0.5, 43)
+    tokm = ops.gemm(x, w, bias, epilogue=ops.EPI_F16)                              # [B*N, 3*H*hd]
+    for tile in (1, 10):
+        ops.gemm_set_tile(tile)
+        try:
+            hm = ops.gemm_heads(x, w, bias, hd)                                    # [3*H, B*N, hd]
+        finally:
+            ops.gemm_set_tile(0)
+        assert torch.equal(hm, tokm.view(B * N, 3 * H, hd).permute(1, 0, 2).contiguous())
+    scale = hd ** -0.5
+    Rh, Rw = _rand((2 * ws - 1, hd), dev, 0.3, 44), _rand((2 * ws - 1, hd), dev, 0.3, 45)
+    pad = bias.half().view(3, H, hd).contiguous()
+    rp = ops.pack_rel_tables(Rh, Rw, True, hd)
+    a = ops.attention(tokm, B, N, H, hd, scale, mode=2, pad_row=pad, gh=g, gw=g, ws=ws,
+                      relq=ops.relpos(tokm, rp, B, N, H, hd, g, ws, True, scale))
+    b = ops.attention(hm, B, N, H, hd, scale, mode=2, pad_row=pad, gh=g, gw=g, ws=ws, head_major=True,
+                      relq=ops.relpos(hm, rp, B, N, H, hd, g, ws, True, scale, head_major=True))
+    assert torch.equal(a, b)
+    Gh, Gw = _rand((2 * g - 1, hd), dev, 0.3, 46), _rand((2 * g - 1, hd), dev, 0.3, 47)
+    rpg = ops.pack_rel_tables(Gh, Gw, False, hd)
+    rh, rw = ops.relpos(tokm, rpg, B, N, H, hd, g, g, False, scale)
+    rh2, rw2 = ops.relpos(hm, rpg, B, N, H, hd, g, g, False, scale, head_major=True)
+    assert torch.equal(rh, rh2) and torch.equal(rw, rw2)
+    a = ops.attention(tokm, B, N, H, hd, scale, mode=1, rel_h=rh, rel_w=rw, gh=g, gw=g)
+    b = ops.attention(hm, B, N, H, hd, scale, mode=1, rel_h=rh, rel_w=rw, gh=g, gw=g, head_major=True)
+    assert torch.equal(a, b)
+    assert torch.equal(ops.attention(tokm, B, N, H, hd, scale), ops.attention(hm, B, N, H, hd, scale, head_major=True))
