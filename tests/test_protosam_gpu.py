@@ -325,3 +325,48 @@ def test_protosam_neg_points_vs_oracle(dev):
     with pytest.raises(TypeError):
         bad, _ = _build(dev, f"random:vit_b:1234:1", 1, use_bbox=True, use_points=False, use_neg_points=True)
         bad(q_img.to(dev), inp)
+
+
+def test_config5_medsam_1024_four_classes(dev):
+    """BASELINE config 5 in miniature: 1024x1024 inputs (DINOv2 at 1022^2 -> 73x73 grid, 36x36 pooled cells), MedSAM ViT-B
+    variant, four classes = four prototype banks of one support image (the reference loops over classes, n_ways == 1,
+    grid_proto_fewshot.py:172; validation.py:207). Reduced depths keep the CPU oracle to seconds."""
+    from oracle import alp as oalp, dinov2 as odino, glue
+    from protosam_amd.grid_proto_fewshot import FewShotSeg
+    from protosam_amd.protomedsam import ProtoMedSAM
+    from protosam_amd.protosam import ALPNetWrapper, InputFactory, TYPE_ALPNET
+    from protosam_amd.synth import ellipse_mask, synth_pair, synth_state_dict
+    S = 1024
+    cfg = dict(CFG, encoder_depth=2)
+    alp = FewShotSeg(S, None, cfg)
+    assert alp.config["feature_hw"] == [73, 73] and alp.cls_unit.kernel_size[0] == 9
+    alp_sd = synth_state_dict(alp, 1234)
+    alp.load_state_dict(alp_sd)
+    alp = alp.to(dev).eval()
+    model = ProtoMedSAM((1024, 1024), ALPNetWrapper(alp), "random:vit_b:1234:2", use_cca=True).to(dev).eval()
+    sam_sd = {k: v.cpu() for k, v in synth_state_dict(model.medsam, 1234).items()}
+    s_img, s_m, q_img, _ = synth_pair(S, seed=2)
+    enc_sd = {k[len("encoder."):]: v for k, v in alp_sd.items() if k.startswith("encoder.")}
+    enc = lambda im: odino.forward_features(im, enc_sd, "dinov2_b14", depth=2)["x_norm_patchtokens"]  # noqa: E731
+    # four "organs": the pair's ellipse and three others drawn on the support slice
+    masks = [s_m] + [torch.from_numpy(ellipse_mask(S, cy, cx, ry, rx)[None]) for cy, cx, ry, rx in
+                     ((0.25, 0.3, 0.1, 0.12), (0.7, 0.72, 0.14, 0.09), (0.3, 0.75, 0.08, 0.15))]
+    worst = 1.0
+    for ci, m in enumerate(masks):
+        inp = InputFactory.create_input(TYPE_ALPNET, q_img, support_images=[s_img], support_labels=[m], isval=True,
+                                        val_wsize=2)
+        inp.to(dev)
+        logits = alp(inp.supp_imgs, inp.fore_mask, inp.back_mask, inp.qry_imgs, True, 2)[0]
+        logits_ref = oalp.fewshot_forward(enc, s_img, m, q_img, S)
+        perr = (logits.cpu().softmax(1) - logits_ref.softmax(1)).abs().max().item()
+        seg, conf = model(q_img.to(dev), inp)
+        seg_ref, conf_ref = glue.protomedsam_forward(q_img, logits_ref, sam_sd, "vit_b", use_cca=True, encoder_depth=2)
+        assert seg.shape == (S, S) and seg.dtype == torch.uint8
+        if seg_ref.sum() == 0:
+            assert int(seg.sum()) == 0
+            continue
+        d = _dice(seg.cpu(), seg_ref)
+        worst = min(worst, d)
+        print(f"class {ci}: coarse prob err {perr:.2e}, Dice {d:.5f}, fg {int(seg_ref.sum())} px")
+        assert perr < 1e-3 and d > 0.995
+    assert worst > 0.995
