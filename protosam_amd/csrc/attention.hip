@@ -25,6 +25,7 @@
 // Rel-pos bias uses the UNSCALED q (image_encoder.py:242-245): rel_h/rel_w are produced by
 // psam_relpos from the same fp16 q and added in fp32 after the scale.
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 struct AttnArgs {
@@ -38,6 +39,7 @@ struct AttnArgs {
   float scale;
   int gh, gw, ws, nwx, nwin;  // token grid, window size, windows per row, windows per image
   int nqb;                    // query blocks per (batch, head) (global modes)
+  int dbg;                    // ablation switches (PSAM_ATTN_DBG): 1 no K/V global loads, 2 no LDS staging, 4 no tile compute
   long long ts, hs, ws_;      // qkv strides in halfs: token, head, which (q/k/v). token-major [B,N,3,H,hd]: 3*H*hd, hd, H*hd;
                               // head-major [3,H,B*N,hd] (psam_gemm_f16_heads): hd, B*N*hd, H*B*N*hd
 };
@@ -45,7 +47,9 @@ struct AttnArgs {
 #define KT 64  // keys per tile
 
 template <int HD, int MODE, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
+// HIP's second launch-bound argument is the minimum number of WAVES PER SIMD (not CUDA's blocks per multiprocessor): the
+// 7-wave window kernel needs 4 per SIMD (<= 128 VGPRs) for two workgroups to be co-resident on a CU
+__global__ __launch_bounds__(NW * 64, (MODE == 2 ? 4 : 2)) void attn_kernel(AttnArgs p) {
   constexpr int NT = NW * 64;
   constexpr int QB = NW * 32;
   constexpr int HDP = (HD + 31) / 32 * 32;
@@ -263,19 +267,20 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
   float mrun[2] = {-INFINITY, -INFINITY};
   float lrun[2] = {0.f, 0.f};
 
-  load_tile(0);
+  if (!(p.dbg & 1)) load_tile(0);
   __syncthreads();  // pad-column zeroing + rel tables visible
-  store_tile();
+  if (!(p.dbg & 2)) store_tile();
   __syncthreads();
 
   // one 64-key tile (NTT = 4 MFMA key tiles) or, for the window's last 4 keys, a single 16-key tile (NTT = 1);
   // `koff` = first resident key row / V^T column of the tile
-  auto compute_tile = [&](auto ntt_c, int tile, int koff) {
+  // kbase = global index of the tile's first key (masking, rel-pos), koff = its first resident row in Ks / column in Vt
+  auto compute_tile = [&](auto ntt_c, int kbase, int koff, bool last_partial) {
     constexpr int NTT = decltype(ntt_c)::value;
     // S^T = K Q^T
-    f32x4 st[4][2];
+    f32x4 st[NTT][2];
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt)
+    for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
           st[tt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qt][s], st[tt][qt], 0, 0, 0);
       }
       if (MODE == 2) {
-        const int kidx = tile * KT + krow;
+        const int kidx = kbase + krow;
         const unsigned lut = klut[kidx & 255];
         const int kh = lut & 0xff, kw = (int)(lut >> 8) + p.ws;  // slots of the two one-hots
         half8_t oh;
@@ -310,21 +315,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
     }
 
     // scale + bias + mask, online softmax (base-2 domain: scale and bias are pre-multiplied by log2(e))
-    half8_t pf[2][2];
-    if (NTT < 4) {
+    half8_t pf[2][(NTT + 1) / 2];
+    if constexpr ((NTT & 1) != 0) {
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) pf[qt][s2][e] = (half_t)0.f;
+        for (int e = 0; e < 8; ++e) pf[qt][NTT / 2][e] = (half_t)0.f;
     }
-    const bool last_partial = (tile == ntiles - 1) && (nkeys % KT != 0);  // wave-uniform
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       // bias that is constant over this lane's keys of the tile is added to the row max instead of to every element
       float bh2 = 0.f;
-      if (MODE == 1) bh2 = relh_q[qt][tile] * LOG2E;
+      if (MODE == 1) bh2 = relh_q[qt][kbase / KT] * LOG2E;
       float mx = -INFINITY;
 #pragma unroll
       for (int tt = 0; tt < NTT; ++tt) {
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
         for (int r = 0; r < 4; ++r) {
           float sv = MODE == 1 ? fmaf(st[tt][qt][r], sl2, rwv[r]) : st[tt][qt][r] * sl2;
           if (last_partial) {
-            const int kidx = tile * KT + (tt >> 1) * 32 + g * 8 + (tt & 1) * 4 + r;
+            const int kidx = kbase + (tt >> 1) * 32 + g * 8 + (tt & 1) * 4 + r;
             if (kidx >= nkeys) sv = -INFINITY;
           }
           st[tt][qt][r] = sv;
@@ -390,12 +392,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
 
   if (MODE == 2) {
     // the whole window is resident: no further loads, no barriers; each wave walks the key tiles on its own
-    for (int tile = 0; tile + 1 < ntiles; ++tile) compute_tile(std::integral_constant<int, 4>{}, tile, tile * KT);
-    compute_tile(std::integral_constant<int, 1>{}, ntiles - 1, (ntiles - 1) * KT);
+    // 32-key chunks (two MFMA key tiles = one PV k-step) keep the score / probability registers at half the size of a
+    // 64-key tile, which is what lets the kernel fit 128 VGPRs (4 waves per SIMD = two workgroups per CU)
+    if (!(p.dbg & 4)) {
+      for (int c = 0; c < 6; ++c) compute_tile(std::integral_constant<int, 2>{}, c * 32, c * 32, false);
+      compute_tile(std::integral_constant<int, 1>{}, 192, 192, true);
+    }
   } else {
     for (int tile = 0; tile < ntiles; ++tile) {
       if (tile + 1 < ntiles) load_tile(tile + 1);
-      compute_tile(std::integral_constant<int, 4>{}, tile, 0);
+      compute_tile(std::integral_constant<int, 4>{}, tile * KT, 0, (tile == ntiles - 1) && (nkeys % KT != 0));
       __syncthreads();  // everyone done reading Ks/Vt
       if (tile + 1 < ntiles) {
         store_tile();
@@ -470,6 +476,7 @@ extern "C" int psam_attention_f16(const void* qkv, void* out, const float* rel_h
   p.gw = gw;
   p.ws = ws;
   p.nwx = p.nwin = 0;
+  { const char* e = getenv("PSAM_ATTN_DBG"); p.dbg = e ? atoi(e) : 0; }
   if (mode == 1) {
     if (gw != KT || gh * gw != N || !rel_h || !rel_w) return PSAM_ERR_ARG;
   }

@@ -1,0 +1,19 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from protosam_amd import ops
+dev = torch.device("cuda:0")
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+H, hd, N = 16, 80, 4096
+qkv = torch.randn(B, N, 3, H, hd, device=dev).half()
+r = torch.randn(B, H, N, 2, 32, device=dev).half() * 0.1
+pad = torch.randn(3, H, hd, device=dev).half()
+out = torch.empty(B, N, H * hd, device=dev, dtype=torch.float16)
+def run(): ops.attention(qkv, B, N, H, hd, hd ** -0.5, out=out, mode=2, relq=r, gh=64, gw=64, ws=14, pad_row=pad)
+for _ in range(3): run()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20): run()
+e1.record(); torch.cuda.synchronize()
+print(f"dbg={os.environ.get('PSAM_ATTN_DBG','0')} B={B}: {e0.elapsed_time(e1)/20*1e3:.1f} us")
