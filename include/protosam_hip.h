@@ -51,12 +51,13 @@ int psam_layernorm(const float* x, const float* w, const float* b, void* y, floa
 /* Fused multi-head attention on the packed projection qkv half [B,N,3,H,hd] -> out half [B,N,H*hd]; hd in {64, 80}.
  * mode 0 global (DINOv2 Attention); mode 1 global + decomposed rel-pos (rel_h/rel_w fp32, gw == 64); mode 2 ws x ws
  * windows with the reference's zero padding (pad_row half [3,H,hd] = qkv bias) + rel-pos folded into the score MFMA
- * as 32 extra k-slots (relq half [B,H,N,2,32] from psam_relpos).
+ * as 32 extra k-slots (relq half [B,H,N,2,32] from psam_relpos, or relq = null and rpack = psam_relpos' windowed table
+ * pack: the query-side terms are then computed inside the kernel and never touch HBM).
  * head_major = 0: qkv is token-major [B,N,3,H,hd]; 1: head-major [3,H,B*N,hd] as written by psam_gemm_f16_heads.
  * image_encoder.py:235-251 (Attention.forward), :254-300 (window_partition / unpartition), :337-372. */
 int psam_attention_f16(const void* qkv, void* out, const float* rel_h, const float* rel_w, const void* relq,
-                       const void* pad_row, int B, int N, int H, int hd, float scale, int mode, int gh, int gw, int ws,
-                       int head_major, void* stream);
+                       const void* rpack, const void* pad_row, int B, int N, int H, int hd, float scale, int mode, int gh,
+                       int gw, int ws, int head_major, void* stream);
 
 /* rel_h[b,h,n,k] = q . Rh[qy - k + K-1], rel_w likewise (UNSCALED q), as an MFMA GEMM against the whole table followed by
  * a scatter. Rpack half [2 (h,w)][2 (hi,lo)][RP][HDP] (RP = 128 global / 32 windowed, zero padded).

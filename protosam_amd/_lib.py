@@ -22,7 +22,7 @@ SIGNATURES = {
     "psam_gemm_set_tile": [c_int],
     "psam_layernorm": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                        c_int, c_int, c_void_p],
-    "psam_attention_f16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+    "psam_attention_f16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                            c_float, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "psam_relpos": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_float, c_int, c_void_p],
     "psam_alp_bank": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float,

@@ -34,7 +34,8 @@ struct AttnArgs {
   const float* rel_h;     // mode1: [B,H,N,gw(64)]  mode2: [B,H,N,16]
   const float* rel_w;
   const half_t* pad_row;  // mode2: [3, H, HD] = fp16(qkv bias)
-  const half_t* relq;     // mode2: [B,H,N,2(hi,lo),32] = (rel_h[0:ws] | rel_w[0:ws] | 0) / scale, split in two halfs
+  const half_t* relq;     // mode2: [B,H,N,2(hi,lo),32] = (rel_h[0:ws] | rel_w[0:ws] | 0) / scale, split in two halfs; or null:
+  const half_t* rpack;    // mode2: psam_relpos' windowed table pack [2][2][32][HDP]: the rel-pos terms are computed in-kernel
   int B, N, H;
   float scale;
   int gh, gw, ws, nwx, nwin;  // token grid, window size, windows per row, windows per image
@@ -169,14 +170,66 @@ __global__ __launch_bounds__(NW * 64, (MODE == 2 ? 4 : 2)) void attn_kernel(Attn
       int kh = idx / p.ws, kw = idx - kh * p.ws;
       klut[idx] = (unsigned short)(kh | (kw << 8));
     }
+    if (p.rpack == nullptr) {
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      const half_t* rq = p.relq + (((size_t)b * H + h) * N + qtok[qt]) * 64 + g * 8;
-      qaug[qt][0] = *reinterpret_cast<const half8_t*>(rq);
-      qaug[qt][1] = *reinterpret_cast<const half8_t*>(rq + 32);
+      for (int qt = 0; qt < 2; ++qt) {
+        const half_t* rq = p.relq + (((size_t)b * H + h) * N + qtok[qt]) * 64 + g * 8;
+        qaug[qt][0] = *reinterpret_cast<const half8_t*>(rq);
+        qaug[qt][1] = *reinterpret_cast<const half8_t*>(rq + 32);
+      }
+    } else {
+      // Fused `add_decomposed_rel_pos` query side (image_encoder.py:337-372; what psam_relpos writes to `relq` otherwise):
+      // T[r][q] = q . R[r] for all 2*14-1 rows of both tables as MFMAs with the (hi + lo split) table as the A operand and
+      // the query fragments already in registers as B; the lane then gathers, through a wave-private corner of the (still
+      // empty) K stage, the 28 values its k-slots need: slot j < 14: T_h[qy + 13 - j], slot 14 + j: T_w[qx + 13 - j].
+      f32x4 D[2][2][2];
+#pragma unroll
+      for (int tab = 0; tab < 2; ++tab)
+#pragma unroll
+        for (int tile = 0; tile < 2; ++tile) {
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt) D[tab][tile][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int part = 0; part < 2; ++part)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+              const half8_t rf = *reinterpret_cast<const half8_t*>(
+                  p.rpack + ((size_t)((tab * 2 + part) * 32 + tile * 16 + li)) * HDP + s * 32 + g * 8);
+#pragma unroll
+              for (int qt = 0; qt < 2; ++qt)
+                D[tab][tile][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rf, qf[qt][s], D[tab][tile][qt], 0, 0, 0);
+            }
+        }
+      float* ts = reinterpret_cast<float*>(Ks) + wv * 1024;   // [tab 2][r 32][q 16] fp32 = 4 KiB per wave, one q-tile at a time
+      const float inv_scale = 1.0f / p.scale;
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+        for (int tab = 0; tab < 2; ++tab)
+#pragma unroll
+          for (int tile = 0; tile < 2; ++tile)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ts[(tab * 32 + tile * 16 + g * 4 + i) * 16 + li] = D[tab][tile][qt][i];
+        const int q = qrow_blk + qt * 16 + li;           // window-local query index (< 224)
+        const int qy = (q * 4682) >> 16, qx = q - 14 * qy;   // q / 14, q % 14
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int j = g * 8 + e;
+          float v = 0.f;
+          if (j < 28) {
+            const int tab = j >= 14;
+            const int r = (tab ? qx : qy) + 13 - (tab ? j - 14 : j);
+            v = ts[(tab * 32 + r) * 16 + li] * inv_scale;
+          }
+          const half_t hi = (half_t)v;
+          qaug[qt][0][e] = hi;
+          qaug[qt][1][e] = (half_t)(v - (float)hi);
+        }
+      }
     }
   }
 
+  if (MODE == 2 && p.rpack != nullptr) __syncthreads();   // every wave is done with its rel-pos scratch inside Ks
   // zero the K pad columns once (they are never overwritten)
   if (HDP > HD) {
     constexpr int PC = (HDP - HD) / 8;
@@ -453,8 +506,8 @@ static int launch_attn(AttnArgs p, int mode, hipStream_t s) {
 // mode 2: ws x ws windows over the gh x gw token map (zero-padded as the reference) + rel-pos folded into the MFMA
 //         (relq = psam_relpos' windowed output).
 extern "C" int psam_attention_f16(const void* qkv, void* out, const float* rel_h, const float* rel_w,
-                                  const void* relq, const void* pad_row, int B, int N, int H, int hd, float scale,
-                                  int mode, int gh, int gw, int ws, int head_major, void* stream) {
+                                  const void* relq, const void* rpack, const void* pad_row, int B, int N, int H, int hd,
+                                  float scale, int mode, int gh, int gw, int ws, int head_major, void* stream) {
   if (B <= 0 || N <= 0 || H <= 0 || mode < 0 || mode > 2) return PSAM_ERR_ARG;
   AttnArgs p;
   if (head_major) {
@@ -468,6 +521,7 @@ extern "C" int psam_attention_f16(const void* qkv, void* out, const float* rel_h
   p.rel_w = rel_w;
   p.pad_row = (const half_t*)pad_row;
   p.relq = (const half_t*)relq;
+  p.rpack = (const half_t*)rpack;
   p.B = B;
   p.N = N;
   p.H = H;
@@ -482,7 +536,7 @@ extern "C" int psam_attention_f16(const void* qkv, void* out, const float* rel_h
   }
   if (mode == 2) {
     // the resident-window schedule is laid out for 14 x 14 = 3 x 64 + 4 keys (SAM's window_size, build_sam.py:73)
-    if (ws != 14 || gh * gw != N || !relq || !pad_row) return PSAM_ERR_ARG;
+    if (ws != 14 || gh * gw != N || (!relq && !rpack) || !pad_row) return PSAM_ERR_ARG;
     p.nwx = (gw + ws - 1) / ws;
     p.nwin = p.nwx * ((gh + ws - 1) / ws);
   }

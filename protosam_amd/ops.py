@@ -41,6 +41,9 @@ GEMM_TIMER = None  # set to a KernelTimer to time psam_gemm_f16 launches
 # scattered 160-byte stores for the GEMM; measured on MI355X at 16 slices: 108.8 / 109.2 vs 109.8 / 109.2 slices/s - a wash)
 import os as _os
 QKV_HEAD_MAJOR = _os.environ.get("PSAM_QKV_HEAD_MAJOR", "0") != "0"
+# window layers: compute the decomposed rel-pos query terms inside the attention kernel (default) instead of a psam_relpos
+# launch that writes them to HBM (PSAM_FUSE_WINDOW_RELPOS=0, kept for A/B)
+FUSE_WINDOW_RELPOS = _os.environ.get("PSAM_FUSE_WINDOW_RELPOS", "1") != "0"
 
 
 def _ptr(t):
@@ -172,15 +175,15 @@ def layernorm(x, weight, bias, eps, out=None, out_dtype=torch.float16, out2=None
 
 
 def attention(qkv, B, N, H, hd, scale, out=None, mode=0, rel_h=None, rel_w=None, relq=None, pad_row=None, gh=0, gw=0,
-              ws=0, head_major=False):
+              ws=0, head_major=False, rpack=None):
     """qkv fp16 [B,N,3,H,hd] (packed as nn.Linear(dim,3*dim) emits it) or, head_major, [3,H,B*N,hd] (gemm_heads)
     -> fp16 [B,N,H*hd]."""
     _req(qkv, torch.float16, "qkv"); _req(rel_h, torch.float32, "rel_h"); _req(rel_w, torch.float32, "rel_w")
-    _req(pad_row, torch.float16, "pad_row"); _req(relq, torch.float16, "relq")
+    _req(pad_row, torch.float16, "pad_row"); _req(relq, torch.float16, "relq"); _req(rpack, torch.float16, "rpack")
     assert qkv.is_contiguous()
     if out is None:
         out = torch.empty((B, N, H * hd), dtype=torch.float16, device=qkv.device)
-    st = _lib.lib().psam_attention_f16(_ptr(qkv), _ptr(out), _ptr(rel_h), _ptr(rel_w), _ptr(relq), _ptr(pad_row), B, N,
+    st = _lib.lib().psam_attention_f16(_ptr(qkv), _ptr(out), _ptr(rel_h), _ptr(rel_w), _ptr(relq), _ptr(rpack), _ptr(pad_row), B, N,
                                       H, hd, float(scale), mode, gh, gw, ws, 1 if head_major else 0, _stream())
     _lib.check(st, "psam_attention_f16")
     return out

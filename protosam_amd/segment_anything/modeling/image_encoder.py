@@ -141,9 +141,14 @@ class ImageEncoderViT(nn.Module):
             else:
                 ops.gemm(ws["ln"], bp["qkv_w"], bp["qkv_b"], out=ws["qkv"], epilogue=ops.EPI_F16)
             if bp["ws"] > 0:
-                ops.relpos(ws["qkv"], bp["rpack"], B, N, H, hd, g, bp["ws"], True, hd ** -0.5, relq=ws["relq"], head_major=ops.QKV_HEAD_MAJOR)
-                ops.attention(ws["qkv"], B, N, H, hd, hd ** -0.5, out=ws["att"], mode=2, relq=ws["relq"],
-                              pad_row=bp["pad_row"], gh=g, gw=g, ws=bp["ws"], head_major=ops.QKV_HEAD_MAJOR)
+                if ops.FUSE_WINDOW_RELPOS:   # the query-side rel-pos terms are computed inside the attention kernel
+                    ops.attention(ws["qkv"], B, N, H, hd, hd ** -0.5, out=ws["att"], mode=2, rpack=bp["rpack"],
+                                  pad_row=bp["pad_row"], gh=g, gw=g, ws=bp["ws"], head_major=ops.QKV_HEAD_MAJOR)
+                else:
+                    ops.relpos(ws["qkv"], bp["rpack"], B, N, H, hd, g, bp["ws"], True, hd ** -0.5, relq=ws["relq"],
+                               head_major=ops.QKV_HEAD_MAJOR)
+                    ops.attention(ws["qkv"], B, N, H, hd, hd ** -0.5, out=ws["att"], mode=2, relq=ws["relq"],
+                                  pad_row=bp["pad_row"], gh=g, gw=g, ws=bp["ws"], head_major=ops.QKV_HEAD_MAJOR)
             else:
                 ops.relpos(ws["qkv"], bp["rpack"], B, N, H, hd, g, g, False, hd ** -0.5, rel_h=ws["relh"],
                            rel_w=ws["relw"], head_major=ops.QKV_HEAD_MAJOR)

@@ -228,3 +228,22 @@ def test_head_major_qkv_layout(dev):
     b = ops.attention(hm, B, N, H, hd, scale, mode=1, rel_h=rh, rel_w=rw, gh=g, gw=g, head_major=True)
     assert torch.equal(a, b)
     assert torch.equal(ops.attention(tokm, B, N, H, hd, scale), ops.attention(hm, B, N, H, hd, scale, head_major=True))
+
+
+def test_window_attention_fused_relpos(dev):
+    """mode 2 with the rel-pos query terms computed in-kernel (rpack) equals the two-kernel path (psam_relpos -> relq)."""
+    from protosam_amd import ops
+    for (H, hd) in ((16, 80), (12, 64)):
+        B, g, ws = 2, 64, 14
+        N = g * g
+        qkv = _rand((B, N, 3, H, hd), dev, 1.0, 51).half()
+        pad = _rand((3, H, hd), dev, 0.5, 52).half()
+        Rh, Rw = _rand((2 * ws - 1, hd), dev, 0.3, 53), _rand((2 * ws - 1, hd), dev, 0.3, 54)
+        rp = ops.pack_rel_tables(Rh, Rw, True, hd)
+        scale = hd ** -0.5
+        relq = ops.relpos(qkv, rp, B, N, H, hd, g, ws, True, scale)
+        a = ops.attention(qkv, B, N, H, hd, scale, mode=2, relq=relq, pad_row=pad, gh=g, gw=g, ws=ws)
+        b = ops.attention(qkv, B, N, H, hd, scale, mode=2, rpack=rp, pad_row=pad, gh=g, gw=g, ws=ws)
+        err = (a.float() - b.float()).abs().max().item()
+        print(f"H{H} hd{hd}: fused vs two-kernel max abs diff {err:.2e}")
+        assert err < 2e-3 and torch.isfinite(b.float()).all()
