@@ -496,16 +496,21 @@ class ProtoSAM(nn.Module):
         return results
 
     def _coarse_only(self, output_logits, original_size):
-        """ProtoSAM.py:580-590 (inference): argmax map, mean fg confidence; optional CCA keeps the best component."""
+        """ProtoSAM.py:580-590 (inference): logits (bilinear to the query's size if they differ) -> argmax map, mean fg
+        confidence (get_confidence_from_logits); optional CCA keeps the best component and reports its confidence."""
         dev = output_logits.device
-        H = output_logits.shape[-2]
-        if H != 1024:
-            raise NotImplementedError("coarse_pred_only is wired for 1024x1024 logits only")
-        bufs = self._work_buffers(dev, 1)
+        H = int(original_size)
+        key = ("coarse", str(dev), H)
+        if key not in self._bufs:
+            self._bufs[key] = dict(fg_sum=torch.zeros(1, dtype=torch.int32, device=dev),
+                                   prob=torch.empty((1, 2, H, H), dtype=torch.float32, device=dev),
+                                   pred=torch.empty((1, H, H), dtype=torch.uint8, device=dev),
+                                   ccl=ops.CclWorkspace(H, H, MAX_COMPONENTS, dev, slots=1))
+        bufs = self._bufs[key]
         bufs["fg_sum"].zero_()
         prob, pred = ops.prob_argmax(output_logits.float().contiguous(), H, H, prob=bufs["prob"], pred=bufs["pred"],
                                      fg_sum=bufs["fg_sum"])
-        cw = ops.ccl(pred[0], prob[0, 1], self._ccl, fg_sum=bufs["fg_sum"])
+        cw = ops.ccl(pred[0], prob[0, 1], bufs["ccl"], fg_sum=bufs["fg_sum"])
         tab = cw.tab.cpu().numpy()
         n = int(tab[1])
         rows = tab[ops.CC_HDR:ops.CC_HDR + ops.CC_STRIDE * n].reshape(n, ops.CC_STRIDE)

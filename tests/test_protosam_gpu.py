@@ -370,3 +370,35 @@ def test_config5_medsam_1024_four_classes(dev):
         print(f"class {ci}: coarse prob err {perr:.2e}, Dice {d:.5f}, fg {int(seg_ref.sum())} px")
         assert perr < 1e-3 and d > 0.995
     assert worst > 0.995
+
+
+@pytest.mark.parametrize("use_cca", [False, True])
+def test_coarse_pred_only(dev, use_cca):
+    """coarse_pred_only=True (ProtoSAM.py:580-590): the ALPNet argmax map at the query's own size and its mean foreground
+    confidence; with use_cca only the most confident component (util/utils.py:496-541) and ITS confidence."""
+    from oracle import alp as oalp, dinov2 as odino, glue
+    from protosam_amd.protosam import InputFactory, TYPE_ALPNET
+    from protosam_amd.synth import synth_pair
+    dino_depth = 12
+    model, alp_sd = _build(dev, "random:vit_b:1234:1", dino_depth, use_bbox=True, use_points=True, coarse_pred_only=True,
+                           use_cca=use_cca)
+    s_img, s_m, q_img, _ = synth_pair(512, seed=0)
+    inp = InputFactory.create_input(TYPE_ALPNET, q_img, support_images=[s_img], support_labels=[s_m], isval=True,
+                                    val_wsize=2)
+    inp.to(dev)
+    pred, conf = model(q_img.to(dev), inp)
+    assert pred.shape == (512, 512) and pred.dtype == torch.int64 and len(conf) == 1
+    enc_sd = {k[len("encoder."):]: v for k, v in alp_sd.items() if k.startswith("encoder.")}
+    enc = lambda im: odino.forward_features(im, enc_sd, "dinov2_b14", depth=dino_depth)["x_norm_patchtokens"]  # noqa
+    logits = oalp.fewshot_forward(enc, s_img, s_m, q_img, 512)
+    ref = logits.argmax(1)[0].numpy()
+    if not use_cca:
+        conf_ref = glue.confidence_from_logits(logits)
+    else:
+        cc, confs = glue.get_connected_components(ref, logits)
+        k = max(confs, key=lambda j: confs[j])
+        conf_ref = float(confs[k])
+        ref = (cc[1] == k).astype(np.int64) if conf_ref > 0 else ref
+    flips = int((pred.cpu().numpy() != ref).sum())
+    print(f"coarse_pred_only use_cca={use_cca}: {flips} differing pixels of 262144, conf {conf[0]:.5f} vs {conf_ref:.5f}")
+    assert flips <= 40 and abs(float(conf[0]) - conf_ref) < 2e-3
