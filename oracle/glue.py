@@ -195,11 +195,23 @@ def quantise_image(query_image_1024):
 
 
 def sam_preprocess(img_u8_hwc):
-    """predictor.py:56-58,88 + sam.py:163-173 (1024x1024 input: resize and pad are identities)."""
+    """predictor.py:56-58,88 + sam.py:163-173: normalise, zero-pad bottom / right to 1024 (input already at long side 1024)."""
     x = torch.as_tensor(img_u8_hwc).permute(2, 0, 1).contiguous()[None]
     mean = torch.tensor(PIXEL_MEAN).view(-1, 1, 1)
     std = torch.tensor(PIXEL_STD).view(-1, 1, 1)
-    return (x - mean) / std
+    x = (x - mean) / std
+    return F.pad(x, (0, 1024 - x.shape[-1], 0, 1024 - x.shape[-2]))
+
+
+def apply_image(img_u8_hwc, target=1024):
+    """utils/transforms.py:32-38: PIL bilinear resize to long side `target` (torchvision's resize(to_pil_image(.)))."""
+    from PIL import Image
+    h, w = img_u8_hwc.shape[:2]
+    scale = target * 1.0 / max(h, w)
+    nh, nw = int(h * scale + 0.5), int(w * scale + 0.5)
+    if (nh, nw) == (h, w):
+        return np.array(img_u8_hwc)
+    return np.array(Image.fromarray(img_u8_hwc).resize((nw, nh), Image.BILINEAR))
 
 
 def mask_prompts(cc):

@@ -208,7 +208,7 @@ def apply_coords(coords, original_size, target=IMG):
 
 
 def predict(sd, features, point_coords, point_labels, box, multimask_output, original_size, variant="upstream",
-            mask_input=None):
+            mask_input=None, input_size=(IMG, IMG)):
     """predictor.py:92-241 for one prompt set. Returns (masks bool [C,H,W], iou [C], low_res [C,256,256])."""
     pts = None
     if point_coords is not None:
@@ -224,5 +224,5 @@ def predict(sd, features, point_coords, point_labels, box, multimask_output, ori
         mk = torch.as_tensor(mask_input, dtype=torch.float)[None, :, :, :]
     sparse, dense = prompt_encoder(sd, pts, bx, masks=mk)
     low, iou = mask_decoder(sd, features, dense_pe(sd), sparse, dense, multimask_output)
-    masks = postprocess_masks(low, (IMG, IMG), original_size, variant)
+    masks = postprocess_masks(low, input_size, original_size, variant)
     return (masks > 0.0)[0], iou[0], low[0]

@@ -31,8 +31,8 @@ class ProtoMedSAM(nn.Module):
         self.coarse_pred_only = coarse_pred_only
         self.debug = debug
         self.use_cca = use_cca
-        if debug or coarse_pred_only:
-            raise NotImplementedError("debug plots / coarse_pred_only are outside the accelerated path")
+        if debug:
+            raise NotImplementedError("debug plots are outside the accelerated path")
         if tuple(self.image_size) != (1024, 1024):
             raise NotImplementedError("image_size must be (1024, 1024) as in validation_protosam.py:234")
         self._ccl = None
@@ -77,6 +77,9 @@ class ProtoMedSAM(nn.Module):
         dev = query_image.device
         coarse_model_input.set_query_images(query_image)
         output_logits = self.coarse_segmentation_model(coarse_model_input)                 # [1,2,H,W] ALP logits
+        if self.coarse_pred_only:                                                          # ProtoMedSAM.py:163-172
+            from .protosam import ProtoSAM
+            return ProtoSAM._coarse_only(self, output_logits, original_size)
         bufs = self._work(dev)
         sam = self.medsam
         S = sam.image_encoder.img_size

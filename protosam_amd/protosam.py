@@ -500,13 +500,14 @@ class ProtoSAM(nn.Module):
         confidence (get_confidence_from_logits); optional CCA keeps the best component and reports its confidence."""
         dev = output_logits.device
         H = int(original_size)
-        key = ("coarse", str(dev), H)
-        if key not in self._bufs:
-            self._bufs[key] = dict(fg_sum=torch.zeros(1, dtype=torch.int32, device=dev),
+        key = (str(dev), H)
+        cache = self.__dict__.setdefault("_coarse_bufs", {})     # (also called with a ProtoMedSAM as `self`)
+        if key not in cache:
+            cache[key] = dict(fg_sum=torch.zeros(1, dtype=torch.int32, device=dev),
                                    prob=torch.empty((1, 2, H, H), dtype=torch.float32, device=dev),
                                    pred=torch.empty((1, H, H), dtype=torch.uint8, device=dev),
                                    ccl=ops.CclWorkspace(H, H, MAX_COMPONENTS, dev, slots=1))
-        bufs = self._bufs[key]
+        bufs = cache[key]
         bufs["fg_sum"].zero_()
         prob, pred = ops.prob_argmax(output_logits.float().contiguous(), H, H, prob=bufs["prob"], pred=bufs["pred"],
                                      fg_sum=bufs["fg_sum"])

@@ -37,24 +37,31 @@ class Sam(nn.Module):
         return _VARIANT[self.postprocess_variant]
 
     def preprocess(self, x):
-        """sam.py:163-173: (x - pixel_mean) / pixel_std, then pad to 1024 (a no-op for the square inputs of this path)."""
+        """sam.py:163-173: (x - pixel_mean) / pixel_std, then zero-pad bottom / right to the square model input."""
         h, w = x.shape[-2:]
         S = self.image_encoder.img_size
-        if (h, w) != (S, S):
-            raise NotImplementedError("inputs are 1024x1024 on this path (ProtoSAM resizes first, ProtoSAM.py:592-594)")
+        if h > S or w > S:
+            raise ValueError(f"preprocess expects images with long side <= {S}, got {(h, w)}")
         if x.dtype not in (torch.uint8, torch.float32):
             x = x.float()
-        return ops.normalize_chw(x.contiguous(), self._mean_host, self._std_host)
+        y = ops.normalize_chw(x.contiguous(), self._mean_host, self._std_host)
+        if (h, w) == (S, S):
+            return y
+        out = torch.zeros(tuple(y.shape[:-2]) + (S, S), dtype=torch.float32, device=y.device)
+        out[..., :h, :w] = y
+        return out
 
     def postprocess_masks(self, masks, input_size, original_size):
-        """low-res logits [B,C,256,256] -> [B,C,*original_size]. Square 1024 inputs only (see preprocess)."""
+        """low-res logits [B,C,256,256] -> [B,C,*original_size]: up-sample to the model input, drop the padding, resize to
+        the original image (sam.py:132-160 / :296-320)."""
         S = self.image_encoder.img_size
-        if tuple(int(v) for v in input_size) != (S, S):
-            raise NotImplementedError("non-square / padded inputs")
-        up = ops.mask_upsample(masks.float().contiguous(), S, self.variant_id())
-        if tuple(int(v) for v in original_size) == (S, S):
-            return up
+        ih, iw = (int(v) for v in input_size)
         oh, ow = (int(v) for v in original_size)
+        up = ops.mask_upsample(masks.float().contiguous(), S, self.variant_id())
+        if (ih, iw) != (S, S):
+            up = up[..., :ih, :iw].contiguous()
+        if (oh, ow) == (ih, iw):
+            return up
         if self.postprocess_variant == "upstream":
             return ops.bilinear_nchw(up, oh, ow)
-        raise NotImplementedError("second-stage resize for the vendored variants at original_size != 1024")
+        raise NotImplementedError("second-stage resize for the vendored variants when original_size != input_size")

@@ -1,8 +1,9 @@
 """`SamPredictor` (models/segment_anything/predictor.py:17-269) over the HIP-backed `Sam`.
 
 Same methods, arguments, return types (numpy from `predict`, tensors from `predict_torch`) and the same RuntimeError
-when predicting before `set_image`. Images must already be 1024 on their long side and square (what ProtoSAM hands
-over, models/ProtoSAM.py:592-594,651-660), so `ResizeLongestSide.apply_image` is the identity.
+when predicting before `set_image`. ProtoSAM hands over 1024x1024 images (models/ProtoSAM.py:592-594,651-660), for
+which `apply_image`, the padding and the second post-processing resize are identities; other sizes take the reference's
+route: PIL resize on the host, zero padding after normalisation, crop + resize of the mask logits.
 """
 import numpy as np
 import torch

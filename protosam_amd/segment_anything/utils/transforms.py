@@ -1,6 +1,8 @@
-"""`ResizeLongestSide` (models/segment_anything/utils/transforms.py:17-148): coordinate / box scaling and the target
-shape rule. Image resizing itself is the identity on this path (everything SAM sees is already 1024x1024); the PIL /
-antialiased-torch resizes of other sizes are outside the hot path and raise."""
+"""`ResizeLongestSide` (models/segment_anything/utils/transforms.py:17-148): coordinate / box scaling, the target shape
+rule and the numpy image resize. On the hot path every image is already 1024x1024 and resizing is the identity; other
+sizes go through PIL's bilinear resize on the host exactly as the reference does (`resize(to_pil_image(image), size)`
+is `PIL.Image.resize(size[::-1], BILINEAR)`, :38). The antialiased torch resize of `apply_image_torch` is only ever the
+identity for ProtoSAM and raises otherwise."""
 from copy import deepcopy
 
 import numpy as np
@@ -20,9 +22,11 @@ class ResizeLongestSide:
         return (int(newh + 0.5), int(neww + 0.5))
 
     def apply_image(self, image):
-        if self.get_preprocess_shape(image.shape[0], image.shape[1], self.target_length) != tuple(image.shape[:2]):
-            raise NotImplementedError("PIL resize of non-1024 images is outside the accelerated path")
-        return np.array(image)
+        target = self.get_preprocess_shape(image.shape[0], image.shape[1], self.target_length)
+        if target == tuple(image.shape[:2]):
+            return np.array(image)
+        from PIL import Image  # host-side, as in the reference (torchvision's PIL path)
+        return np.array(Image.fromarray(image).resize((target[1], target[0]), Image.BILINEAR))
 
     def apply_image_torch(self, image):
         if self.get_preprocess_shape(image.shape[-2], image.shape[-1], self.target_length) != tuple(image.shape[-2:]):

@@ -402,3 +402,26 @@ def test_coarse_pred_only(dev, use_cca):
     flips = int((pred.cpu().numpy() != ref).sum())
     print(f"coarse_pred_only use_cca={use_cca}: {flips} differing pixels of 262144, conf {conf[0]:.5f} vs {conf_ref:.5f}")
     assert flips <= 40 and abs(float(conf[0]) - conf_ref) < 2e-3
+
+
+def test_protomedsam_coarse_pred_only(dev):
+    from protosam_amd.grid_proto_fewshot import FewShotSeg
+    from protosam_amd.protomedsam import ProtoMedSAM
+    from protosam_amd.protosam import ALPNetWrapper, InputFactory, TYPE_ALPNET
+    from protosam_amd.synth import synth_pair, synth_state_dict
+    cfg = dict(CFG, encoder_depth=2)
+    alp = FewShotSeg(512, None, cfg)
+    alp.load_state_dict(synth_state_dict(alp, 1234))
+    alp = alp.to(dev).eval()
+    s_img, s_m, q_img, _ = synth_pair(512, seed=0)
+    inp = InputFactory.create_input(TYPE_ALPNET, q_img, support_images=[s_img], support_labels=[s_m], isval=True, val_wsize=2)
+    inp.to(dev)
+    logits = alp(inp.supp_imgs, inp.fore_mask, inp.back_mask, [q_img.to(dev)], True, 2)[0]
+    for use_cca in (False, True):
+        m = ProtoMedSAM((1024, 1024), ALPNetWrapper(alp), "random:vit_b:1234:1", use_cca=use_cca, coarse_pred_only=True).to(dev).eval()
+        pred, conf = m(q_img.to(dev), inp)
+        assert pred.shape == (512, 512) and len(conf) == 1 and 0.0 <= float(conf[0]) <= 1.0
+        if not use_cca:
+            assert torch.equal(pred.bool(), logits.argmax(1)[0].bool())
+        else:
+            assert int(pred.sum()) <= int(logits.argmax(1)[0].sum())

@@ -137,3 +137,34 @@ def test_mask_prompt_embedding_and_predict(dev):
     assert e_low < 5e-3 and e_iou < 5e-3
     with pytest.raises(ValueError):
         sam.prompt_encoder(points=None, boxes=None, masks=torch.zeros((1, 1, 128, 128), device=dev))
+
+
+@pytest.mark.parametrize("hw", [(600, 900), (1024, 768), (300, 300)])
+def test_predictor_arbitrary_image_size(dev, hw):
+    """SamPredictor on images that are not 1024x1024: PIL resize of the long side, zero padding after normalisation, prompt
+    coordinates scaled by ResizeLongestSide, mask logits cropped and resized back (predictor.py:34-90,92-241; sam.py:132-173)."""
+    from oracle import glue, sam_image_encoder as oenc, sam_prompt_decoder as odec
+    from protosam_amd.segment_anything import SamPredictor
+    sam, sd = _sam(dev, "vit_b", 2)
+    rng = np.random.RandomState(hw[0])
+    import scipy.ndimage as ndi
+    img = np.stack([ndi.gaussian_filter(rng.rand(*hw), 6 + c) for c in range(3)], -1)
+    img = ((img - img.min()) / (img.max() - img.min()) * 255).astype(np.uint8)
+    pred = SamPredictor(sam)
+    pred.set_image(img)
+    pts = np.array([[hw[1] * 0.4, hw[0] * 0.5], [hw[1] * 0.6, hw[0] * 0.3]])
+    lab = np.array([1, 0])
+    box = np.array([hw[1] * 0.2, hw[0] * 0.1, hw[1] * 0.8, hw[0] * 0.9])
+    masks, iou, low = pred.predict(point_coords=pts, point_labels=lab, box=box, multimask_output=True)
+    assert masks.shape == (3,) + hw and masks.dtype == bool and low.shape == (3, 256, 256)
+    # oracle
+    rz = glue.apply_image(img)
+    assert tuple(rz.shape[:2]) == tuple(pred.input_size) and max(rz.shape[:2]) == 1024
+    feats = oenc.image_encoder(glue.sam_preprocess(rz), sd, model_type="vit_b", depth=2)
+    m_ref, iou_ref, low_ref = odec.predict(sd, feats, pts, lab, box, True, hw, input_size=tuple(rz.shape[:2]))
+    perr = (torch.sigmoid(torch.from_numpy(low)) - torch.sigmoid(low_ref)).abs().max().item()
+    d = min(2.0 * (masks[c] & m_ref[c].numpy()).sum() / max(masks[c].sum() + m_ref[c].numpy().sum(), 1) for c in range(3)
+            if m_ref[c].any())
+    print(f"{hw}: input {pred.input_size}, max |dprob(low_res)| {perr:.2e}, iou err {np.abs(iou - iou_ref.numpy()).max():.2e}, "
+          f"min Dice {d:.5f}")
+    assert perr < 5e-3 and np.abs(iou - iou_ref.numpy()).max() < 5e-3 and d > 0.99
