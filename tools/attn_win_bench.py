@@ -9,11 +9,18 @@ qkv = torch.randn(B, N, 3, H, hd, device=dev).half()
 r = torch.randn(B, H, N, 2, 32, device=dev).half() * 0.1
 pad = torch.randn(3, H, hd, device=dev).half()
 out = torch.empty(B, N, H * hd, device=dev, dtype=torch.float16)
-def run(): ops.attention(qkv, B, N, H, hd, hd ** -0.5, out=out, mode=2, relq=r, gh=64, gw=64, ws=14, pad_row=pad)
+Rh, Rw = torch.randn(27, hd, device=dev) * 0.3, torch.randn(27, hd, device=dev) * 0.3
+rp = ops.pack_rel_tables(Rh, Rw, True, hd)
+FUSED = os.environ.get("FUSED", "0") == "1"
+def run():
+    if FUSED:
+        ops.attention(qkv, B, N, H, hd, hd ** -0.5, out=out, mode=2, rpack=rp, gh=64, gw=64, ws=14, pad_row=pad)
+    else:
+        ops.attention(qkv, B, N, H, hd, hd ** -0.5, out=out, mode=2, relq=r, gh=64, gw=64, ws=14, pad_row=pad)
 for _ in range(3): run()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(20): run()
 e1.record(); torch.cuda.synchronize()
-print(f"dbg={os.environ.get('PSAM_ATTN_DBG','0')} B={B}: {e0.elapsed_time(e1)/20*1e3:.1f} us")
+print(f"fused={int(FUSED)} dbg={os.environ.get('PSAM_ATTN_DBG','0')} B={B}: {e0.elapsed_time(e1)/20*1e3:.1f} us")
