@@ -57,14 +57,24 @@ __global__ __launch_bounds__(NW * 64, (MODE == 2 ? 4 : 2)) void attn_kernel(Attn
   constexpr int KS = HDP / 32;
   constexpr int DT = HD / 16;
   constexpr int CH = HD / 8;       // 16-byte chunks per row
-  constexpr int KLD = HDP + 8;     // Ks row stride (halfs)
+  // LDS images are XOR-swizzled in 16-byte chunks instead of padded (bank model of MI355X_MICROARCH.md, checked with
+  // SQ_LDS_BANK_CONFLICT: the padded [64][104] / [80][72] images cost 2x on every fragment read and ~6x on the transposing
+  // V writes - 64 % of all LDS cycles of the global kernel were conflict cycles):
+  //   K  [row][HDP]:  chunk ^= (row >> 2) & 3            (hd = 80: 12 chunks per row; hd = 64 keeps its padded row)
+  //   V^T[d][VLD]:    chunk ^= (d >> VSH) & VMSK         (64-key tile: 10 chunks per row, (d>>4)&7 for hd 80, (d>>2)&7 for
+  //                                                       hd 64; the window kernel keeps its padded images)
+  constexpr bool KSWZ = HDP != HD && MODE != 2;          // hd = 80, global modes (the window kernel sits at its 128-VGPR
+                                                         // budget; the swizzle arithmetic made it spill 244 bytes: it keeps padding)
+  constexpr int KLD = KSWZ ? HDP : HDP + 8;              // Ks row stride (halfs)
   // window mode keeps the WHOLE window (196 keys in 3 x 64 + 1 x 16 MFMA key tiles; K rows zero-padded to 200, V^T columns to 224; 78.7 KB -> two
   // workgroups per CU) resident in LDS:
   // one load phase with every request in flight at once and one barrier, instead of a load/store/2-barrier round per
   // 64-key tile (measured before: 40 us per window-head for ~2 us of MFMA work - latency and rendezvous bound)
   constexpr int KRES = MODE == 2 ? 200 : KT;          // key rows resident in Ks (masked rows of the last key tile clamp to 199)
   constexpr int VCOL = MODE == 2 ? 224 : KT;          // key columns resident in Vt
-  constexpr int VLD = VCOL + 8;    // Vt row stride (halfs)
+  constexpr int VLD = MODE == 2 ? VCOL + 8 : VCOL + 16;   // Vt row stride (halfs): padded (window) / 10 chunks, swizzled
+  constexpr int VSH = (MODE == 2 || HD == 80) ? 4 : 2;
+  constexpr int VMSK = MODE == 2 ? 0 : 7;
   constexpr int NKL = (KRES * CH + NT - 1) / NT;        // K chunk loads per thread (per load phase)
   constexpr int NVL = ((VCOL / 2) * CH + NT - 1) / NT;  // V chunk-pair loads per thread
   const float LOG2E = 1.4426950408889634f;
@@ -72,8 +82,10 @@ __global__ __launch_bounds__(NW * 64, (MODE == 2 ? 4 : 2)) void attn_kernel(Attn
 
   __shared__ __attribute__((aligned(16))) half_t Ks[KRES * KLD];
   __shared__ __attribute__((aligned(16))) half_t Vt[HD * VLD];
+  auto koff_of = [](int row, int chunk) { return row * KLD + ((KSWZ ? (chunk ^ ((row >> 2) & 3)) : chunk) << 3); };
+  auto voff_of = [](int d, int chunk) { return d * VLD + ((chunk ^ ((d >> VSH) & VMSK)) << 3); };
   __shared__ unsigned short klut[MODE == 2 ? 256 : 1];  // window key index -> kh | (kw << 8)
-  constexpr int RWLD = 68;                               // padded row (floats) of the rel_w stage
+  constexpr int RWLD = 64;                               // rel_w stage row (floats); 16-byte chunks XOR-swizzled by q & 15
   __shared__ __attribute__((aligned(16))) float relw_s[MODE == 1 ? QB * RWLD : 4];  // rel_w[q][kw] * log2(e)
 
   const int t = threadIdx.x;
@@ -158,7 +170,7 @@ __global__ __launch_bounds__(NW * 64, (MODE == 2 ? 4 : 2)) void attn_kernel(Attn
       q = q < N ? q : N - 1;
       float4 v = *reinterpret_cast<const float4*>(p.rel_w + (((size_t)b * H + h) * N + q) * (size_t)p.gw + c4 * 4);
       v.x *= LOG2E; v.y *= LOG2E; v.z *= LOG2E; v.w *= LOG2E;
-      *reinterpret_cast<float4*>(&relw_s[qr * RWLD + c4 * 4]) = v;
+      *reinterpret_cast<float4*>(&relw_s[qr * RWLD + ((c4 ^ (qr & 15)) << 2)]) = v;
     }
   }
   // MODE 2: the decomposed rel-pos bias is folded into the S^T MFMA as 32 extra k-slots:
@@ -235,7 +247,7 @@ __global__ __launch_bounds__(NW * 64, (MODE == 2 ? 4 : 2)) void attn_kernel(Attn
     constexpr int PC = (HDP - HD) / 8;
     for (int idx = t; idx < KRES * PC; idx += NT) {
       int key = idx / PC, c = idx % PC;
-      *reinterpret_cast<uint4*>(&Ks[key * KLD + HD + c * 8]) = make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(&Ks[koff_of(key, HD / 8 + c)]) = make_uint4(0, 0, 0, 0);
     }
   }
 
@@ -286,7 +298,7 @@ __global__ __launch_bounds__(NW * 64, (MODE == 2 ? 4 : 2)) void attn_kernel(Attn
       int idx = t + i * NT;
       if (idx < KRES * CH) {
         int key = idx / CH, c = idx % CH;
-        *reinterpret_cast<uint4*>(&Ks[key * KLD + c * 8]) = kreg[i];
+        *reinterpret_cast<uint4*>(&Ks[koff_of(key, c)]) = kreg[i];
       }
     }
 #pragma unroll
@@ -301,8 +313,8 @@ __global__ __launch_bounds__(NW * 64, (MODE == 2 ? 4 : 2)) void attn_kernel(Attn
           // elements 2e, 2e+1 of both keys -> Vt[c*8+2e][2kp..2kp+1], Vt[c*8+2e+1][2kp..2kp+1]
           uint32_t lo = (a[e] & 0xffffu) | (bb[e] << 16);
           uint32_t hi = (a[e] >> 16) | (bb[e] & 0xffff0000u);
-          *reinterpret_cast<uint32_t*>(&Vt[(c * 8 + 2 * e) * VLD + 2 * kp]) = lo;
-          *reinterpret_cast<uint32_t*>(&Vt[(c * 8 + 2 * e + 1) * VLD + 2 * kp]) = hi;
+          *reinterpret_cast<uint32_t*>(&Vt[voff_of(c * 8 + 2 * e, kp >> 2) + 2 * (kp & 3)]) = lo;
+          *reinterpret_cast<uint32_t*>(&Vt[voff_of(c * 8 + 2 * e + 1, kp >> 2) + 2 * (kp & 3)]) = hi;
         }
       }
     }
@@ -344,7 +356,7 @@ __global__ __launch_bounds__(NW * 64, (MODE == 2 ? 4 : 2)) void attn_kernel(Attn
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         const int kr = (MODE == 2 && NTT < 4) ? min(koff + krow, KRES - 1) : koff + krow;  // clamped rows are masked keys
-        half8_t kf = *reinterpret_cast<const half8_t*>(&Ks[kr * KLD + s * 32 + g * 8]);
+        half8_t kf = *reinterpret_cast<const half8_t*>(&Ks[koff_of(kr, s * 4 + g)]);
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
           st[tt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qt][s], st[tt][qt], 0, 0, 0);
@@ -386,7 +398,7 @@ __global__ __launch_bounds__(NW * 64, (MODE == 2 ? 4 : 2)) void attn_kernel(Attn
         float4 rw4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (MODE == 1)
           rw4 = *reinterpret_cast<const float4*>(
-              &relw_s[(wv * 32 + qt * 16 + li) * RWLD + (tt >> 1) * 32 + g * 8 + (tt & 1) * 4]);
+              &relw_s[(wv * 32 + qt * 16 + li) * RWLD + ((((tt >> 1) * 8 + g * 2 + (tt & 1)) ^ li) << 2)]);
         const float rwv[4] = {rw4.x, rw4.y, rw4.z, rw4.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -435,7 +447,7 @@ __global__ __launch_bounds__(NW * 64, (MODE == 2 ? 4 : 2)) void attn_kernel(Attn
     for (int d = 0; d < DT; ++d) {
 #pragma unroll
       for (int s2 = 0; s2 < (NTT + 1) / 2; ++s2) {
-        half8_t vf = *reinterpret_cast<const half8_t*>(&Vt[(d * 16 + li) * VLD + koff + s2 * 32 + g * 8]);
+        half8_t vf = *reinterpret_cast<const half8_t*>(&Vt[voff_of(d * 16 + li, (koff >> 3) + s2 * 4 + g)]);
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
           ot[d][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qt][s2], ot[d][qt], 0, 0, 0);
