@@ -64,7 +64,8 @@ __global__ __launch_bounds__(NW * 64, (MODE == 2 ? 4 : 2)) void attn_kernel(Attn
   //   V^T[d][VLD]:    chunk ^= (d >> VSH) & VMSK         (64-key tile: 10 chunks per row, (d>>4)&7 for hd 80, (d>>2)&7 for
   //                                                       hd 64; the window kernel keeps its padded images)
   constexpr bool KSWZ = HDP != HD && MODE != 2;          // hd = 80, global modes (the window kernel sits at its 128-VGPR
-                                                         // budget; the swizzle arithmetic made it spill 244 bytes: it keeps padding)
+                                                         // budget: with the swizzle arithmetic it spills 92 bytes and runs 12 %
+                                                         // slower, so its K image stays padded and its V^T padding is 30 chunks)
   constexpr int KLD = KSWZ ? HDP : HDP + 8;              // Ks row stride (halfs)
   // window mode keeps the WHOLE window (196 keys in 3 x 64 + 1 x 16 MFMA key tiles; K rows zero-padded to 200, V^T columns to 224; 78.7 KB -> two
   // workgroups per CU) resident in LDS:
@@ -72,7 +73,8 @@ __global__ __launch_bounds__(NW * 64, (MODE == 2 ? 4 : 2)) void attn_kernel(Attn
   // 64-key tile (measured before: 40 us per window-head for ~2 us of MFMA work - latency and rendezvous bound)
   constexpr int KRES = MODE == 2 ? 200 : KT;          // key rows resident in Ks (masked rows of the last key tile clamp to 199)
   constexpr int VCOL = MODE == 2 ? 224 : KT;          // key columns resident in Vt
-  constexpr int VLD = MODE == 2 ? VCOL + 8 : VCOL + 16;   // Vt row stride (halfs): padded (window) / 10 chunks, swizzled
+  constexpr int VLD = VCOL + 16;   // Vt row stride (halfs): window 30 chunks, padded only (conflict-free fragment reads by the
+                                   // bank model; 29 chunks cost 2x); 64-key tile: 10 chunks, swizzled
   constexpr int VSH = (MODE == 2 || HD == 80) ? 4 : 2;
   constexpr int VMSK = MODE == 2 ? 0 : 7;
   constexpr int NKL = (KRES * CH + NT - 1) / NT;        // K chunk loads per thread (per load phase)
