@@ -60,13 +60,15 @@ __global__ __launch_bounds__(NW * 64, (MODE == 2 ? 4 : 2)) void attn_kernel(Attn
   // LDS images are XOR-swizzled in 16-byte chunks instead of padded (bank model of MI355X_MICROARCH.md, checked with
   // SQ_LDS_BANK_CONFLICT: the padded [64][104] / [80][72] images cost 2x on every fragment read and ~6x on the transposing
   // V writes - 64 % of all LDS cycles of the global kernel were conflict cycles):
-  //   K  [row][HDP]:  chunk ^= (row >> 2) & 3            (hd = 80: 12 chunks per row; hd = 64 keeps its padded row)
+  //   K  [row][HDP]:  chunk ^= (row >> 2) & 3            (hd = 80: 12 chunks per row)
+  //                   chunk ^= row&3 | ((row>>3)&1)<<2   (hd = 64: 8 chunks per row)
   //   V^T[d][VLD]:    chunk ^= (d >> VSH) & VMSK         (64-key tile: 10 chunks per row, (d>>4)&7 for hd 80, (d>>2)&7 for
   //                                                       hd 64; the window kernel keeps its padded images)
   constexpr bool KSWZ = HDP != HD && MODE != 2;          // hd = 80, global modes (the window kernel sits at its 128-VGPR
                                                          // budget: with the swizzle arithmetic it spills 92 bytes and runs 12 %
                                                          // slower, so its K image stays padded and its V^T padding is 30 chunks)
-  constexpr int KLD = KSWZ ? HDP : HDP + 8;              // Ks row stride (halfs)
+  constexpr bool KSWZ64 = HDP == HD && MODE != 2;        // hd = 64, global modes: 8 chunks per row, chunk ^= r&3 | (r>>3&1)<<2
+  constexpr int KLD = (KSWZ || KSWZ64) ? HDP : HDP + 8;  // Ks row stride (halfs)
   // window mode keeps the WHOLE window (196 keys in 3 x 64 + 1 x 16 MFMA key tiles; K rows zero-padded to 200, V^T columns to 224; 78.7 KB -> two
   // workgroups per CU) resident in LDS:
   // one load phase with every request in flight at once and one barrier, instead of a load/store/2-barrier round per
@@ -84,7 +86,10 @@ __global__ __launch_bounds__(NW * 64, (MODE == 2 ? 4 : 2)) void attn_kernel(Attn
 
   __shared__ __attribute__((aligned(16))) half_t Ks[KRES * KLD];
   __shared__ __attribute__((aligned(16))) half_t Vt[HD * VLD];
-  auto koff_of = [](int row, int chunk) { return row * KLD + ((KSWZ ? (chunk ^ ((row >> 2) & 3)) : chunk) << 3); };
+  auto koff_of = [](int row, int chunk) {
+    const int c = KSWZ ? (chunk ^ ((row >> 2) & 3)) : (KSWZ64 ? (chunk ^ ((row & 3) | (((row >> 3) & 1) << 2))) : chunk);
+    return row * KLD + (c << 3);
+  };
   auto voff_of = [](int d, int chunk) { return d * VLD + ((chunk ^ ((d >> VSH) & VMSK)) << 3); };
   __shared__ unsigned short klut[MODE == 2 ? 256 : 1];  // window key index -> kh | (kw << 8)
   constexpr int RWLD = 64;                               // rel_w stage row (floats); 16-byte chunks XOR-swizzled by q & 15
