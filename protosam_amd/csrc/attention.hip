@@ -125,13 +125,15 @@ __global__ __launch_bounds__(NW * 64, (MODE == 2 ? 4 : 2)) void attn_kernel(Attn
   const int N = p.N, H = p.H;
   const size_t rs = (size_t)p.ts;  // qkv token stride (halfs)
   const half_t* qkv_b = p.qkv + (size_t)b * N * rs;
-  const int nkeys = MODE == 2 ? p.ws * p.ws : N;
+  constexpr int WS = 14;   // the only window size the resident-window schedule is laid out for (checked by the host entry): a
+                           // compile-time divisor turns the ~20 runtime integer divisions per thread into multiply-shifts
+  const int nkeys = MODE == 2 ? WS * WS : N;
   const int ntiles = (nkeys + KT - 1) / KT;
 
   // ---- index helpers --------------------------------------------------------------------
   // window-local index j -> token index, or -1 for a zero-padded position
   auto win_token = [&](int j) -> int {
-    int y = wy * p.ws + j / p.ws, x = wx * p.ws + j % p.ws;
+    int y = wy * WS + j / WS, x = wx * WS + j % WS;
     return (y < p.gh && x < p.gw) ? y * p.gw + x : -1;
   };
 
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(NW * 64, (MODE == 2 ? 4 : 2)) void attn_kernel(Attn
   half8_t qaug[2][2];
   if (MODE == 2) {
     for (int idx = t; idx < 256; idx += NT) {
-      int kh = idx / p.ws, kw = idx - kh * p.ws;
+      int kh = idx / WS, kw = idx - kh * WS;
       klut[idx] = (unsigned short)(kh | (kw << 8));
     }
     if (p.rpack == nullptr) {
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(NW * 64, (MODE == 2 ? 4 : 2)) void attn_kernel(Attn
       if (MODE == 2) {
         const int kidx = kbase + krow;
         const unsigned lut = klut[kidx & 255];
-        const int kh = lut & 0xff, kw = (int)(lut >> 8) + p.ws;  // slots of the two one-hots
+        const int kh = lut & 0xff, kw = (int)(lut >> 8) + WS;  // slots of the two one-hots
         half8_t oh;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
