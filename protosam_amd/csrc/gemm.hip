@@ -39,6 +39,8 @@ struct GemmArgs {
   int out_seg_off;
   int map_mode;  // 0: XCD-region tile map (default); 1: identity; 2: contiguous chunk per XCD
   int head_hd;   // > 0: head-major output, out[(n / head_hd), m, n % head_hd] (planes of [M, head_hd]); EPI_F16 only
+  unsigned long long* trace;  // PSAM_GEMM_TRACE: per-workgroup timestamps (tile 10, debugging)
+  int stagger;   // start-time spread of the first round of workgroups, in units of s_sleep(8) (tile 10)
   int dbg;       // ablation switches for tools/gemm_ablate.py (PSAM_GEMM_DBG; only the DBG instantiation reads it)
 };
 
@@ -230,6 +232,107 @@ __device__ __forceinline__ void store_slab_staged(const f32x16 (&a00), const f32
   slab_emit<EPI, PRE>(slab, mbase, nbase, lane, p, pre);
 }
 
+// fp16-output slabs (EPI_F16 / EPI_GELU_F16): bias / GELU are applied in fp32 in the accumulator layout and the slab is parked
+// as fp16 (half the LDS bytes of the fp32 parking), then re-read so that 8 lanes cover one 64-column row with 16 bytes each:
+// every global store is a dwordx4 over 8 rows x 128 contiguous bytes. The CU's store path is ISSUE-bound (~40 cycles per
+// store instruction whatever its width: 256 dwordx2 stores per 256x256 tile took 5.6 us of a 45 us tile), so halving the
+// instruction count is what counts. 16-byte chunks XOR-swizzled by (row >> 1) & 7: the 8-byte parking writes and the
+// 16-byte reads are both conflict-free.
+template <int EPI>
+__device__ __forceinline__ void slab_park16(const f32x16 (&a00), const f32x16 (&a01), const f32x16 (&a10),
+                                            const f32x16 (&a11), half_t* __restrict__ slab, int nbase, int lane,
+                                            const GemmArgs& p) {
+  const int lr = lane & 31, lg = lane >> 5;
+  const f32x16* accs[2][2] = {{&a00, &a01}, {&a10, &a11}};
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + nbase + j * 32 + 8 * q + 4 * lg);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = i * 32 + lr;
+        const int chunk = j * 4 + q;
+        const f32x16& a = *accs[i][j];
+        float4 v = make_float4(a[4 * q] + bv.x, a[4 * q + 1] + bv.y, a[4 * q + 2] + bv.z, a[4 * q + 3] + bv.w);
+        if (EPI == EPI_GELU_F16) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+        half4_t h = {(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
+        *reinterpret_cast<half4_t*>(&slab[row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3) + 4 * lg]) = h;
+      }
+    }
+}
+
+__device__ __forceinline__ void slab_emit16(const half_t* __restrict__ slab, int mbase, int nbase, int lane,
+                                            const GemmArgs& p) {
+  const int c8 = lane & 7;
+  const int n = nbase + c8 * 8;
+  int pl = 0, ncol = n;
+  if (p.head_hd) { pl = n / p.head_hd; ncol = n - pl * p.head_hd; }   // 8 columns never straddle a head (hd % 8 == 0)
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int row = it * 8 + (lane >> 3);
+    const int m = mbase + row;
+    const half8_t v = *reinterpret_cast<const half8_t*>(&slab[row * 64 + ((c8 ^ ((row >> 1) & 7)) << 3)]);
+    if (m >= p.M) continue;
+    half_t* dst;
+    if (p.head_hd) {
+      dst = reinterpret_cast<half_t*>(p.out) + ((size_t)pl * p.M + m) * p.head_hd + ncol;
+    } else {
+      const size_t orow = p.out_seg ? (size_t)(m / p.out_seg) * p.out_seg_stride + p.out_seg_off + (m % p.out_seg) : (size_t)m;
+      dst = reinterpret_cast<half_t*>(p.out) + orow * p.ldo + n;
+    }
+    *reinterpret_cast<half8_t*>(dst) = v;
+  }
+}
+
+// 32-row x 64-column fp32 slabs for the `x += gamma * (acc + bias)` epilogue of the 128x64 wave tile
+__device__ __forceinline__ void prefetch_resid32(const GemmArgs& p, int mbase, int nbase, int lane, float4 (&r)[8]) {
+  const int n = nbase + (lane & 15) * 4;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    int m = mbase + it * 4 + (lane >> 4);
+    m = m < p.M ? m : p.M - 1;
+    const size_t rrow = p.resid_mod ? (size_t)(m % p.resid_mod) : (size_t)m;
+    r[it] = *reinterpret_cast<const float4*>(p.resid + rrow * p.ldr + n);
+  }
+}
+
+__device__ __forceinline__ void slab_park32(const f32x16 (&a0), const f32x16 (&a1), float* __restrict__ slab, int lane) {
+  const int lr = lane & 31, lg = lane >> 5;
+  const f32x16* accs[2] = {&a0, &a1};
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int chunk = (j * 32 + 8 * q + 4 * lg) >> 2;
+      const f32x16& a = *accs[j];
+      *reinterpret_cast<float4*>(&slab[lr * 64 + ((chunk ^ (lr & 15)) << 2)]) =
+          make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+    }
+}
+
+__device__ __forceinline__ void slab_emit32(const float* __restrict__ slab, int mbase, int nbase, int lane,
+                                            const GemmArgs& p, const float4 (&pre)[8]) {
+  const int c4 = lane & 15;
+  const int n = nbase + c4 * 4;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), gv = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + n);
+  if (p.gamma) gv = *reinterpret_cast<const float4*>(p.gamma + n);
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int row = it * 4 + (lane >> 4);
+    const int m = mbase + row;
+    float4 v = *reinterpret_cast<const float4*>(&slab[row * 64 + ((c4 ^ (row & 15)) << 2)]);
+    if (m >= p.M) continue;
+    const size_t orow = p.out_seg ? (size_t)(m / p.out_seg) * p.out_seg_stride + p.out_seg_off + (m % p.out_seg) : (size_t)m;
+    const float4 r = pre[it];
+    v.x = (v.x + bv.x) * gv.x + r.x; v.y = (v.y + bv.y) * gv.y + r.y;
+    v.z = (v.z + bv.z) * gv.z + r.z; v.w = (v.w + bv.w) * gv.w + r.w;
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + orow * p.ldo + n) = v;
+  }
+}
+
 // 128-row x 64-column wave tile (two slabs) with the residual rows of BOTH slabs requested before anything waits on
 // them (16 float4 loads in flight per lane, issued ahead of the LDS parking). Without this the `x += ...` epilogues (proj,
 // lin2) ran 30-40 % below the fp16-output GEMMs of the same shape (profiles/r01_f: 528 / 712 vs 830 / 1010 TFLOP/s).
@@ -237,14 +340,29 @@ template <int EPI>
 __device__ __forceinline__ void store_wave_tile_128x64(const f32x16 (&acc)[2][2][2], float* __restrict__ slab, int mbase,
                                                        int nbase, int lane, const GemmArgs& p) {
   if (EPI == EPI_F32 && p.resid != nullptr) {
-    float4 r0[16];
-    prefetch_resid(p, mbase, nbase, lane, r0);
-    slab_park(acc[0][0][0], acc[0][0][1], acc[0][1][0], acc[0][1][1], slab, lane);
-    slab_emit<EPI, true>(slab, mbase, nbase, lane, p, r0);
-    __builtin_amdgcn_sched_barrier(0);
-    prefetch_resid(p, mbase + 64, nbase, lane, r0);
-    slab_park(acc[1][0][0], acc[1][0][1], acc[1][1][0], acc[1][1][1], slab, lane);
-    slab_emit<EPI, true>(slab, mbase + 64, nbase, lane, p, r0);
+    // four 32-row slabs; the residual rows of slab s+1 are requested before slab s is emitted (two 8-float4 sets in
+    // flight), so only the first request's latency is exposed and the register peak stays below the spill line
+    float4 ra[8], rb[8];
+    float* slab2[2] = {slab, slab + 2048};
+    prefetch_resid32(p, mbase, nbase, lane, ra);
+#pragma unroll
+    for (int sidx = 0; sidx < 4; ++sidx) {
+      const int a = sidx >> 1, i = sidx & 1;
+      float* sl = slab2[sidx & 1];
+      slab_park32(acc[a][i][0], acc[a][i][1], sl, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      if (sidx < 3) prefetch_resid32(p, mbase + (sidx + 1) * 32, nbase, lane, (sidx & 1) ? ra : rb);
+      __builtin_amdgcn_sched_barrier(0);
+      slab_emit32(sl, mbase + sidx * 32, nbase, lane, p, (sidx & 1) ? rb : ra);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else if (EPI == EPI_F16 || EPI == EPI_GELU_F16) {
+    half_t* slab16 = reinterpret_cast<half_t*>(slab);   // two 8 KiB fp16 slabs inside the wave's 16 KiB
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      slab_park16<EPI>(acc[a][0][0], acc[a][0][1], acc[a][1][0], acc[a][1][1], slab16 + a * 4096, nbase, lane, p);
+      slab_emit16(slab16 + a * 4096, mbase + a * 64, nbase, lane, p);
+    }
   } else {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -1209,6 +1327,13 @@ __global__ __launch_bounds__(512) void gemm8k_f16_kernel(GemmArgs p) {
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wr = wv >> 2, wc = wv & 3;
   const int lr = lane & 31, lg = lane >> 5;
+  if (p.dbg & 32) return;
+  unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
+  if (p.trace) tr0 = wall_clock64();
+  if (p.stagger > 0 && blockIdx.x < 256) {
+    const int n = (int)(((blockIdx.x * 167u) & 255u) * (unsigned)p.stagger) >> 8;
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(8);
+  }
 
   unsigned aoff[2][2], boff[2];
 #pragma unroll
@@ -1277,6 +1402,7 @@ __global__ __launch_bounds__(512) void gemm8k_f16_kernel(GemmArgs p) {
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger the second wave row by one barrier
   asm volatile("" ::: "memory");
+  if (p.trace) tr1 = wall_clock64();
 
   for (int kt = 0; kt < nk; ++kt) {
     const half_t* buf = ring + (kt & 1) * 4 * HT;
@@ -1319,9 +1445,47 @@ __global__ __launch_bounds__(512) void gemm8k_f16_kernel(GemmArgs p) {
 #undef PHASE_SYNC_IN
 #undef PHASE_SYNC_OUT
   if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the stagger
+  if (p.trace) tr2 = wall_clock64();
+  if (p.dbg & 8) { if (acc[0][0][0][0] == 123.456f) reinterpret_cast<half_t*>(p.out)[0] = (half_t)acc[1][1][1][3]; return; }
 
   float* slab = reinterpret_cast<float*>(ring) + wv * 4096;
+  if (p.dbg & 64) {   // LDS part of the epilogue only
+    float sum = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      slab_park(acc[a][0][0], acc[a][0][1], acc[a][1][0], acc[a][1][1], slab, lane);
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int row = it * 4 + (lane >> 4);
+        float4 v = *reinterpret_cast<const float4*>(&slab[row * 64 + (((lane & 15) ^ (row & 15)) << 2)]);
+        sum += v.x + v.y + v.z + v.w;
+      }
+    }
+    if (sum == 123.456f) reinterpret_cast<half_t*>(p.out)[0] = (half_t)sum;
+    return;
+  }
+  if (p.dbg & 128) {  // direct stores from the accumulator layout
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          store_acc32<EPI>(acc[a][i][b], m0 + wr * 128 + a * 64 + i * 32 + lr, n0 + wc * 64 + b * 32 + 4 * lg, p);
+    return;
+  }
   store_wave_tile_128x64<EPI>(acc, slab, m0 + wr * 128, n0 + wc * 64, lane, p);
+  if (p.trace && lane == 0) {
+    const unsigned long long tr3 = wall_clock64();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long tr4 = wall_clock64();
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned long long* o = p.trace + ((size_t)blockIdx.x * 8 + wv) * 8;
+    o[0] = tr0; o[1] = tr1; o[2] = tr2; o[3] = tr3; o[4] = tr4; o[5] = hw; o[6] = xcc; o[7] = blockIdx.x;
+  }
 }
 
 template <int EPI>
@@ -1420,12 +1584,18 @@ static int gemm_dispatch(const void* A, const void* W, const float* bias, void* 
   p.out_seg_off = out_seg_off;
   { const char* e = getenv("PSAM_GEMM_MAP"); p.map_mode = e ? atoi(e) : 0; }
   { const char* e = getenv("PSAM_GEMM_DBG"); p.dbg = e ? atoi(e) : 0; }
+  p.trace = nullptr;
+  { static int st = -1; if (st < 0) { const char* e = getenv("PSAM_GEMM_STAGGER"); st = e ? atoi(e) : 0; } p.stagger = st; }
   p.head_hd = head_hd;
   const int ntm = (M + BM - 1) / BM, ntn = N / BN;
   dim3 grid(tile_map_grid(ntm, ntn, p.map_mode)), block(256);
   hipStream_t s = (hipStream_t)stream;
   int tsel = epilogue == EPI_RELU_F16 ? 1 : pick_tile(M, N, K, epilogue);
   if (head_hd && tsel != 1 && tsel != 7 && tsel != 8 && tsel != 10) tsel = 1;   // the head-major store lives in the staged epilogue  // the ReLU epilogue lives in the 128x128 kernel
+  // the wave-tile epilogue of tiles 7 / 8 / 10 stores fp16 rows with 16-byte instructions
+  if ((tsel == 7 || tsel == 8 || tsel == 10) && epilogue != EPI_F32 &&
+      ((ldo % 8) != 0 || (reinterpret_cast<uintptr_t>(out) & 15) != 0 || (out_seg && (out_seg_off * (long)ldo) % 8 != 0)))
+    tsel = 1;
   if ((tsel == 3 || tsel == 5) && N % 256 == 0) {
     if (tsel == 3) {
       if (epilogue == EPI_F16) launch256<EPI_F16, 256, 1>(p, s);
@@ -1439,9 +1609,23 @@ static int gemm_dispatch(const void* A, const void* W, const float* bias, void* 
     return psam_launch_status();
   }
   if (tsel == 10 && N % 256 == 0) {
+    static const char* trace_path = getenv("PSAM_GEMM_TRACE");
+    const size_t nblk = (size_t)tile_map_grid((M + 255) / 256, N / 256, p.map_mode);
+    if (trace_path) {   // debugging aid: dump per-wave timestamps of this launch (synchronous)
+      (void)hipMalloc((void**)&p.trace, nblk * 64 * sizeof(unsigned long long));
+      (void)hipMemsetAsync(p.trace, 0, nblk * 64 * sizeof(unsigned long long), s);
+    }
     if (epilogue == EPI_F16) launch8k<EPI_F16>(p, s);
     else if (epilogue == EPI_GELU_F16) launch8k<EPI_GELU_F16>(p, s);
     else launch8k<EPI_F32>(p, s);
+    if (trace_path) {
+      std::vector<unsigned long long> h(nblk * 64);
+      (void)hipStreamSynchronize(s);
+      (void)hipMemcpy(h.data(), p.trace, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+      (void)hipFree(p.trace);
+      FILE* f = fopen(trace_path, "wb");
+      if (f) { fwrite(h.data(), sizeof(unsigned long long), h.size(), f); fclose(f); }
+    }
     return psam_launch_status();
   }
   if (tsel == 9 && N % 256 == 0) {
