@@ -40,6 +40,7 @@ struct GemmArgs {
   int map_mode;  // 0: XCD-region tile map (default); 1: identity; 2: contiguous chunk per XCD
   int head_hd;   // > 0: head-major output, out[(n / head_hd), m, n % head_hd] (planes of [M, head_hd]); EPI_F16 only
   unsigned long long* trace;  // PSAM_GEMM_TRACE: per-workgroup timestamps (tile 10, debugging)
+  int wide16;    // fp16 output rows may be stored with 16-byte instructions (ldo % 8 == 0, 16-byte aligned base)
   int stagger;   // start-time spread of the first round of workgroups, in units of s_sleep(8) (tile 10)
   int dbg;       // ablation switches for tools/gemm_ablate.py (PSAM_GEMM_DBG; only the DBG instantiation reads it)
 };
@@ -476,7 +477,11 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs p) {
   if (EPI == EPI_F32 && has_res)
     store_slab_staged<EPI, true>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], slab, m0 + wm * 64, n0 + wn * 64, lane, p,
                                  rpre);
-  else
+  else if ((EPI == EPI_F16 || EPI == EPI_GELU_F16) && p.wide16) {
+    half_t* slab16 = reinterpret_cast<half_t*>(slab);
+    slab_park16<EPI>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], slab16, n0 + wn * 64, lane, p);
+    slab_emit16(slab16, m0 + wm * 64, n0 + wn * 64, lane, p);
+  } else
     store_slab_staged<EPI, false>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], slab, m0 + wm * 64, n0 + wn * 64, lane, p);
 }
 
@@ -1592,10 +1597,9 @@ static int gemm_dispatch(const void* A, const void* W, const float* bias, void* 
   hipStream_t s = (hipStream_t)stream;
   int tsel = epilogue == EPI_RELU_F16 ? 1 : pick_tile(M, N, K, epilogue);
   if (head_hd && tsel != 1 && tsel != 7 && tsel != 8 && tsel != 10) tsel = 1;   // the head-major store lives in the staged epilogue  // the ReLU epilogue lives in the 128x128 kernel
-  // the wave-tile epilogue of tiles 7 / 8 / 10 stores fp16 rows with 16-byte instructions
-  if ((tsel == 7 || tsel == 8 || tsel == 10) && epilogue != EPI_F32 &&
-      ((ldo % 8) != 0 || (reinterpret_cast<uintptr_t>(out) & 15) != 0 || (out_seg && (out_seg_off * (long)ldo) % 8 != 0)))
-    tsel = 1;
+  // the slab epilogues store fp16 rows with 16-byte instructions when the layout allows (tiles 7 / 8 / 10 require it)
+  p.wide16 = (ldo % 8) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (!head_hd || head_hd % 8 == 0);
+  if ((tsel == 7 || tsel == 8 || tsel == 10) && epilogue != EPI_F32 && !p.wide16) tsel = 1;
   if ((tsel == 3 || tsel == 5) && N % 256 == 0) {
     if (tsel == 3) {
       if (epilogue == EPI_F16) launch256<EPI_F16, 256, 1>(p, s);
