@@ -1505,6 +1505,287 @@ static void launch8k(const GemmArgs& p, hipStream_t s) {
   hipLaunchKernelGGL((gemm8k_f16_kernel<EPI>), dim3(tile_map_grid(ntm, ntn, p.map_mode)), dim3(512), LDS, s, p);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Tile 11: the 8-phase kernel above made PERSISTENT for the fp16-output epilogues. One workgroup per CU walks tiles
+// bid, bid + grid, ... of the same XCD-aware map. What it buys (per-workgroup timeline, tools/gemm_trace.py, 65536x3840x1280:
+// prologue 2.3 us + k-loop 35.8 us + epilogue 4.2 us + 0.9 us until the CU's next workgroup starts): the next tile's first
+// five half-tile DMAs are issued BEFORE the epilogue of the finished tile and land while its stores drain, and there is no
+// workgroup turn-around. The epilogue therefore cannot park its slabs in the ring: each wave owns 4 KiB of the 32 KiB that
+// the 128 KiB ring leaves free and emits its 128x64 tile as four 32-row fp16 slabs (4 dwordx4 stores each).
+__device__ __forceinline__ void slab_park16h(const f32x16 (&a0), const f32x16 (&a1), half_t* __restrict__ slab,
+                                             const float4 (&bv)[2][4], int lane, bool gelu) {
+  const int lr = lane & 31, lg = lane >> 5;
+  const f32x16* accs[2] = {&a0, &a1};
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x16& a = *accs[j];
+      const float4 b = bv[j][q];
+      float4 v = make_float4(a[4 * q] + b.x, a[4 * q + 1] + b.y, a[4 * q + 2] + b.z, a[4 * q + 3] + b.w);
+      if (gelu) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+      half4_t h = {(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
+      *reinterpret_cast<half4_t*>(&slab[lr * 64 + (((j * 4 + q) ^ ((lr >> 1) & 7)) << 3) + 4 * lg]) = h;
+    }
+}
+
+__device__ __forceinline__ void slab_emit16h(const half_t* __restrict__ slab, int mbase, int nbase, int lane,
+                                             const GemmArgs& p) {
+  const int c8 = lane & 7;
+  const int n = nbase + c8 * 8;
+  int pl = 0, ncol = n;
+  if (p.head_hd) { pl = n / p.head_hd; ncol = n - pl * p.head_hd; }
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = it * 8 + (lane >> 3);
+    const int m = mbase + row;
+    const half8_t v = *reinterpret_cast<const half8_t*>(&slab[row * 64 + ((c8 ^ ((row >> 1) & 7)) << 3)]);
+    if (m >= p.M) continue;
+    half_t* dst;
+    if (p.head_hd) {
+      dst = reinterpret_cast<half_t*>(p.out) + ((size_t)pl * p.M + m) * p.head_hd + ncol;
+    } else {
+      const size_t orow = p.out_seg ? (size_t)(m / p.out_seg) * p.out_seg_stride + p.out_seg_off + (m % p.out_seg) : (size_t)m;
+      dst = reinterpret_cast<half_t*>(p.out) + orow * p.ldo + n;
+    }
+    *reinterpret_cast<half8_t*>(dst) = v;
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm8kp_f16_kernel(GemmArgs p, int total) {
+  extern __shared__ __attribute__((aligned(16))) half_t ring[];  // [buf 2][A0 A1 B0 B1][128][64] + 8 x 4 KiB slabs
+  constexpr int HT = 128 * 64;
+  const int ntn = p.N / 256;
+  const int ntm = (p.M + 255) / 256;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = wv >> 2, wc = wv & 3;
+  const int lr = lane & 31, lg = lane >> 5;
+  half_t* slab = ring + 8 * HT + wv * 2048;
+  const int nk = p.K / 64;
+  const unsigned bh = 32u * (unsigned)p.ldw;
+  const int arow0 = wr * 64 + lr, brow0 = wc * 32 + lr;
+
+  int idx = blockIdx.x, tm = 0, tn = 0;
+  while (idx < total && !tile_map(idx, ntm, ntn, p.map_mode, tm, tn)) idx += gridDim.x;
+  if (idx >= total) return;
+
+  unsigned aoff[2][2], boff[2];
+  auto offsets = [&](int m0, int n0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int lrow = j * 64 + (t >> 3);
+      const int chunk = (t & 7) ^ ((lrow >> 1) & 7);
+      const int arow = (lrow >> 6) * 128 + (lrow & 63);
+      const int brow = (lrow >> 5) * 64 + (lrow & 31);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int am = m0 + arow + h * 64;
+        am = am < p.M ? am : p.M - 1;
+        aoff[j][h] = (unsigned)am * (unsigned)p.lda + chunk * 8;
+      }
+      boff[j] = (unsigned)(n0 + brow) * (unsigned)p.ldw + chunk * 8;
+    }
+  };
+  auto stage = [&](int which, int kt) {  // 0 A0, 1 A1, 2 B0, 3 B1
+    half_t* dst = ring + ((kt & 1) * 4 + which) * HT + wv * 512;
+    const int h = which & 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const half_t* g = which < 2 ? p.A + (aoff[j][h] + (unsigned)kt * 64u) : p.W + (boff[j] + h * bh + (unsigned)kt * 64u);
+      glds16(g, dst + j * 4096);
+    }
+  };
+  auto prologue = [&]() {
+    stage(0, 0); stage(2, 0); stage(3, 0); stage(1, 0);
+    if (nk > 1) stage(0, 1);
+  };
+
+  if (p.stagger > 0) {
+    const int n = (int)(((blockIdx.x * 167u) & 255u) * (unsigned)p.stagger) >> 8;
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(8);
+  }
+  offsets(tm * 256, tn * 256);
+  prologue();
+
+  half8_t fa[2][2];      // [i][k within the half]
+  half8_t fb[2][2][2];   // [k half][b][k within the half]
+
+#define RD_A(bufp, h, kh)                                                                                         \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int k2 = 0; k2 < 2; ++k2)                   \
+      fa[i][k2] = *reinterpret_cast<const half8_t*>(&(bufp)[(h) * HT + lds_off64(arow0 + i * 32, ((kh) * 2 + k2) * 2 + lg)]);
+#define RD_B(bufp, kh)                                                                                            \
+  _Pragma("unroll") for (int b = 0; b < 2; ++b) _Pragma("unroll") for (int k2 = 0; k2 < 2; ++k2)                   \
+      fb[kh][b][k2] = *reinterpret_cast<const half8_t*>(&(bufp)[(2 + b) * HT + lds_off64(brow0, ((kh) * 2 + k2) * 2 + lg)]);
+#define MMA_H(a, kh)                                                                                              \
+  _Pragma("unroll") for (int k2 = 0; k2 < 2; ++k2) _Pragma("unroll") for (int i = 0; i < 2; ++i)                   \
+      _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                               \
+          acc[a][i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[kh][b][k2], fa[i][k2], acc[a][i][b], 0, 0, 0);
+#define PHASE_SYNC_IN()                                   \
+  __builtin_amdgcn_s_barrier();                           \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+  __builtin_amdgcn_sched_barrier(0);                      \
+  __builtin_amdgcn_s_setprio(1);
+#define PHASE_SYNC_OUT()                                  \
+  __builtin_amdgcn_s_setprio(0);                          \
+  __builtin_amdgcn_sched_barrier(0);                      \
+  __builtin_amdgcn_s_barrier();                           \
+  asm volatile("" ::: "memory");
+
+  bool first = true;
+  for (;;) {
+    const int m0 = tm * 256, n0 = tn * 256;
+    f32x16 acc[2][2][2];  // [a][i][b]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][i][b][r] = 0.f;
+
+    // first tile: the counted wait of the 8-phase prologue. Later tiles: the previous tile's stores were issued AFTER this
+    // tile's first DMAs, and a count says nothing about which of loads and stores are still in flight, so wait for all
+    // (the DMAs landed during the epilogue; stores are acknowledged ~0.1 us after issue)
+    if (first) { if (nk > 1) wait_vmcnt<4>(); else wait_vmcnt<2>(); } else { wait_vmcnt<0>(); }
+    first = false;
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger the second wave row by one barrier
+    asm volatile("" ::: "memory");
+
+    for (int kt = 0; kt < nk; ++kt) {
+      const half_t* buf = ring + (kt & 1) * 4 * HT;
+      const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+      RD_B(buf, 0)
+      __builtin_amdgcn_sched_barrier(0);
+      RD_A(buf, 0, 0)
+      if (more1) stage(2, kt + 1);
+      if (more1) wait_vmcnt<6>(); else wait_vmcnt<0>();
+      PHASE_SYNC_IN();
+      MMA_H(0, 0)
+      PHASE_SYNC_OUT();
+      RD_B(buf, 1)
+      __builtin_amdgcn_sched_barrier(0);
+      RD_A(buf, 0, 1)
+      if (more1) stage(3, kt + 1);
+      if (more1) wait_vmcnt<6>(); else wait_vmcnt<0>();
+      PHASE_SYNC_IN();
+      MMA_H(0, 1)
+      PHASE_SYNC_OUT();
+      RD_A(buf, 1, 0)
+      if (more1) stage(1, kt + 1);
+      if (more1) wait_vmcnt<6>(); else wait_vmcnt<0>();
+      PHASE_SYNC_IN();
+      MMA_H(1, 0)
+      PHASE_SYNC_OUT();
+      RD_A(buf, 1, 1)
+      if (more2) { stage(0, kt + 2); wait_vmcnt<4>(); } else if (more1) { wait_vmcnt<2>(); } else { wait_vmcnt<0>(); }
+      PHASE_SYNC_IN();
+      MMA_H(1, 1)
+      PHASE_SYNC_OUT();
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the stagger: every wave is done with the ring here
+
+    // next tile of this workgroup: request its first half-tiles now
+    int nidx = idx + gridDim.x, ntm_ = 0, ntn_ = 0;
+    while (nidx < total && !tile_map(nidx, ntm, ntn, p.map_mode, ntm_, ntn_)) nidx += gridDim.x;
+    const bool have = nidx < total;
+    if (have) {
+      offsets(ntm_ * 256, ntn_ * 256);
+      prologue();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    if constexpr (EPI == EPI_F32) {
+      // x (+)= gamma * (acc + bias) in fp32: eight 32x32 blocks through the 4 KiB slab, 8 lanes per 128-byte row; the
+      // residual rows of block s+1 are requested before block s is emitted
+      const int mbase = m0 + wr * 128, nbase = n0 + wc * 64;
+      float* slabf = reinterpret_cast<float*>(slab);
+      const int c = lane & 7, r8 = lane >> 3;
+      auto pre = [&](int blk, float4 (&r)[4]) {
+        const int mb = mbase + (blk >> 1) * 32, n = nbase + (blk & 1) * 32 + c * 4;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          int m = mb + it * 8 + r8;
+          m = m < p.M ? m : p.M - 1;
+          const size_t rrow = p.resid_mod ? (size_t)(m % p.resid_mod) : (size_t)m;
+          r[it] = p.resid ? *reinterpret_cast<const float4*>(p.resid + rrow * p.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      };
+      float4 bvv[2], gvv[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        bvv[j] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nbase + j * 32 + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        gvv[j] = p.gamma ? *reinterpret_cast<const float4*>(p.gamma + nbase + j * 32 + c * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+      }
+      float4 ra[4], rb[4];
+      pre(0, ra);
+#pragma unroll
+      for (int blk = 0; blk < 8; ++blk) {
+        const f32x16& a = acc[blk >> 2][(blk >> 1) & 1][blk & 1];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4*>(&slabf[lr * 32 + (((2 * q + lg) ^ ((lr >> 1) & 7)) << 2)]) =
+              make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (blk < 7) pre(blk + 1, (blk & 1) ? ra : rb);
+        __builtin_amdgcn_sched_barrier(0);
+        const float4 (&r)[4] = (blk & 1) ? rb : ra;
+        const float4 bv = bvv[blk & 1], gv = gvv[blk & 1];
+        const int mb = mbase + (blk >> 1) * 32, n = nbase + (blk & 1) * 32 + c * 4;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int row = it * 8 + r8;
+          const int m = mb + row;
+          float4 v = *reinterpret_cast<const float4*>(&slabf[row * 32 + ((c ^ ((row >> 1) & 7)) << 2)]);
+          if (m >= p.M) continue;
+          const size_t orow = p.out_seg ? (size_t)(m / p.out_seg) * p.out_seg_stride + p.out_seg_off + (m % p.out_seg) : (size_t)m;
+          v.x = (v.x + bv.x) * gv.x + r[it].x; v.y = (v.y + bv.y) * gv.y + r[it].y;
+          v.z = (v.z + bv.z) * gv.z + r[it].z; v.w = (v.w + bv.w) * gv.w + r[it].w;
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + orow * p.ldo + n) = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {  // epilogue of the finished tile from the wave's private slab
+      const int mbase = m0 + wr * 128, nbase = n0 + wc * 64;
+      float4 bv[2][4];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          bv[j][q] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nbase + j * 32 + 8 * q + 4 * lg)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int sidx = 0; sidx < 4; ++sidx) {
+        slab_park16h(acc[sidx >> 1][sidx & 1][0], acc[sidx >> 1][sidx & 1][1], slab, bv, lane, EPI == EPI_GELU_F16);
+        slab_emit16h(slab, mbase + sidx * 32, nbase, lane, p);
+      }
+    }
+    if (!have) break;
+    idx = nidx; tm = ntm_; tn = ntn_;
+  }
+#undef RD_A
+#undef RD_B
+#undef MMA_H
+#undef PHASE_SYNC_IN
+#undef PHASE_SYNC_OUT
+}
+
+template <int EPI>
+static void launch8kp(const GemmArgs& p, hipStream_t s) {
+  constexpr int LDS = 2 * 4 * 128 * 64 * 2 + 8 * 4096;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm8kp_f16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr = true;
+  }
+  const int ntm = (p.M + 255) / 256, ntn = p.N / 256;
+  const int total = tile_map_grid(ntm, ntn, p.map_mode);
+  hipLaunchKernelGGL((gemm8kp_f16_kernel<EPI>), dim3(total < 256 ? total : 256), dim3(512), LDS, s, p, total);
+}
+
 template <int EPI>
 static void launch_ws(const GemmArgs& p, hipStream_t s) {
   constexpr int LDS = 4 * (384 + 128) * 32 * 2;
@@ -1556,7 +1837,12 @@ static int pick_tile(int M, int N, int K, int epilogue) {
     // the fp32 residual epilogue with a short K (proj: 20 K-tiles) is better served by two workgroups per CU unless the
     // 256-tiles fill their rounds completely (65536x1280x1280: 603 vs 525 TFLOP/s; 32768x1280x1280, 2.5 rounds: 653 vs 689)
     const bool short_f32 = epilogue == EPI_F32 && K < 2048;
-    if (K >= 1024 && t256 * 100 >= rounds * 256 * (short_f32 ? 95 : 80)) return 10;   // (7 = its quadrant-phase predecessor)
+    // 10 = 8-phase with K-split phases (7 = its quadrant-phase predecessor); 11 = its persistent form (fp16 outputs)
+    if (K >= 1024 && t256 * 100 >= rounds * 256 * (short_f32 ? 95 : 80)) {
+      static int f32p = -1;
+      if (f32p < 0) { const char* e = getenv("PSAM_GEMM_F32_PERSIST"); f32p = e ? atoi(e) : 1; }
+      return epilogue == EPI_F32 && !f32p ? 10 : 11;
+    }
   }
   return 1;
 }
@@ -1596,10 +1882,10 @@ static int gemm_dispatch(const void* A, const void* W, const float* bias, void* 
   dim3 grid(tile_map_grid(ntm, ntn, p.map_mode)), block(256);
   hipStream_t s = (hipStream_t)stream;
   int tsel = epilogue == EPI_RELU_F16 ? 1 : pick_tile(M, N, K, epilogue);
-  if (head_hd && tsel != 1 && tsel != 7 && tsel != 8 && tsel != 10) tsel = 1;   // the head-major store lives in the staged epilogue  // the ReLU epilogue lives in the 128x128 kernel
+  if (head_hd && tsel != 1 && tsel != 7 && tsel != 8 && tsel != 10 && tsel != 11) tsel = 1;   // the head-major store lives in the staged epilogue  // the ReLU epilogue lives in the 128x128 kernel
   // the slab epilogues store fp16 rows with 16-byte instructions when the layout allows (tiles 7 / 8 / 10 require it)
   p.wide16 = (ldo % 8) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (!head_hd || head_hd % 8 == 0);
-  if ((tsel == 7 || tsel == 8 || tsel == 10) && epilogue != EPI_F32 && !p.wide16) tsel = 1;
+  if ((tsel == 7 || tsel == 8 || tsel == 10 || tsel == 11) && epilogue != EPI_F32 && !p.wide16) tsel = 1;
   if ((tsel == 3 || tsel == 5) && N % 256 == 0) {
     if (tsel == 3) {
       if (epilogue == EPI_F16) launch256<EPI_F16, 256, 1>(p, s);
@@ -1610,6 +1896,13 @@ static int gemm_dispatch(const void* A, const void* W, const float* bias, void* 
       else if (epilogue == EPI_GELU_F16) launch256<EPI_GELU_F16, 256, 0>(p, s);
       else launch256<EPI_F32, 256, 0>(p, s);
     }
+    return psam_launch_status();
+  }
+  if (tsel == 11 && N % 256 == 0 && epilogue != EPI_F32 && !p.wide16) tsel = 10;
+  if (tsel == 11 && N % 256 == 0) {
+    if (epilogue == EPI_F16) launch8kp<EPI_F16>(p, s);
+    else if (epilogue == EPI_GELU_F16) launch8kp<EPI_GELU_F16>(p, s);
+    else launch8kp<EPI_F32>(p, s);
     return psam_launch_status();
   }
   if (tsel == 10 && N % 256 == 0) {

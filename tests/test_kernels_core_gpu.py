@@ -38,7 +38,7 @@ def test_gemm(dev, M, N, K, epi):
         torch.testing.assert_close(out, resid + gamma * ref, rtol=1e-4, atol=2e-4)
 
 
-@pytest.mark.parametrize("tile", [2, 3, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("tile", [2, 3, 5, 6, 7, 8, 9, 10, 11])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (1297, 768, 768), (4096, 1280, 1280), (1000, 512, 192)])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_gemm_large_tiles(dev, tile, M, N, K, epi):
@@ -65,6 +65,39 @@ def test_gemm_large_tiles(dev, tile, M, N, K, epi):
             torch.testing.assert_close(out, resid + gamma * ref, rtol=1e-4, atol=2e-4)
     finally:
         ops.gemm_set_tile(0)
+
+
+@pytest.mark.parametrize("M,N,K", [(20000, 1536, 128), (70001, 768, 64), (33000, 2304, 192)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_persistent_tile_walks_many_tiles(dev, M, N, K, epi):
+    """Tile 11 (one persistent workgroup per CU) with more 256x256 tiles than CUs and a ragged last row of tiles: the same
+    arithmetic as tile 10 in the same order => bit-identical output, and correct against fp32 matmul."""
+    from protosam_amd import ops
+    a = _rand((M, K), dev, 1.0, 21).half()
+    w = _rand((N, K), dev, 0.05, 22).half()
+    bias = _rand((N,), dev, 0.5, 23)
+    e = (ops.EPI_F16, ops.EPI_GELU_F16, ops.EPI_F32)[epi]
+    resid = _rand((M, N), dev, 1.0, 24) if epi == 2 else None
+    gamma = _rand((N,), dev, 1.0, 25) if epi == 2 else None
+    outs = []
+    for tile in (10, 11):
+        ops.gemm_set_tile(tile)
+        try:
+            if epi == 2:
+                x = resid.clone()                                   # in place, as the encoder blocks call it
+                outs.append(ops.gemm(a, w, bias, out=x, epilogue=e, resid=x, gamma=gamma))
+            else:
+                outs.append(ops.gemm(a, w, bias, epilogue=e))
+        finally:
+            ops.gemm_set_tile(0)
+    assert torch.equal(outs[0], outs[1])
+    ref = a.float() @ w.float().t() + bias
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+    if epi == 2:
+        torch.testing.assert_close(outs[1], resid + gamma * ref, rtol=1e-4, atol=2e-4)
+    else:
+        torch.testing.assert_close(outs[1].float(), ref, rtol=2e-3, atol=2e-3)
 
 
 def test_gemm_row_remap_and_resid_mod(dev):
@@ -203,7 +236,7 @@ def test_head_major_qkv_layout(dev):
     w = _rand((3 * D, D), dev, 0.05, 42).half()
     bias = _rand((3 * D,), dev, 0.5, 43)
     tokm = ops.gemm(x, w, bias, epilogue=ops.EPI_F16)                              # [B*N, 3*H*hd]
-    for tile in (1, 10):
+    for tile in (1, 10, 11):
         ops.gemm_set_tile(tile)
         try:
             hm = ops.gemm_heads(x, w, bias, hd)                                    # [3*H, B*N, hd]

@@ -1,2 +1,2 @@
 #!/bin/bash
-for st in ${1:-0 32 64 128}; do echo "== stagger $st"; PSAM_GEMM_STAGGER=$st python3 tools/gemm_ksweep.py 10 65536 3840 | grep "K= 1280"; PSAM_GEMM_STAGGER=$st python3 tools/gemm_ksweep.py 10 65536 1280 f32 | grep "K= 1280\|K= 5120"; done
+for st in ${1:-0 32 64 128}; do echo "== stagger $st"; PSAM_GEMM_STAGGER=$st python3 tools/gemm_tiles.py ${2:-11} "78400x3840x1280;65536x5120x1280;65536x3840x1280"; done
