@@ -1334,7 +1334,8 @@ __global__ __launch_bounds__(512) void gemm8k_f16_kernel(GemmArgs p) {
   const int lr = lane & 31, lg = lane >> 5;
   if (p.dbg & 32) return;
   unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
-  if (p.trace) tr0 = wall_clock64();
+  unsigned long long cy0 = 0;
+  if (p.trace) { tr0 = wall_clock64(); cy0 = __builtin_amdgcn_s_memtime(); }
   if (p.stagger > 0 && blockIdx.x < 256) {
     const int n = (int)(((blockIdx.x * 167u) & 255u) * (unsigned)p.stagger) >> 8;
     for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(8);
@@ -1489,7 +1490,7 @@ __global__ __launch_bounds__(512) void gemm8k_f16_kernel(GemmArgs p) {
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     unsigned long long* o = p.trace + ((size_t)blockIdx.x * 8 + wv) * 8;
-    o[0] = tr0; o[1] = tr1; o[2] = tr2; o[3] = tr3; o[4] = tr4; o[5] = hw; o[6] = xcc; o[7] = blockIdx.x;
+    o[0] = tr0; o[1] = tr1; o[2] = tr2; o[3] = tr3; o[4] = tr4; o[5] = hw; o[6] = xcc; o[7] = __builtin_amdgcn_s_memtime() - cy0;
   }
 }
 
@@ -1549,6 +1550,76 @@ __device__ __forceinline__ void slab_emit16h(const half_t* __restrict__ slab, in
       dst = reinterpret_cast<half_t*>(p.out) + orow * p.ldo + n;
     }
     *reinterpret_cast<half8_t*>(dst) = v;
+  }
+}
+
+// Epilogue of one 128x64 wave tile of the persistent kernels, through the wave's private 4 KiB slab.
+template <int EPI>
+__device__ __forceinline__ void persist_epilogue(const f32x16 (&acc)[2][2][2], half_t* __restrict__ slab, int mbase, int nbase,
+                                                 int lane, const GemmArgs& p) {
+  const int lr = lane & 31, lg = lane >> 5;
+  if constexpr (EPI == EPI_F32) {
+    // x (+)= gamma * (acc + bias) in fp32: eight 32x32 blocks through the 4 KiB slab, 8 lanes per 128-byte row; the
+    // residual rows of block s+1 are requested before block s is emitted
+    float* slabf = reinterpret_cast<float*>(slab);
+    const int c = lane & 7, r8 = lane >> 3;
+    auto pre = [&](int blk, float4 (&r)[4]) {
+      const int mb = mbase + (blk >> 1) * 32, n = nbase + (blk & 1) * 32 + c * 4;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        int m = mb + it * 8 + r8;
+        m = m < p.M ? m : p.M - 1;
+        const size_t rrow = p.resid_mod ? (size_t)(m % p.resid_mod) : (size_t)m;
+        r[it] = p.resid ? *reinterpret_cast<const float4*>(p.resid + rrow * p.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    };
+    float4 bvv[2], gvv[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bvv[j] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nbase + j * 32 + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      gvv[j] = p.gamma ? *reinterpret_cast<const float4*>(p.gamma + nbase + j * 32 + c * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+    }
+    float4 ra[4], rb[4];
+    pre(0, ra);
+#pragma unroll
+    for (int blk = 0; blk < 8; ++blk) {
+      const f32x16& a = acc[blk >> 2][(blk >> 1) & 1][blk & 1];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(&slabf[lr * 32 + (((2 * q + lg) ^ ((lr >> 1) & 7)) << 2)]) =
+            make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (blk < 7) pre(blk + 1, (blk & 1) ? ra : rb);
+      __builtin_amdgcn_sched_barrier(0);
+      const float4 (&r)[4] = (blk & 1) ? rb : ra;
+      const float4 bv = bvv[blk & 1], gv = gvv[blk & 1];
+      const int mb = mbase + (blk >> 1) * 32, n = nbase + (blk & 1) * 32 + c * 4;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + r8;
+        const int m = mb + row;
+        float4 v = *reinterpret_cast<const float4*>(&slabf[row * 32 + ((c ^ ((row >> 1) & 7)) << 2)]);
+        if (m >= p.M) continue;
+        const size_t orow = p.out_seg ? (size_t)(m / p.out_seg) * p.out_seg_stride + p.out_seg_off + (m % p.out_seg) : (size_t)m;
+        v.x = (v.x + bv.x) * gv.x + r[it].x; v.y = (v.y + bv.y) * gv.y + r[it].y;
+        v.z = (v.z + bv.z) * gv.z + r[it].z; v.w = (v.w + bv.w) * gv.w + r[it].w;
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + orow * p.ldo + n) = v;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {  // epilogue of the finished tile from the wave's private slab
+    float4 bv[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        bv[j][q] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nbase + j * 32 + 8 * q + 4 * lg)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int sidx = 0; sidx < 4; ++sidx) {
+      slab_park16h(acc[sidx >> 1][sidx & 1][0], acc[sidx >> 1][sidx & 1][1], slab, bv, lane, EPI == EPI_GELU_F16);
+      slab_emit16h(slab, mbase + sidx * 32, nbase, lane, p);
+    }
   }
 }
 
@@ -1658,33 +1729,28 @@ __global__ __launch_bounds__(512) void gemm8kp_f16_kernel(GemmArgs p, int total)
     for (int kt = 0; kt < nk; ++kt) {
       const half_t* buf = ring + (kt & 1) * 4 * HT;
       const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
-      RD_B(buf, 0)
-      __builtin_amdgcn_sched_barrier(0);
-      RD_A(buf, 0, 0)
-      if (more1) stage(2, kt + 1);
+#define LOAD_PHASE(RDS, ST) RDS __builtin_amdgcn_sched_barrier(0); ST
+      LOAD_PHASE(RD_B(buf, 0) __builtin_amdgcn_sched_barrier(0); RD_A(buf, 0, 0), if (more1) stage(2, kt + 1);)
       if (more1) wait_vmcnt<6>(); else wait_vmcnt<0>();
       PHASE_SYNC_IN();
       MMA_H(0, 0)
       PHASE_SYNC_OUT();
-      RD_B(buf, 1)
-      __builtin_amdgcn_sched_barrier(0);
-      RD_A(buf, 0, 1)
-      if (more1) stage(3, kt + 1);
+      LOAD_PHASE(RD_B(buf, 1) __builtin_amdgcn_sched_barrier(0); RD_A(buf, 0, 1), if (more1) stage(3, kt + 1);)
       if (more1) wait_vmcnt<6>(); else wait_vmcnt<0>();
       PHASE_SYNC_IN();
       MMA_H(0, 1)
       PHASE_SYNC_OUT();
-      RD_A(buf, 1, 0)
-      if (more1) stage(1, kt + 1);
+      LOAD_PHASE(RD_A(buf, 1, 0), if (more1) stage(1, kt + 1);)
       if (more1) wait_vmcnt<6>(); else wait_vmcnt<0>();
       PHASE_SYNC_IN();
       MMA_H(1, 0)
       PHASE_SYNC_OUT();
-      RD_A(buf, 1, 1)
-      if (more2) { stage(0, kt + 2); wait_vmcnt<4>(); } else if (more1) { wait_vmcnt<2>(); } else { wait_vmcnt<0>(); }
+      LOAD_PHASE(RD_A(buf, 1, 1), if (more2) stage(0, kt + 2);)
+      if (more2) { wait_vmcnt<4>(); } else if (more1) { wait_vmcnt<2>(); } else { wait_vmcnt<0>(); }
       PHASE_SYNC_IN();
       MMA_H(1, 1)
       PHASE_SYNC_OUT();
+#undef LOAD_PHASE
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the stagger: every wave is done with the ring here
 
@@ -1698,71 +1764,7 @@ __global__ __launch_bounds__(512) void gemm8kp_f16_kernel(GemmArgs p, int total)
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    if constexpr (EPI == EPI_F32) {
-      // x (+)= gamma * (acc + bias) in fp32: eight 32x32 blocks through the 4 KiB slab, 8 lanes per 128-byte row; the
-      // residual rows of block s+1 are requested before block s is emitted
-      const int mbase = m0 + wr * 128, nbase = n0 + wc * 64;
-      float* slabf = reinterpret_cast<float*>(slab);
-      const int c = lane & 7, r8 = lane >> 3;
-      auto pre = [&](int blk, float4 (&r)[4]) {
-        const int mb = mbase + (blk >> 1) * 32, n = nbase + (blk & 1) * 32 + c * 4;
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          int m = mb + it * 8 + r8;
-          m = m < p.M ? m : p.M - 1;
-          const size_t rrow = p.resid_mod ? (size_t)(m % p.resid_mod) : (size_t)m;
-          r[it] = p.resid ? *reinterpret_cast<const float4*>(p.resid + rrow * p.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-      };
-      float4 bvv[2], gvv[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        bvv[j] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nbase + j * 32 + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        gvv[j] = p.gamma ? *reinterpret_cast<const float4*>(p.gamma + nbase + j * 32 + c * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
-      }
-      float4 ra[4], rb[4];
-      pre(0, ra);
-#pragma unroll
-      for (int blk = 0; blk < 8; ++blk) {
-        const f32x16& a = acc[blk >> 2][(blk >> 1) & 1][blk & 1];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          *reinterpret_cast<float4*>(&slabf[lr * 32 + (((2 * q + lg) ^ ((lr >> 1) & 7)) << 2)]) =
-              make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (blk < 7) pre(blk + 1, (blk & 1) ? ra : rb);
-        __builtin_amdgcn_sched_barrier(0);
-        const float4 (&r)[4] = (blk & 1) ? rb : ra;
-        const float4 bv = bvv[blk & 1], gv = gvv[blk & 1];
-        const int mb = mbase + (blk >> 1) * 32, n = nbase + (blk & 1) * 32 + c * 4;
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int row = it * 8 + r8;
-          const int m = mb + row;
-          float4 v = *reinterpret_cast<const float4*>(&slabf[row * 32 + ((c ^ ((row >> 1) & 7)) << 2)]);
-          if (m >= p.M) continue;
-          const size_t orow = p.out_seg ? (size_t)(m / p.out_seg) * p.out_seg_stride + p.out_seg_off + (m % p.out_seg) : (size_t)m;
-          v.x = (v.x + bv.x) * gv.x + r[it].x; v.y = (v.y + bv.y) * gv.y + r[it].y;
-          v.z = (v.z + bv.z) * gv.z + r[it].z; v.w = (v.w + bv.w) * gv.w + r[it].w;
-          *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + orow * p.ldo + n) = v;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else {  // epilogue of the finished tile from the wave's private slab
-      const int mbase = m0 + wr * 128, nbase = n0 + wc * 64;
-      float4 bv[2][4];
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          bv[j][q] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nbase + j * 32 + 8 * q + 4 * lg)
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int sidx = 0; sidx < 4; ++sidx) {
-        slab_park16h(acc[sidx >> 1][sidx & 1][0], acc[sidx >> 1][sidx & 1][1], slab, bv, lane, EPI == EPI_GELU_F16);
-        slab_emit16h(slab, mbase + sidx * 32, nbase, lane, p);
-      }
-    }
+    persist_epilogue<EPI>(acc, slab, m0 + wr * 128, n0 + wc * 64, lane, p);
     if (!have) break;
     idx = nidx; tm = ntm_; tn = ntn_;
   }

@@ -25,6 +25,8 @@ T = (d[:, :, :5] - t0) * 0.01          # us
 hw = d[:, 0, 5]; xcc = d[:, 0, 6] & 0xf
 cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7
 cuid = xcc * 1000 + se * 100 + sh * 10 + cu * 1
+cyc = d[:, :, 7].astype(np.float64); dur = (d[:, :, 4] - d[:, :, 0]) * 0.01
+print(f"shader clock over the workgroups' lifetimes: {np.median(cyc / np.maximum(dur, 1e-9)) / 1e3:.3f} GHz (s_memtime / wall)")
 print("blocks", len(d), "distinct CUs", len(set(cuid.tolist())), "kernel span us", T[:, :, 4].max())
 ent = T[:, :, 0].min(1); ls = T[:, :, 1].max(1); le = T[:, :, 2].max(1); si = T[:, :, 3].max(1); sa = T[:, :, 4].max(1)
 print(f"per block (us): prologue {np.mean(ls-ent):.2f}  k-loop {np.mean(le-ls):.2f}  epilogue issue {np.mean(si-le):.2f}  "
