@@ -130,14 +130,14 @@ def main():
     nl, tg, fl = timer.summary()
     achieved = fl / tg / 1e12 if tg > 0 else 0.0
     # HBM-side bytes per GEMM launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same
-    # command, gfx950 read correction applied; see profiles/r01_h_gemm_pmc_traffic.json). None if the file is absent.
+    # command, gfx950 read correction applied; see profiles/r01_m_gemm_pmc_traffic.json). None if the file is absent.
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_h_gemm_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01_m_gemm_pmc_traffic.json")) as f:
             traffic = json.load(f)["all_gemm_launches"]["bytes_per_launch_avg"]
     except Exception:
         pass
-    roofline = {"bound": "mfma", "kernel": "psam_gemm_f16 (gemm8k_f16_kernel 256x256x64 8-phase / gemm_f16_kernel 128x128x64)",
+    roofline = {"bound": "mfma", "kernel": "psam_gemm_f16 (gemm8kp_f16_kernel persistent 256x256x64 8-phase / gemm_f16_kernel 128x128x64)",
                 "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic, "launches": nl,
                 "avg_launch_us": round(tg / max(nl, 1) * 1e6, 2), "flop_per_launch_avg": round(fl / max(nl, 1)),
