@@ -188,6 +188,18 @@ int psam_im2col(const void* in, int B, int H, int W, int C, int kh, int kw, int 
 int psam_im2col_stem(const float* img, int B, int H, int W, int ldo, void* out, void* stream);
 int psam_maxpool3x3s2(const void* in, int B, int H, int W, int C, void* out, void* stream);
 
+/* ---- rotation test-time augmentation: ProtoSAM.forward(..., degrees_rotate != 0) ---------------------------------------------
+ * Replaces util/utils.py:66-83 `rotate_tensor_no_crop` (torchvision `rotate(expand=True)` + `resize(antialias=True)`) and
+ * util/utils.py:40-59 `reverse_tensor` (`resize` + `rotate(expand=False)` + centre crop), called from models/ProtoSAM.py:544
+ * and :553. torchvision 0.15.2 (requirements.txt:65) is not in /root/reference: restated from its tensor code path
+ * (affine grid + grid_sample NEAREST / aten _upsample_bilinear2d_aa), see oracle/rotate.py.
+ * psam_rotate_nearest: planes [C,H,W] fp32 -> [C,outH,outW]; xg / yg = the base-grid linspace values of the (expanded)
+ *   canvas, rt6 = host pointer to the 3x2 rescaled theta (row-major), crop_* = first canvas row / column kept.
+ * psam_resize_aa: anti-aliased bilinear [C,H,W] -> [C,OH,OW] (tmp = fp32 scratch [C,H,OW]). */
+int psam_rotate_nearest(const float* src, float* dst, const float* xg, const float* yg, const float* rt6, int C, int H, int W,
+                        int crop_y, int crop_x, int outH, int outW, void* stream);
+int psam_resize_aa(const float* src, float* tmp, float* dst, int C, int H, int W, int OH, int OW, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

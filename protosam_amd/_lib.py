@@ -51,6 +51,9 @@ SIGNATURES = {
     "psam_im2col": [c_void_p] + [c_int] * 10 + [c_void_p, c_void_p],
     "psam_im2col_stem": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "psam_maxpool3x3s2": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "psam_rotate_nearest": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                            c_int, c_void_p],
+    "psam_resize_aa": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "psam_volume_stats": [c_void_p, c_int, ctypes.c_longlong, c_float, c_float, c_void_p, c_void_p],
     "psam_volume_slices": [c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_int, c_int, c_int,
                            c_void_p, c_void_p],

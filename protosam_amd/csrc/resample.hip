@@ -490,3 +490,84 @@ extern "C" int psam_maxpool3x3s2(const void* in, int B, int H, int W, int C, voi
                      Ho, Wo, (half_t*)out);
   return psam_launch_status();
 }
+
+// =====================================================================================================
+// Rotation test-time augmentation (ProtoSAM.forward(..., degrees_rotate != 0), models/ProtoSAM.py:544-556 through
+// util/utils.py:40-83). The reference calls torchvision 0.15.2's tensor `rotate` (affine grid + grid_sample, NEAREST,
+// zero padding, align_corners = False) and `resize(..., BILINEAR, antialias = True)` (aten `_upsample_bilinear2d_aa`);
+// torchvision is absent from /root/reference, so both are restated from their published algorithms (oracle/rotate.py).
+//
+// psam_rotate_nearest: planes [C, H, W] fp32 -> [C, outH, outW]: output pixel (y, x) samples the source at the affine-grid
+// point built from xg[x + crop_x], yg[y + crop_y] (the host passes torchvision's base-grid `linspace` values, so the
+// expanded canvas and `reverse_tensor`'s centre crop are both expressed by crop offsets) and the 3x2 `rescaled_theta`
+// rt (row-major), un-normalised as grid_sample does and rounded half-to-even.
+__global__ void rotate_nearest_kernel(const float* __restrict__ src, float* __restrict__ dst, const float* __restrict__ xg,
+                                      const float* __restrict__ yg, float r00, float r01, float r10, float r11, float r20,
+                                      float r21, int H, int W, int crop_y, int crop_x, int outH, int outW) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, c = blockIdx.z;
+  if (x >= outW) return;
+  const float bx = xg[x + crop_x], by = yg[y + crop_y];
+  // base_grid[p, :] . rescaled_theta[:, k] over (x, y, 1)
+  const float gx = __fadd_rn(__fadd_rn(__fmul_rn(bx, r00), __fmul_rn(by, r10)), r20);
+  const float gy = __fadd_rn(__fadd_rn(__fmul_rn(bx, r01), __fmul_rn(by, r11)), r21);
+  const float ix = __fdiv_rn(__fadd_rn(__fmul_rn(__fadd_rn(gx, 1.f), (float)W), -1.f), 2.f);
+  const float iy = __fdiv_rn(__fadd_rn(__fmul_rn(__fadd_rn(gy, 1.f), (float)H), -1.f), 2.f);
+  const float fx = nearbyintf(ix), fy = nearbyintf(iy);
+  float v = 0.f;
+  if (fx >= 0.f && fx <= (float)(W - 1) && fy >= 0.f && fy <= (float)(H - 1))
+    v = src[((size_t)c * H + (int)fy) * W + (int)fx];
+  dst[((size_t)c * outH + y) * outW + x] = v;
+}
+extern "C" int psam_rotate_nearest(const float* src, float* dst, const float* xg, const float* yg, const float* rt6, int C,
+                                   int H, int W, int crop_y, int crop_x, int outH, int outW, void* stream) {
+  if (C <= 0 || H <= 0 || W <= 0 || outH <= 0 || outW <= 0 || crop_y < 0 || crop_x < 0 || !rt6) return PSAM_ERR_ARG;
+  hipLaunchKernelGGL(rotate_nearest_kernel, dim3((outW + 255) / 256, outH, C), dim3(256), 0, (hipStream_t)stream, src, dst,
+                     xg, yg, rt6[0], rt6[1], rt6[2], rt6[3], rt6[4], rt6[5], H, W, crop_y, crop_x, outH, outW);
+  return psam_launch_status();
+}
+
+// psam_resize_aa: anti-aliased bilinear resize of fp32 planes [C, H, W] -> [C, OH, OW], separable, width first with an
+// fp32 intermediate [C, H, OW] (aten UpSampleKernel.cpp, `_compute_indices_min_size_weights_aa` with the triangle filter):
+// scale = in / out, support = max(scale, 1), centre = scale * (i + 0.5), taps [int(centre - support + 0.5), int(centre +
+// support + 0.5)) clipped to the input, weights triangle((j - centre + 0.5) / max(scale, 1)) normalised to sum 1.
+__global__ void resize_aa_pass_kernel(const float* __restrict__ src, float* __restrict__ dst, int in_len, int out_len,
+                                      int in_stride, int out_stride, int lines, int line_in_stride, int line_out_stride,
+                                      size_t plane_in, size_t plane_out) {
+  // one thread per (output index i along the resized axis, line l along the other axis); blockIdx.z = plane
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y;
+  if (i >= out_len || l >= lines) return;
+  const float scale = (float)in_len / (float)out_len;
+  const float support = scale >= 1.f ? scale : 1.f;
+  const float invscale = scale >= 1.f ? 1.f / scale : 1.f;
+  const float center = scale * ((float)i + 0.5f);
+  int xmin = (int)(center - support + 0.5f);
+  xmin = xmin > 0 ? xmin : 0;
+  int xmax = (int)(center + support + 0.5f);
+  xmax = xmax < in_len ? xmax : in_len;
+  const int xsize = xmax - xmin;
+  const float* s = src + blockIdx.z * plane_in + (size_t)l * line_in_stride;
+  float total = 0.f;
+  for (int j = 0; j < xsize; ++j) {
+    float a = fabsf(((float)(j + xmin) - center + 0.5f) * invscale);
+    total += a < 1.f ? 1.f - a : 0.f;
+  }
+  float acc = 0.f;
+  for (int j = 0; j < xsize; ++j) {
+    float a = fabsf(((float)(j + xmin) - center + 0.5f) * invscale);
+    float w = a < 1.f ? 1.f - a : 0.f;
+    if (total != 0.f) w /= total;
+    acc += w * s[(size_t)(j + xmin) * in_stride];
+  }
+  dst[blockIdx.z * plane_out + (size_t)l * line_out_stride + (size_t)i * out_stride] = acc;
+}
+extern "C" int psam_resize_aa(const float* src, float* tmp, float* dst, int C, int H, int W, int OH, int OW, void* stream) {
+  if (C <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || !tmp) return PSAM_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  // width: lines = rows of the input
+  hipLaunchKernelGGL(resize_aa_pass_kernel, dim3((OW + 127) / 128, H, C), dim3(128), 0, s, src, tmp, W, OW, 1, 1, H, W, OW,
+                     (size_t)H * W, (size_t)H * OW);
+  // height: lines = columns of the intermediate
+  hipLaunchKernelGGL(resize_aa_pass_kernel, dim3((OH + 127) / 128, OW, C), dim3(128), 0, s, tmp, dst, H, OH, OW, OW, OW, 1, 1,
+                     (size_t)H * OW, (size_t)OH * OW);
+  return psam_launch_status();
+}

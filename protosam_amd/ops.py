@@ -157,6 +157,30 @@ def maxpool3x3s2(x, B, H, W, C, out=None):
     return out, Ho, Wo
 
 
+def rotate_nearest(img, xg, yg, rt, crop_y, crop_x, out_h, out_w):
+    """torchvision-style affine NEAREST resampling of fp32 [B,C,H,W] (protosam_amd/rotate.py); rt = host fp32 [3,2]."""
+    _req(img, torch.float32, "img"); _req(xg, torch.float32, "xg"); _req(yg, torch.float32, "yg")
+    assert img.is_contiguous() and rt.dtype == torch.float32 and rt.device.type == "cpu" and rt.is_contiguous()
+    B, C, H, W = img.shape
+    out = torch.empty((B, C, out_h, out_w), dtype=torch.float32, device=img.device)
+    st = _lib.lib().psam_rotate_nearest(_ptr(img), _ptr(out), _ptr(xg), _ptr(yg), rt.data_ptr(), B * C, H, W, crop_y, crop_x,
+                                        out_h, out_w, _stream())
+    _lib.check(st, "psam_rotate_nearest")
+    return out
+
+
+def resize_aa(img, oh, ow):
+    """anti-aliased bilinear resize of fp32 [B,C,H,W] (aten _upsample_bilinear2d_aa semantics)."""
+    _req(img, torch.float32, "img")
+    assert img.is_contiguous()
+    B, C, H, W = img.shape
+    tmp = torch.empty((B * C, H, ow), dtype=torch.float32, device=img.device)
+    out = torch.empty((B, C, oh, ow), dtype=torch.float32, device=img.device)
+    st = _lib.lib().psam_resize_aa(_ptr(img), _ptr(tmp), _ptr(out), B * C, H, W, oh, ow, _stream())
+    _lib.check(st, "psam_resize_aa")
+    return out
+
+
 def layernorm(x, weight, bias, eps, out=None, out_dtype=torch.float16, out2=None, zero_tail_rows=0, M=None):
     """Row LayerNorm of fp32 x[M,D]. Optionally writes `zero_tail_rows` all-zero rows after row M-1."""
     _req(x, torch.float32, "x"); _req(weight, torch.float32, "weight"); _req(bias, torch.float32, "bias")

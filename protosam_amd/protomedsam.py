@@ -71,14 +71,12 @@ class ProtoMedSAM(nn.Module):
 
     @torch.no_grad()
     def forward(self, query_image, coarse_model_input, degrees_rotate=0):
-        if degrees_rotate != 0:
-            raise NotImplementedError("rotation TTA is outside the hot path")
+        from .protosam import ProtoSAM
         original_size = query_image.shape[-2]
         dev = query_image.device
-        coarse_model_input.set_query_images(query_image)
-        output_logits = self.coarse_segmentation_model(coarse_model_input)                 # [1,2,H,W] ALP logits
+        # ProtoMedSAM.py:129-139 (rotation TTA around the coarse model; identity at 0 degrees)
+        output_logits = ProtoSAM._coarse_logits(self, query_image, coarse_model_input, degrees_rotate)   # [1,2,H,W] ALP logits
         if self.coarse_pred_only:                                                          # ProtoMedSAM.py:163-172
-            from .protosam import ProtoSAM
             return ProtoSAM._coarse_only(self, output_logits, original_size)
         bufs = self._work(dev)
         sam = self.medsam

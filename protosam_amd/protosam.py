@@ -22,8 +22,8 @@ so `use_mask` then changes nothing and its work is skipped.
 Negative points (`use_neg_points=True`, ProtoSAM.py:361-372,395-419,508-511): `psam_neg_points` finds, on the device, the
 most confident background pixel of each component's 10-pixel dilation ring and the global one (p_bg >= 0.95); components
 whose prompt sets end up with different token counts are decoded in separate batches.
-Unsupported (outside SURVEY §8's hot path, raise NotImplementedError):
-`degrees_rotate != 0`, `debug` plotting, training mode.
+`degrees_rotate != 0` runs the coarse model on the rotated query and rotates its logits back (protosam_amd/rotate.py).
+Unsupported (outside SURVEY §8's hot path, raise NotImplementedError): `debug` plotting, training mode.
 """
 import os
 from abc import ABC, abstractmethod
@@ -34,6 +34,7 @@ import torch.nn as nn
 
 from . import ops
 from .grid_proto_fewshot import FewShotSeg
+from .rotate import reverse_tensor, rotate_tensor_no_crop
 from .sam_wrapper import SamWrapper
 from .segment_anything import SamPredictor, sam_model_registry
 from .segment_anything.utils.transforms import ResizeLongestSide
@@ -343,18 +344,26 @@ class ProtoSAM(nn.Module):
 
     def forward(self, query_image, coarse_model_input, degrees_rotate=0):
         """Reference contract (ProtoSAM.py:536-678): one query slice [1,3,H,W] -> (pred [H,W] float {0,1}, scores)."""
-        if degrees_rotate != 0:
-            raise NotImplementedError("rotation TTA (util/utils.py:40-83) is outside the hot path")
         if self.training:
             raise NotImplementedError("training-mode outputs (logits) are outside the inference hot path")
         if self.coarse_pred_only:
-            coarse_model_input.set_query_images(query_image)
-            output_logits = self.coarse_segmentation_model(coarse_model_input)
+            output_logits = self._coarse_logits(query_image, coarse_model_input, degrees_rotate)
             return self._coarse_only(output_logits, query_image.shape[-2])
-        return self.forward_batch(query_image, coarse_model_input)[0]
+        return self.forward_batch(query_image, coarse_model_input, degrees_rotate)[0]
+
+    def _coarse_logits(self, query_images, coarse_model_input, degrees_rotate=0):
+        """ProtoSAM.py:544-556: the coarse model sees the query rotated by `degrees_rotate` (expanded canvas resized back to
+        H x W), its logits are rotated back and centre-cropped (protosam_amd/rotate.py); identity at 0 degrees."""
+        if degrees_rotate == 0:
+            coarse_model_input.set_query_images(query_images)
+            return self.coarse_segmentation_model(coarse_model_input)
+        rotated, (rot_h, rot_w) = rotate_tensor_no_crop(query_images, degrees_rotate)
+        coarse_model_input.set_query_images(rotated)
+        logits_rot = self.coarse_segmentation_model(coarse_model_input)
+        return reverse_tensor(logits_rot, rot_h, rot_w, -degrees_rotate)
 
     @torch.no_grad()
-    def forward_batch(self, query_images, coarse_model_input):
+    def forward_batch(self, query_images, coarse_model_input, degrees_rotate=0):
         """MI355X extension: B independent query slices [B,3,H,W] sharing one support set go through every stage as
         one batch (the ViT GEMMs see M = B*tokens rows, the mask decoder sees all components of all slices at once).
         Slices never interact, so each result equals the per-slice `forward`. Returns a list of (pred, scores)."""
@@ -374,8 +383,7 @@ class ProtoSAM(nn.Module):
             with torch.cuda.stream(side):
                 feat_tok = self._sam_features(query_images, bufs, B, S)
                 bufs["sam_done"].record(side)
-        coarse_model_input.set_query_images(query_images)
-        output_logits = self.coarse_segmentation_model(coarse_model_input)      # [B,2,H,W]
+        output_logits = self._coarse_logits(query_images, coarse_model_input, degrees_rotate)   # [B,2,H,W]
         # 1. (bilinear to 1024) -> softmax -> argmax                               ProtoSAM.py:592-602
         bufs["fg_sum"].zero_()
         output_p, pred = ops.prob_argmax(output_logits.float().contiguous(), S, S, prob=bufs["prob"], pred=bufs["pred"],
