@@ -47,7 +47,14 @@ struct AttnArgs {
 
 #define KT 64  // keys per tile
 
-template <int HD, int MODE, int NW>
+// FULL (global modes only): the host guarantees N % 64 == 0, so no key of any tile is masked and every staging load is in
+// range - the zero-fills, null checks and per-element mask selects (a quarter of the loop's VALU issue in a kernel whose
+// SIMDs are 87 % issue-busy) drop out at compile time.
+// native 16-byte vector for the staging registers: HIP's `uint4` is a struct, and its copies reach the optimiser as
+// cross-address-space memcpys that keep the staging array in memory (promoted to LDS / scratch)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int HD, int MODE, int NW, bool FULL = false>
 // HIP's second launch-bound argument is the minimum number of WAVES PER SIMD (not CUDA's blocks per multiprocessor): the
 // 7-wave window kernel needs 4 per SIMD (<= 128 VGPRs) for two workgroups to be co-resident on a CU
 __global__ __launch_bounds__(NW * 64, (MODE == 2 ? 4 : 2)) void attn_kernel(AttnArgs p) {
@@ -261,12 +268,12 @@ __global__ __launch_bounds__(NW * 64, (MODE == 2 ? 4 : 2)) void attn_kernel(Attn
   }
 
   // ---- K/V tile prefetch registers -----------------------------------------------------------
-  uint4 kreg[NKL];
-  uint4 vreg[NVL][2];
+  u32x4 kreg[NKL];
+  u32x4 vreg[NVL][2];
 
   auto key_src = [&](int kidx, int which) -> const half_t* {
     // pointer to the hd-vector of key `kidx` (tile-global index), or nullptr if masked
-    if (kidx >= nkeys) return nullptr;
+    if (!FULL && kidx >= nkeys) return nullptr;
     if (MODE == 2) {
       int tok = win_token(kidx);
       if (tok < 0) return p.pad_row + ((size_t)which * H + h) * HD;
@@ -279,24 +286,38 @@ __global__ __launch_bounds__(NW * 64, (MODE == 2 ? 4 : 2)) void attn_kernel(Attn
 #pragma unroll
     for (int i = 0; i < NKL; ++i) {
       int idx = t + i * NT;
-      kreg[i] = make_uint4(0, 0, 0, 0);
-      if (idx < KRES * CH) {
-        int key = idx / CH, c = idx % CH;
-        const half_t* src = key_src(tile * KT + key, 1);
-        if (src) kreg[i] = *reinterpret_cast<const uint4*>(src + c * 8);
+      if constexpr (FULL) {   // every lane loads (out-of-range lanes re-read the last chunk and never store it): no partially
+                    // defined registers, so the compiler keeps all requests in flight
+        idx = idx < KRES * CH ? idx : KRES * CH - 1;
+        const int key = idx / CH, c = idx % CH;
+        kreg[i] = *reinterpret_cast<const u32x4*>(key_src(tile * KT + key, 1) + c * 8);
+      } else {
+        kreg[i] = u32x4{0u, 0u, 0u, 0u};
+        if (idx < KRES * CH) {
+          int key = idx / CH, c = idx % CH;
+          const half_t* src = key_src(tile * KT + key, 1);
+          if (src) kreg[i] = *reinterpret_cast<const u32x4*>(src + c * 8);
+        }
       }
     }
 #pragma unroll
     for (int i = 0; i < NVL; ++i) {
       int idx = t + i * NT;
-      vreg[i][0] = make_uint4(0, 0, 0, 0);
-      vreg[i][1] = make_uint4(0, 0, 0, 0);
-      if (idx < (VCOL / 2) * CH) {
-        int kp = idx / CH, c = idx % CH;
-        const half_t* s0 = key_src(tile * KT + 2 * kp, 2);
-        const half_t* s1 = key_src(tile * KT + 2 * kp + 1, 2);
-        if (s0) vreg[i][0] = *reinterpret_cast<const uint4*>(s0 + c * 8);
-        if (s1) vreg[i][1] = *reinterpret_cast<const uint4*>(s1 + c * 8);
+      if constexpr (FULL) {
+        idx = idx < (VCOL / 2) * CH ? idx : (VCOL / 2) * CH - 1;
+        const int kp = idx / CH, c = idx % CH;
+        vreg[i][0] = *reinterpret_cast<const u32x4*>(key_src(tile * KT + 2 * kp, 2) + c * 8);
+        vreg[i][1] = *reinterpret_cast<const u32x4*>(key_src(tile * KT + 2 * kp + 1, 2) + c * 8);
+      } else {
+        vreg[i][0] = u32x4{0u, 0u, 0u, 0u};
+        vreg[i][1] = u32x4{0u, 0u, 0u, 0u};
+        if (idx < (VCOL / 2) * CH) {
+          int kp = idx / CH, c = idx % CH;
+          const half_t* s0 = key_src(tile * KT + 2 * kp, 2);
+          const half_t* s1 = key_src(tile * KT + 2 * kp + 1, 2);
+          if (s0) vreg[i][0] = *reinterpret_cast<const u32x4*>(s0 + c * 8);
+          if (s1) vreg[i][1] = *reinterpret_cast<const u32x4*>(s1 + c * 8);
+        }
       }
     }
   };
@@ -307,7 +328,7 @@ __global__ __launch_bounds__(NW * 64, (MODE == 2 ? 4 : 2)) void attn_kernel(Attn
       int idx = t + i * NT;
       if (idx < KRES * CH) {
         int key = idx / CH, c = idx % CH;
-        *reinterpret_cast<uint4*>(&Ks[koff_of(key, c)]) = kreg[i];
+        *reinterpret_cast<u32x4*>(&Ks[koff_of(key, c)]) = kreg[i];
       }
     }
 #pragma unroll
@@ -412,7 +433,7 @@ __global__ __launch_bounds__(NW * 64, (MODE == 2 ? 4 : 2)) void attn_kernel(Attn
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float sv = MODE == 1 ? fmaf(st[tt][qt][r], sl2, rwv[r]) : st[tt][qt][r] * sl2;
-          if (last_partial) {
+          if (!FULL && last_partial) {
             const int kidx = kbase + (tt >> 1) * 32 + g * 8 + (tt & 1) * 4 + r;
             if (kidx >= nkeys) sv = -INFINITY;
           }
@@ -515,10 +536,14 @@ static int launch_attn(AttnArgs p, int mode, hipStream_t s) {
     p.nqb = (p.N + NW * 32 - 1) / (NW * 32);
     const int groups8 = (p.B * p.H + 7) / 8;
     dim3 grid(groups8 * 8 * p.nqb), block(NW * 64);
-    if (mode == 1)
-      hipLaunchKernelGGL((attn_kernel<HD, 1, NW>), grid, block, 0, s, p);
-    else
-      hipLaunchKernelGGL((attn_kernel<HD, 0, NW>), grid, block, 0, s, p);
+    const bool full = (p.N % 64) == 0;
+    if (mode == 1) {
+      if (full) hipLaunchKernelGGL((attn_kernel<HD, 1, NW, true>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((attn_kernel<HD, 1, NW>), grid, block, 0, s, p);
+    } else {
+      if (full) hipLaunchKernelGGL((attn_kernel<HD, 0, NW, true>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((attn_kernel<HD, 0, NW>), grid, block, 0, s, p);
+    }
   }
   return psam_launch_status();
 }
