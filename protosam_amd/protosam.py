@@ -320,6 +320,7 @@ class ProtoSAM(nn.Module):
                 q1024=torch.empty((B, 3, 1024, 1024), dtype=torch.float32, device=dev),
                 mm=torch.empty(2 * B, dtype=torch.int32, device=dev),
                 patches=torch.empty((B * 4096, 768), dtype=torch.float16, device=dev),
+                fg_host=torch.zeros(B, dtype=torch.int32).pin_memory(), fg_event=torch.cuda.Event(),
                 event=torch.cuda.Event(), sam_done=torch.cuda.Event())
         if self._ccl is None or self._ccl.slots < B:
             self._ccl = ops.CclWorkspace(1024, 1024, MAX_COMPONENTS, dev, slots=max(B, 1))
@@ -336,11 +337,11 @@ class ProtoSAM(nn.Module):
         sam = self.sam
         q = query_images.float().contiguous()
         if tuple(q.shape[-2:]) != (S, S):
-            q = ops.bilinear_nchw(q, S, S, out=bufs["q1024"])
-        ops.minmax(q, B, mm=bufs["mm"])
-        ops.sam_patchify(q, bufs["mm"], S, sam.image_encoder.patch_size, sam._mean_host, sam._std_host, True,
-                         out=bufs["patches"])
-        return sam.image_encoder.encode_patches(bufs["patches"], B)
+            q = ops.bilinear_nchw(q, S, S, out=bufs["q1024"][:B])
+        mm, patches = bufs["mm"][:2 * B], bufs["patches"][:B * 4096]       # B may be a sub-batch (non-empty slices only)
+        ops.minmax(q, B, mm=mm)
+        ops.sam_patchify(q, mm, S, sam.image_encoder.patch_size, sam._mean_host, sam._std_host, True, out=patches)
+        return sam.image_encoder.encode_patches(patches, B)
 
     def forward(self, query_image, coarse_model_input, degrees_rotate=0):
         """Reference contract (ProtoSAM.py:536-678): one query slice [1,3,H,W] -> (pred [H,W] float {0,1}, scores)."""
@@ -388,6 +389,8 @@ class ProtoSAM(nn.Module):
         bufs["fg_sum"].zero_()
         output_p, pred = ops.prob_argmax(output_logits.float().contiguous(), S, S, prob=bufs["prob"], pred=bufs["pred"],
                                          fg_sum=bufs["fg_sum"])
+        bufs["fg_host"].copy_(bufs["fg_sum"], non_blocking=True)                # foreground pixel count per slice
+        bufs["fg_event"].record()
         # 2. connected components + per-component statistics; the tables go to pinned host memory asynchronously
         cw = self._ccl
         for b in range(B):
@@ -405,8 +408,20 @@ class ProtoSAM(nn.Module):
         bufs["event"].record()
         # 3./4. image hand-off + SAM image encoder (already running on the side stream, or enqueued here before the host looks
         #       at the component tables)
+        #       A slice whose coarse mask is empty never reaches SAM (ProtoSAM.py:612-613 returns before `set_image`): only the
+        #       non-empty slices are encoded. The foreground counts arrive while the CCL kernels above keep the GPU busy.
+        feat_row = list(range(B))                                               # slice -> row of feat_tok
         if feat_tok is None:
-            feat_tok = self._sam_features(query_images, bufs, B, S)
+            bufs["fg_event"].synchronize()
+            keep = [b for b in range(B) if int(bufs["fg_host"][b]) > 0]
+            if len(keep) == B:
+                feat_tok = self._sam_features(query_images, bufs, B, S)
+            elif keep:
+                sub = query_images[torch.tensor(keep, device=dev)]
+                feat_tok = self._sam_features(sub, bufs, len(keep), S)
+                feat_row = [-1] * B
+                for i, b in enumerate(keep):
+                    feat_row[b] = i
         # 5. host: number of components and prompts per slice
         bufs["event"].synchronize()
         if side is not None:
@@ -414,7 +429,7 @@ class ProtoSAM(nn.Module):
             feat_tok.record_stream(main)
         tabs = cw.tabs_host[:B].numpy()
         results = [None] * B
-        coords, labels, img_idx, spans = [], [], [], []
+        coords, labels, img_idx, slice_idx, spans = [], [], [], [], []   # img_idx: row of feat_tok, slice_idx: slice
         stats = []
         for b in range(B):
             tab = tabs[b]
@@ -428,14 +443,15 @@ class ProtoSAM(nn.Module):
                 ids = [int(tab[3]) + 1] if self.use_cca else list(range(1, n + 1))
                 spans.append((b, len(img_idx), len(ids)))
                 labels += ids
-                img_idx += [b] * len(ids)
+                img_idx += [feat_row[b]] * len(ids)
+                slice_idx += [b] * len(ids)
                 stats[b].update(n_prompts=len(ids))
                 continue
             c, l, rows = self._prompts_from_table(tab, bufs["neg_keys_host"][b].numpy() if self.use_neg_points else None)
             spans.append((b, len(img_idx), len(l)))
             coords += c
             labels += l
-            img_idx += [b] * len(l)
+            img_idx += [feat_row[b]] * len(l)
             stats[b].update(n_prompts=len(l), table=rows, prompts=(c, l))
         self.last_stats = stats[0] if B == 1 else dict(per_slice=stats)
         if spans and self._mask_only:
@@ -447,7 +463,8 @@ class ProtoSAM(nn.Module):
             iop = torch.tensor(img_idx, dtype=torch.int64).to(dev, non_blocking=True)
             ids = torch.tensor(labels, dtype=torch.int32).to(dev, non_blocking=True)
             fg, bg = self._mask_vals
-            prompt = torch.where(bufs["lab256"][iop] == ids[:, None, None], fg, bg).to(torch.float32)
+            sop = torch.tensor(slice_idx, dtype=torch.int64).to(dev, non_blocking=True)
+            prompt = torch.where(bufs["lab256"][sop] == ids[:, None, None], fg, bg).to(torch.float32)
             dense = sam.prompt_encoder.embed_masks_tokens(prompt[:, None])               # [P, 4096, 256]
             src = (feat_tok[iop] + dense).contiguous()                                    # mask_decoder.py:126-127
             tokens = dpk["out_tok"].unsqueeze(0).expand(P, -1, -1).contiguous()

@@ -113,6 +113,11 @@ class ImageEncoderViT(nn.Module):
 
     def _workspace(self, B):
         if B not in self._ws:
+            big = max((b for b in self._ws if b > B), default=None)
+            if big is not None:   # a sub-batch (e.g. only the slices with a non-empty coarse mask): views of the larger set
+                N = self.grid * self.grid
+                self._ws[B] = {k: (v[:B] if v.shape[0] == big else v[:B * N]) for k, v in self._ws[big].items()}
+                return self._ws[B]
             D, oc, N, H = self.embed_dim, self.out_chans, self.grid * self.grid, self.num_heads
             dev = self.pos_embed.device
             M = B * N

@@ -177,6 +177,59 @@ def test_forward_batch_equals_per_slice(dev):
         assert len(sb) == len(s1) and np.allclose(np.array(sb, dtype=np.float64), np.array(s1, dtype=np.float64), atol=2e-3)
 
 
+@pytest.mark.parametrize("mask_only", [False, True])
+def test_forward_batch_skips_sam_for_empty_slices(dev, mask_only):
+    """A slice whose coarse mask is empty never reaches SAM (ProtoSAM.py:612-613 returns before set_image): in a batch only
+    the non-empty slices are encoded, and every slice still equals its per-slice forward."""
+    from protosam_amd.protosam import InputFactory, TYPE_ALPNET
+    from protosam_amd.synth import synth_pair
+    kw = dict(use_bbox=False, use_points=False, use_mask=True) if mask_only else \
+        dict(use_bbox=True, use_points=True, point_mode="both")
+    model, _ = _build(dev, "random:vit_b:1234:2", 2, **kw)
+    s_img, s_m, q0, _ = synth_pair(512, seed=0)
+    _, _, q1, _ = synth_pair(512, seed=3)
+    _, _, q2, _ = synth_pair(512, seed=5)
+    qs = torch.cat([q0, q1, q2, q0], 0).to(dev)
+    inp = InputFactory.create_input(TYPE_ALPNET, qs, support_images=[s_img], support_labels=[s_m], isval=True,
+                                    val_wsize=2)
+    inp.to(dev)
+    real = model.coarse_segmentation_model
+    empty = (0, 2)
+
+    class SomeEmpty:   # the real coarse model, but slices 0 and 2 of a 4-batch predict background everywhere
+        def __call__(self, cin):
+            z = real(cin).clone()
+            if z.shape[0] == 4:
+                for b in empty:
+                    z[b, 0], z[b, 1] = 5.0, -5.0
+            return z
+    calls = []
+    enc = model.sam.image_encoder
+    orig = enc.encode_patches
+    enc.encode_patches = lambda patches, B: (calls.append(B), orig(patches, B))[1]
+    try:
+        model.coarse_segmentation_model = SomeEmpty()
+        batched = model.forward_batch(qs, inp)
+        assert calls == [2]                                   # two of four slices went through the image encoder
+        for b in empty:
+            pb, sb = batched[b]
+            assert pb.shape == (1024, 1024) and int(pb.sum()) == 0 and sb == [0]
+        model.coarse_segmentation_model = real
+        for b in (1, 3):
+            p1, s1 = model(qs[b:b + 1], inp)
+            pb, sb = batched[b]
+            assert pb.shape == p1.shape and (pb != p1).sum().item() <= 8
+            assert len(sb) == len(s1) and np.allclose(np.array(sb, dtype=np.float64), np.array(s1, dtype=np.float64), atol=2e-3)
+        calls.clear()
+        model.coarse_segmentation_model = SomeEmpty()
+        empty = (0, 1, 2, 3)
+        out = model.forward_batch(qs, inp)
+        assert calls == [] and all(int(p.sum()) == 0 and sc == [0] for p, sc in out)
+    finally:
+        enc.encode_patches = orig
+        model.coarse_segmentation_model = real
+
+
 def test_protomedsam_forward_vs_oracle(dev):
     from oracle import alp as oalp, dinov2 as odino, glue
     from protosam_amd.grid_proto_fewshot import FewShotSeg
