@@ -97,44 +97,72 @@ extern "C" int psam_bilinear_nchw(const float* in, int planes, int IH, int IW, i
 
 // logits [B,2,IH,IW] -> (bilinear to OH,OW unless equal) -> softmax -> prob [B,2,OH,OW], pred u8 [B,OH,OW]
 // fg_sum[b] (optional): number of foreground pixels (int32, atomically accumulated; caller zeroes it).
-__global__ void prob_argmax_kernel(const float* __restrict__ logits, int IH, int IW, int OH, int OW,
-                                   float* __restrict__ prob, uint8_t* __restrict__ pred, int* __restrict__ fg_sum) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+// Each thread produces four consecutive pixels of a row (16-byte probability stores, one 4-byte label store); the
+// foreground count is reduced over the workgroup before the single atomic (it was one contended atomic per wave).
+__global__ __launch_bounds__(256) void prob_argmax_kernel(const float* __restrict__ logits, int IH, int IW, int OH, int OW,
+                                                          float* __restrict__ prob, uint8_t* __restrict__ pred,
+                                                          int* __restrict__ fg_sum) {
+  __shared__ int wsum[4];
+  const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   const int y = blockIdx.y, b = blockIdx.z;
-  int fg = 0;
-  if (x < OW) {
+  int fgc = 0;
+  if (x0 < OW) {
     const float* l0p = logits + ((size_t)b * 2 + 0) * IH * IW;
     const float* l1p = l0p + (size_t)IH * IW;
-    float l0, l1;
-    if (IH == OH && IW == OW) {
-      l0 = l0p[(size_t)y * IW + x];
-      l1 = l1p[(size_t)y * IW + x];
-    } else {
-      const float sh = (float)IH / (float)OH, sw = (float)IW / (float)OW;
-      Lin ly = lin_src(y, sh, IH), lx = lin_src(x, sw, IW);
-      l0 = bilerp(l0p, IW, ly, lx);
-      l1 = bilerp(l1p, IW, ly, lx);
+    const bool same = (IH == OH && IW == OW);
+    const float sh = (float)IH / (float)OH, sw = (float)IW / (float)OW;
+    Lin ly = lin_src(y, sh, IH);
+    float p0v[4], p1v[4];
+    uint8_t fgv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int x = min(x0 + k, OW - 1);
+      float l0, l1;
+      if (same) {
+        l0 = l0p[(size_t)y * IW + x];
+        l1 = l1p[(size_t)y * IW + x];
+      } else {
+        Lin lx = lin_src(x, sw, IW);
+        l0 = bilerp(l0p, IW, ly, lx);
+        l1 = bilerp(l1p, IW, ly, lx);
+      }
+      const float m = fmaxf(l0, l1);
+      const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+      const float s = e0 + e1;
+      p0v[k] = e0 / s;
+      p1v[k] = e1 / s;
+      fgv[k] = p1v[k] > p0v[k] ? 1 : 0;  // argmax returns the first maximum on ties
+      if (x0 + k < OW) fgc += fgv[k];
     }
-    const float m = fmaxf(l0, l1);
-    const float e0 = expf(l0 - m), e1 = expf(l1 - m);
-    const float s = e0 + e1;
-    const float p0 = e0 / s, p1 = e1 / s;
-    const size_t o = ((size_t)b * 2) * OH * OW + (size_t)y * OW + x;
-    prob[o] = p0;
-    prob[o + (size_t)OH * OW] = p1;
-    fg = p1 > p0 ? 1 : 0;  // argmax returns the first maximum on ties
-    pred[((size_t)b * OH + y) * OW + x] = (uint8_t)fg;
+    const size_t o = ((size_t)b * 2) * OH * OW + (size_t)y * OW + x0;
+    if (x0 + 3 < OW && (OW & 3) == 0) {
+      *reinterpret_cast<float4*>(prob + o) = make_float4(p0v[0], p0v[1], p0v[2], p0v[3]);
+      *reinterpret_cast<float4*>(prob + o + (size_t)OH * OW) = make_float4(p1v[0], p1v[1], p1v[2], p1v[3]);
+      *reinterpret_cast<uchar4*>(pred + ((size_t)b * OH + y) * OW + x0) = make_uchar4(fgv[0], fgv[1], fgv[2], fgv[3]);
+    } else {
+      for (int k = 0; k < 4 && x0 + k < OW; ++k) {
+        prob[o + k] = p0v[k];
+        prob[o + k + (size_t)OH * OW] = p1v[k];
+        pred[((size_t)b * OH + y) * OW + x0 + k] = fgv[k];
+      }
+    }
   }
   if (fg_sum) {
-    unsigned long long bal = __ballot(fg);
-    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&fg_sum[b], __popcll(bal));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) fgc += __shfl_xor(fgc, o, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = fgc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+      if (t) atomicAdd(&fg_sum[b], t);
+    }
   }
 }
 
 extern "C" int psam_prob_argmax(const float* logits, int B, int IH, int IW, int OH, int OW, float* prob, void* pred,
                                 int* fg_sum, void* stream) {
   if (B <= 0) return PSAM_ERR_ARG;
-  hipLaunchKernelGGL(prob_argmax_kernel, dim3((OW + 255) / 256, OH, B), dim3(256), 0, (hipStream_t)stream, logits, IH,
+  hipLaunchKernelGGL(prob_argmax_kernel, dim3((OW + 1023) / 1024, OH, B), dim3(256), 0, (hipStream_t)stream, logits, IH,
                      IW, OH, OW, prob, (uint8_t*)pred, fg_sum);
   return psam_launch_status();
 }
@@ -173,14 +201,28 @@ __global__ __launch_bounds__(256) void minmax_kernel(const float* __restrict__ x
   const int b = blockIdx.y;
   const float* p = x + (size_t)b * n_per_img;
   float lo = INFINITY, hi = -INFINITY;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_per_img; i += (size_t)gridDim.x * blockDim.x) {
+  const size_t n4 = ((reinterpret_cast<uintptr_t>(p) & 15) == 0) ? n_per_img / 4 : 0;   // 16-byte loads where aligned
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(p)[i];
+    lo = fminf(fminf(lo, v.x), fminf(fminf(v.y, v.z), v.w));
+    hi = fmaxf(fmaxf(hi, v.x), fmaxf(fmaxf(v.y, v.z), v.w));
+  }
+  for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_per_img; i += (size_t)gridDim.x * blockDim.x) {
     float v = p[i];
     lo = fminf(lo, v);
     hi = fmaxf(hi, v);
   }
   lo = wave_min(lo);
   hi = wave_max(hi);
+  __shared__ float red[2][4];      // one atomic pair per workgroup (the 32 K per-wave atomics on 2 B addresses were the cost)
   if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = lo;
+    red[1][threadIdx.x >> 6] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    lo = fminf(fminf(red[0][0], red[0][1]), fminf(red[0][2], red[0][3]));
+    hi = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
     atomicMin(&mm[2 * b], f2ord(lo));
     atomicMax(&mm[2 * b + 1], f2ord(hi));
   }
@@ -220,8 +262,8 @@ extern "C" int psam_minmax(const float* x, int B, long long n_per_img, void* mm,
   if (B <= 0 || n_per_img <= 0) return PSAM_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(minmax_init_kernel, dim3((B + 63) / 64), dim3(64), 0, s, (uint32_t*)mm, B);
-  int nb = (int)((n_per_img + 256 * 8 - 1) / (256 * 8));
-  if (nb > 512) nb = 512;
+  int nb = (int)((n_per_img + 256 * 16 - 1) / (256 * 16));
+  if (nb > 128) nb = 128;
   hipLaunchKernelGGL(minmax_kernel, dim3(nb, B), dim3(256), 0, s, x, (size_t)n_per_img, (uint32_t*)mm);
   return psam_launch_status();
 }
