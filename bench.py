@@ -130,10 +130,10 @@ def main():
     nl, tg, fl = timer.summary()
     achieved = fl / tg / 1e12 if tg > 0 else 0.0
     # HBM-side bytes per GEMM launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same
-    # command, gfx950 read correction applied; see profiles/r01_m_gemm_pmc_traffic.json). None if the file is absent.
+    # command, gfx950 read correction applied; see profiles/r01_n_gemm_pmc_traffic.json). None if the file is absent.
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_m_gemm_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01_n_gemm_pmc_traffic.json")) as f:
             traffic = json.load(f)["all_gemm_launches"]["bytes_per_launch_avg"]
     except Exception:
         pass
