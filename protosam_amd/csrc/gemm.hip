@@ -88,6 +88,34 @@ __device__ __forceinline__ bool tile_map(int bid, int ntm, int ntn, int mode, in
   tn = c0 + rem / rows;
   return true;
 }
+// Largest number of tiles any XCD region of the 2-D map (mode 0) holds (host side). One workgroup per CU and 32 CUs per
+// XCD: a region of 33 tiles costs two rounds where a balanced split costs one (85 x 3 tiles: five regions of 11 x 3).
+static int tile_map_max_region(int ntm, int ntn) {
+  int xm = 8, xn = 1, best = (ntm + 7) / 8 + ntn;
+  int c = (ntm + 3) / 4 + (ntn + 1) / 2;
+  if (c < best) { best = c; xm = 4; xn = 2; }
+  c = (ntm + 1) / 2 + (ntn + 3) / 4;
+  if (c < best) { best = c; xm = 2; xn = 4; }
+  c = ntm + (ntn + 7) / 8;
+  if (c < best) { best = c; xm = 1; xn = 8; }
+  int mx = 0;
+  for (int x = 0; x < 8; ++x) {
+    const int rx = x / xn, cx = x % xn;
+    const int nr = ((rx + 1) * ntm) / xm - (rx * ntm) / xm, nc = ((cx + 1) * ntn) / xn - (cx * ntn) / xn;
+    mx = nr * nc > mx ? nr * nc : mx;
+  }
+  return mx;
+}
+// map for the one-workgroup-per-CU kernels: the 2-D region map unless its fullest region needs more rounds than a balanced
+// split of the tiles (then contiguous, balanced chunks per XCD: mode 2). PSAM_GEMM_MAP overrides.
+static int pick_map_mode(int ntm, int ntn) {
+  static int forced = -2;
+  if (forced == -2) { const char* e = getenv("PSAM_GEMM_MAP"); forced = e ? atoi(e) : -1; }
+  if (forced >= 0) return forced;
+  const int total = ntm * ntn;
+  const int rounds_region = (tile_map_max_region(ntm, ntn) + 31) / 32, rounds_even = (total + 255) / 256;
+  return rounds_region > rounds_even ? 2 : 0;
+}
 // grid size that covers every region of tile_map (host side)
 static int tile_map_grid(int ntm, int ntn, int mode) {
   if (mode != 0) return ntm * ntn;
@@ -1784,8 +1812,10 @@ static void launch8kp(const GemmArgs& p, hipStream_t s) {
     attr = true;
   }
   const int ntm = (p.M + 255) / 256, ntn = p.N / 256;
-  const int total = tile_map_grid(ntm, ntn, p.map_mode);
-  hipLaunchKernelGGL((gemm8kp_f16_kernel<EPI>), dim3(total < 256 ? total : 256), dim3(512), LDS, s, p, total);
+  GemmArgs q = p;
+  q.map_mode = pick_map_mode(ntm, ntn);
+  const int total = tile_map_grid(ntm, ntn, q.map_mode);
+  hipLaunchKernelGGL((gemm8kp_f16_kernel<EPI>), dim3(total < 256 ? total : 256), dim3(512), LDS, s, q, total);
 }
 
 template <int EPI>
@@ -1875,7 +1905,7 @@ static int gemm_dispatch(const void* A, const void* W, const float* bias, void* 
   p.out_seg = out_seg;
   p.out_seg_stride = out_seg_stride;
   p.out_seg_off = out_seg_off;
-  { const char* e = getenv("PSAM_GEMM_MAP"); p.map_mode = e ? atoi(e) : 0; }
+  { static int mm = -2; if (mm == -2) { const char* e = getenv("PSAM_GEMM_MAP"); mm = e ? atoi(e) : 0; } p.map_mode = mm; }
   { const char* e = getenv("PSAM_GEMM_DBG"); p.dbg = e ? atoi(e) : 0; }
   p.trace = nullptr;
   { static int st = -1; if (st < 0) { const char* e = getenv("PSAM_GEMM_STAGGER"); st = e ? atoi(e) : 0; } p.stagger = st; }
