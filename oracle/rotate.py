@@ -12,6 +12,9 @@ torch:
     `grid_sample(mode="nearest", padding_mode="zeros", align_corners=False)`;
   * `resize(img, (h, w), BILINEAR, antialias=True)` = `interpolate(mode="bilinear", align_corners=False, antialias=True)`
     (NEAREST ignores antialias).
+The two helpers themselves (canvas bookkeeping, interpolation choice by channel count, resize -> rotate -> crop order) ARE
+pinned: oracle/validate_against_reference.py imports /root/reference/util/utils.py with these restated primitives injected
+as `torchvision.transforms.functional.rotate / resize` and compares bit for bit (golden vector: tests/golden, `rotate_*`).
 The reference's own caller only ever passes degrees_rotate = 0 (validation_protosam.py:388), for which both helpers are the
 identity; that case is pinned by the golden vectors of the main path.
 """

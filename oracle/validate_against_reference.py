@@ -41,10 +41,18 @@ def install_shims():
     tv.models.segmentation = stub("torchvision.models.segmentation")
     tv.transforms = stub("torchvision.transforms")
     from PIL import Image  # torchvision's resize(to_pil_image(x), size) IS PIL's bilinear resize
-    tv.transforms.functional = stub("torchvision.transforms.functional",
-                                    resize=lambda im, size: im.resize((size[1], size[0]), Image.BILINEAR),
-                                    to_pil_image=Image.fromarray, rotate=None,
-                                    InterpolationMode=types.SimpleNamespace(BILINEAR=2, NEAREST=0))
+    from oracle import rotate as orot  # torchvision's TENSOR rotate / resize are absent: restated ones are injected
+    modes = types.SimpleNamespace(BILINEAR=2, NEAREST=0)
+
+    def tv_resize(im, size, interpolation=modes.BILINEAR, antialias=None):
+        if isinstance(im, torch.Tensor):
+            return orot.tv_resize(im, size, nearest=(interpolation == modes.NEAREST))
+        return im.resize((size[1], size[0]), Image.BILINEAR)
+
+    tv.transforms.functional = stub("torchvision.transforms.functional", resize=tv_resize,
+                                    to_pil_image=Image.fromarray,
+                                    rotate=lambda im, angle, expand=False: orot.tv_rotate(im, angle, expand=expand),
+                                    InterpolationMode=modes)
     tv.ops = stub("torchvision.ops")
     from oracle import amg as oamg  # torchvision.ops NMS is absent: the restated one is injected (oracle/amg.py header)
     tv.ops.boxes = stub("torchvision.ops.boxes", batched_nms=oamg.batched_nms, box_area=None)
@@ -362,6 +370,44 @@ def check_amg(gold):
     gold["amg_best_index"] = np.array([bi], dtype=np.int32)
 
 
+def check_rotate(gold):
+    """util/utils.py `rotate_tensor_no_crop` / `reverse_tensor` (the reference's own code: canvas bookkeeping, which
+    interpolation for which channel count, resize-then-rotate-then-crop order) against oracle/rotate.py. The torchvision
+    primitives underneath are the restated ones in both (torchvision is absent), so this pins the helpers, not `rotate` /
+    `resize` themselves."""
+    import matplotlib
+    matplotlib.use("Agg")
+    for name in ("tqdm", "tqdm.auto"):
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                m = types.ModuleType(name)
+                m.tqdm = lambda x, *a, **k: x
+                sys.modules[name] = m
+    from util import utils as rutils  # reference
+    from oracle import rotate as orot
+    print("rotation helpers (util/utils.py:40-83)")
+    g = torch.Generator().manual_seed(77)
+    for shape, deg in (((1, 3, 96, 96), 15), ((2, 3, 64, 80), -30), ((1, 1, 64, 64), 20), ((1, 3, 50, 50), 0)):
+        x = torch.randn(shape, generator=g)
+        ref, ref_sz = rutils.rotate_tensor_no_crop(x, deg)
+        got, got_sz = orot.rotate_tensor_no_crop(x, deg)
+        assert tuple(ref_sz) == tuple(got_sz), (ref_sz, got_sz)
+        close(got, ref, 0.0, f"rotate_tensor_no_crop {shape} by {deg}")
+        if deg != 0:
+            logits = torch.randn((shape[0], 2) + shape[2:], generator=g)
+            close(orot.reverse_tensor(logits, got_sz[0], got_sz[1], -deg),
+                  rutils.reverse_tensor(logits, ref_sz[0], ref_sz[1], -deg), 0.0, f"reverse_tensor {shape} by {-deg}")
+    # golden vector (reference helper outputs on a small case) for tests/test_oracle_golden.py
+    x = torch.randn((1, 3, 48, 48), generator=g)
+    lg = torch.randn((1, 2, 48, 48), generator=g)
+    r, (rh, rw) = rutils.rotate_tensor_no_crop(x, 15)
+    gold["rotate_in"], gold["rotate_logits"] = x.numpy(), lg.numpy()
+    gold["rotate_out"], gold["rotate_size"] = r.numpy(), np.array([rh, rw], dtype=np.int32)
+    gold["rotate_back"] = rutils.reverse_tensor(lg, rh, rw, -15).numpy()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--write-golden", action="store_true")
@@ -379,6 +425,7 @@ def main():
     check_sam_decoder(gold)
     check_glue(gold)
     check_amg(gold)
+    check_rotate(gold)
     if args.write_golden:
         os.makedirs(GOLD, exist_ok=True)
         path = os.path.join(GOLD, "reference_outputs.npz")

@@ -153,3 +153,14 @@ def test_dilation_restatement_matches_scipy():
     assert decode_point_key(key, 1024) == (5, 7, 0.96875)
     assert decode_point_key(key - (1 << 64), 1024) == (5, 7, 0.96875)      # the int64 view of the same key
     assert decode_point_key(0, 1024) is None
+
+
+def test_rotation_helpers(gold):
+    """`rotate_tensor_no_crop` / `reverse_tensor` outputs recorded from the reference's util/utils.py (with the restated
+    torchvision tensor ops underneath - torchvision itself is absent, see oracle/rotate.py)."""
+    from oracle import rotate as orot
+    x, lg = torch.from_numpy(gold["rotate_in"]), torch.from_numpy(gold["rotate_logits"])
+    r, (rh, rw) = orot.rotate_tensor_no_crop(x, 15)
+    assert [rh, rw] == gold["rotate_size"].tolist()
+    _close(r, gold["rotate_out"], 1e-6)
+    _close(orot.reverse_tensor(lg, rh, rw, -15), gold["rotate_back"], 1e-6)
