@@ -1818,6 +1818,182 @@ static void launch8kp(const GemmArgs& p, hipStream_t s) {
   hipLaunchKernelGGL((gemm8kp_f16_kernel<EPI>), dim3(total < 256 ? total : 256), dim3(512), LDS, s, q, total);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Tile 13: FOUR waves (one per SIMD), 128x128 wave tiles, same 256x256x64 macro tile, DMA ring and persistent walk as tile
+// 11. Why: tools/micro/mfma_shadow_bench.hip - one wave per SIMD, back-to-back 32x32x16 MFMAs with this kernel's load mix
+// in their shadows (2 ds_read_b128 + 1 LDS-DMA per 4 MFMAs, two fragment sets alternating without copies) runs 35.3
+// cycles per MFMA = 2260 cycles per K-tile, against 2970 measured for the 8-wave kernels: a 128x128 wave tile needs 32
+// fragment reads per 64 MFMAs instead of 48, and a single in-order stream has no barrier-coupled intervals.
+// Schedule per K-tile kt (four k16 sub-steps of 16 MFMAs; fragment sets alternate, so the loop has no register rotation):
+//   S0: MFMA set 0 | read (kt, s1) -> set 1 | DMA pieces 8..15 of K-tile kt+1
+//   S1: MFMA set 1 | read (kt, s2) -> set 0
+//   S2: MFMA set 0 | read (kt, s3) -> set 1 ; lgkmcnt(0) ; vmcnt(0) ; ONE barrier
+//   S3: MFMA set 1 | read (kt+1, s0) -> set 0 | DMA pieces 0..7 of K-tile kt+2 (into the buffer the barrier just freed)
+// so a DMA piece is waited for 2 to 4 sub-steps (1100-2300 cycles) after it was issued.
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void gemm4p_f16_kernel(GemmArgs p, int total) {
+  extern __shared__ __attribute__((aligned(16))) half_t ring[];  // [buf 2][A0 A1 B0 B1][128][64] + 4 x 8 KiB slabs
+  constexpr int HT = 128 * 64;
+  const int ntn = p.N / 256;
+  const int ntm = (p.M + 255) / 256;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = wv >> 1, wc = wv & 1;
+  const int lr = lane & 31, lg = lane >> 5;
+  half_t* slab = ring + 8 * HT + wv * 4096;
+  const int nk = p.K / 64;
+
+  int idx = blockIdx.x, tm = 0, tn = 0;
+  while (idx < total && !tile_map(idx, ntm, ntn, p.map_mode, tm, tn)) idx += gridDim.x;
+  if (idx >= total) return;
+
+  // DMA piece (which, j): rows j*32 + t/8 of half-tile `which` (8 lanes per 128-byte row), LDS slot t%8 <- source chunk
+  unsigned aoff[2][4], boff[2][4];
+  auto offsets = [&](int m0, int n0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = j * 32 + (t >> 3);
+      const int chunk = (t & 7) ^ ((row >> 1) & 7);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int am = m0 + h * 128 + row;
+        am = am < p.M ? am : p.M - 1;
+        aoff[h][j] = (unsigned)am * (unsigned)p.lda + chunk * 8;
+        boff[h][j] = (unsigned)(n0 + h * 128 + row) * (unsigned)p.ldw + chunk * 8;
+      }
+    }
+  };
+  auto piece = [&](int q, int kt) {   // q = 0..15: which = q >> 2 (A0 A1 B0 B1), j = q & 3
+    const int which = q >> 2, j = q & 3;
+    half_t* dst = ring + ((kt & 1) * 4 + which) * HT + (j * 32 + wv * 8) * 64;
+    const half_t* g = which < 2 ? p.A + (aoff[which][j] + (unsigned)kt * 64u) : p.W + (boff[which - 2][j] + (unsigned)kt * 64u);
+    if (!(kt > 1 && (p.dbg & 1))) glds16(g, dst);
+  };
+
+  offsets(tm * 256, tn * 256);
+#pragma unroll
+  for (int q = 0; q < 16; ++q) piece(q, 0);
+  if (nk > 1) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) piece(q, 1);
+  }
+
+  half8_t fa[2][4], fb[2][4];   // [set][row block / column block]
+  const int arow = lr, brow = lr;
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define RDA(set, bufp, s, r) \
+  fa[set][r] = *reinterpret_cast<const half8_t*>(&(bufp)[wr * HT + lds_off64(arow + (r) * 32, (s) * 2 + lg)])
+#define RDB(set, bufp, s, r) \
+  fb[set][r] = *reinterpret_cast<const half8_t*>(&(bufp)[(2 + wc) * HT + lds_off64(brow + (r) * 32, (s) * 2 + lg)])
+#define MF(set, rb, cb) \
+  acc[(cb) >> 1][(rb) >> 1][(rb) & 1][(cb) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[set][cb], fa[set][rb], acc[(cb) >> 1][(rb) >> 1][(rb) & 1][(cb) & 1], 0, 0, 0)
+// one k16 sub-step: 16 MFMAs on fragment set `set`; X0..X7 go behind MFMAs 0..7, Y0..Y7 behind MFMAs 8..15
+#define SUBSTEP(set, X0, X1, X2, X3, X4, X5, X6, X7, Y0, Y1, Y2, Y3, Y4, Y5, Y6, Y7)                                  \
+  MF(set, 0, 0); X0; SB(); MF(set, 0, 1); X1; SB(); MF(set, 0, 2); X2; SB(); MF(set, 0, 3); X3; SB();                 \
+  MF(set, 1, 0); X4; SB(); MF(set, 1, 1); X5; SB(); MF(set, 1, 2); X6; SB(); MF(set, 1, 3); X7; SB();                 \
+  MF(set, 2, 0); Y0; SB(); MF(set, 2, 1); Y1; SB(); MF(set, 2, 2); Y2; SB(); MF(set, 2, 3); Y3; SB();                 \
+  MF(set, 3, 0); Y4; SB(); MF(set, 3, 1); Y5; SB(); MF(set, 3, 2); Y6; SB(); MF(set, 3, 3); Y7; SB();
+
+  bool first = true;
+  unsigned long long tcyc = 0, twall = 0, tks = 0;
+  for (;;) {
+    const int m0 = tm * 256, n0 = tn * 256;
+    f32x16 acc[2][2][2][2];  // [column half][a][i][b]: rows (2a+i)*32, columns (2*half+b)*32 of the 128x128 wave tile
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][a][i][b][r] = 0.f;
+
+    // K-tile 0 landed (the 8 pieces of K-tile 1 may fly); later tiles: the previous tile's stores are in the count
+    if (first) { if (nk > 1) wait_vmcnt<16>(); else wait_vmcnt<0>(); } else { wait_vmcnt<0>(); }
+    first = false;
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    RDA(0, ring, 0, 0); RDA(0, ring, 0, 1); RDA(0, ring, 0, 2); RDA(0, ring, 0, 3);
+    RDB(0, ring, 0, 0); RDB(0, ring, 0, 1); RDB(0, ring, 0, 2); RDB(0, ring, 0, 3);
+    SB();
+
+    unsigned long long c0 = 0, w0 = 0;
+    if (p.trace) { c0 = __builtin_amdgcn_s_memtime(); w0 = wall_clock64(); }
+    for (int kt = 0; kt < nk; ++kt) {
+      const half_t* buf = ring + (kt & 1) * 4 * HT;
+      const half_t* nbuf = ring + ((kt + 1) & 1) * 4 * HT;
+      const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+      SUBSTEP(0, RDA(1, buf, 1, 0), RDA(1, buf, 1, 1), RDA(1, buf, 1, 2), RDA(1, buf, 1, 3), RDB(1, buf, 1, 0), RDB(1, buf, 1, 1), RDB(1, buf, 1, 2), RDB(1, buf, 1, 3),
+ , , , , , , , )
+      SUBSTEP(1, RDA(0, buf, 2, 0), RDA(0, buf, 2, 1), RDA(0, buf, 2, 2), RDA(0, buf, 2, 3), RDB(0, buf, 2, 0), RDB(0, buf, 2, 1), RDB(0, buf, 2, 2), RDB(0, buf, 2, 3), , , , , , , , )
+      SUBSTEP(0, RDA(1, buf, 3, 0), RDA(1, buf, 3, 1), RDA(1, buf, 3, 2), RDA(1, buf, 3, 3), RDB(1, buf, 3, 0), RDB(1, buf, 3, 1), RDB(1, buf, 3, 2), RDB(1, buf, 3, 3), , , , , , , , )
+      // every wave is done reading this K-tile's buffer and has its pieces of the next one: one barrier per K-tile
+      if (!(p.dbg & 2)) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+      asm volatile("" ::: "memory");
+      // (after the last K-tile these reads fetch stale ring contents that nobody uses: no second copy of the MFMA stream)
+      SUBSTEP(1, RDA(0, nbuf, 0, 0); if (more2) piece(0, kt + 2), RDA(0, nbuf, 0, 1); if (more2) piece(1, kt + 2), RDA(0, nbuf, 0, 2); if (more2) piece(2, kt + 2), RDA(0, nbuf, 0, 3); if (more2) piece(3, kt + 2), RDB(0, nbuf, 0, 0); if (more2) piece(4, kt + 2), RDB(0, nbuf, 0, 1); if (more2) piece(5, kt + 2), RDB(0, nbuf, 0, 2); if (more2) piece(6, kt + 2), RDB(0, nbuf, 0, 3); if (more2) piece(7, kt + 2),
+                 if (more2) piece(8, kt + 2), if (more2) piece(9, kt + 2), if (more2) piece(10, kt + 2), if (more2) piece(11, kt + 2), if (more2) piece(12, kt + 2), if (more2) piece(13, kt + 2), if (more2) piece(14, kt + 2), if (more2) piece(15, kt + 2))
+    }
+
+    if (p.trace) { tcyc += __builtin_amdgcn_s_memtime() - c0; twall += wall_clock64() - w0; tks += nk; }
+    // next tile of this workgroup: request its first K-tile and half of the second now (the ring is idle)
+    int nidx = idx + gridDim.x, ntm_ = 0, ntn_ = 0;
+    while (nidx < total && !tile_map(nidx, ntm, ntn, p.map_mode, ntm_, ntn_)) nidx += gridDim.x;
+    const bool have = nidx < total;
+    if (have) {
+      offsets(ntm_ * 256, ntn_ * 256);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) piece(q, 0);
+      if (nk > 1) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) piece(q, 1);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    persist_epilogue<EPI>(acc[0], slab, m0 + wr * 128, n0 + wc * 128, lane, p);
+    persist_epilogue<EPI>(acc[1], slab, m0 + wr * 128, n0 + wc * 128 + 64, lane, p);
+    if (!have) break;
+    idx = nidx; tm = ntm_; tn = ntn_;
+  }
+  if (p.trace && t == 0) { p.trace[blockIdx.x * 4 + 0] = tcyc; p.trace[blockIdx.x * 4 + 1] = twall; p.trace[blockIdx.x * 4 + 2] = tks; }
+#undef SB
+#undef RDA
+#undef RDB
+#undef MF
+#undef SUBSTEP
+}
+
+template <int EPI>
+static void launch4p(const GemmArgs& p, hipStream_t s) {
+  constexpr int LDS = 2 * 4 * 128 * 64 * 2 + 4 * 8192;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm4p_f16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr = true;
+  }
+  const int ntm = (p.M + 255) / 256, ntn = p.N / 256;
+  GemmArgs q = p;
+  q.map_mode = pick_map_mode(ntm, ntn);
+  const int total = tile_map_grid(ntm, ntn, q.map_mode);
+  static const char* tr = getenv("PSAM_GEMM_TRACE");
+  if (tr) { (void)hipMalloc((void**)&q.trace, 256 * 4 * sizeof(unsigned long long)); (void)hipMemsetAsync(q.trace, 0, 256 * 32, s); }
+  hipLaunchKernelGGL((gemm4p_f16_kernel<EPI>), dim3(total < 256 ? total : 256), dim3(256), LDS, s, q, total);
+  if (tr) {   // debugging aid: cycles and wall time inside the k-loops (s_memtime / s_memrealtime at 100 MHz)
+    std::vector<unsigned long long> h(256 * 4);
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h.data(), q.trace, h.size() * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(q.trace);
+    double c = 0, w = 0, n = 0;
+    for (int b = 0; b < 256; ++b) { c += (double)h[b * 4]; w += (double)h[b * 4 + 1]; n += (double)h[b * 4 + 2]; }
+    if (n > 0) fprintf(stderr, "tile13 k-loop: %.0f cycles, %.3f us per K-tile -> %.3f GHz\n", c / n, w / n * 0.01, c / (w * 10.0));
+  }
+}
+
 template <int EPI>
 static void launch_ws(const GemmArgs& p, hipStream_t s) {
   constexpr int LDS = 4 * (384 + 128) * 32 * 2;
@@ -1846,7 +2022,8 @@ static void launch256(const GemmArgs& p, hipStream_t s) {
 
 // tile choice: 0 = auto, 1 = 128x128x64 double buffer, 2 = 256x128 / 3 = 256x256 staggered ring, 5 = 256x256 plain ring,
 // 6 = wave-specialised 384x128, 7 = 256x256x64 8-phase, 8 = 7 with one barrier per phase, 9 = four waves with 128x128
-// wave tiles and register staging (experimental), 10 = 8-phase with K-split phases (the default large tile)
+// wave tiles and register staging (experimental), 10 = 8-phase with K-split phases, 11 = its persistent form (the default
+// large tile), 13 = four waves / 128x128 wave tiles / LDS-DMA / persistent (experimental, same speed as 11)
 // (PSAM_GEMM_TILE env var or psam_gemm_set_tile)
 static int g_tile_override = -1;
 extern "C" int psam_gemm_set_tile(int t) {
@@ -1914,10 +2091,10 @@ static int gemm_dispatch(const void* A, const void* W, const float* bias, void* 
   dim3 grid(tile_map_grid(ntm, ntn, p.map_mode)), block(256);
   hipStream_t s = (hipStream_t)stream;
   int tsel = epilogue == EPI_RELU_F16 ? 1 : pick_tile(M, N, K, epilogue);
-  if (head_hd && tsel != 1 && tsel != 7 && tsel != 8 && tsel != 10 && tsel != 11) tsel = 1;   // the head-major store lives in the staged epilogue  // the ReLU epilogue lives in the 128x128 kernel
+  if (head_hd && tsel != 1 && tsel != 7 && tsel != 8 && tsel != 10 && tsel != 11 && tsel != 13) tsel = 1;   // the head-major store lives in the staged epilogue  // the ReLU epilogue lives in the 128x128 kernel
   // the slab epilogues store fp16 rows with 16-byte instructions when the layout allows (tiles 7 / 8 / 10 require it)
   p.wide16 = (ldo % 8) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (!head_hd || head_hd % 8 == 0);
-  if ((tsel == 7 || tsel == 8 || tsel == 10 || tsel == 11) && epilogue != EPI_F32 && !p.wide16) tsel = 1;
+  if ((tsel == 7 || tsel == 8 || tsel == 10 || tsel == 11 || tsel == 13) && epilogue != EPI_F32 && !p.wide16) tsel = 1;
   if ((tsel == 3 || tsel == 5) && N % 256 == 0) {
     if (tsel == 3) {
       if (epilogue == EPI_F16) launch256<EPI_F16, 256, 1>(p, s);
@@ -1930,7 +2107,13 @@ static int gemm_dispatch(const void* A, const void* W, const float* bias, void* 
     }
     return psam_launch_status();
   }
-  if (tsel == 11 && N % 256 == 0 && epilogue != EPI_F32 && !p.wide16) tsel = 10;
+  if ((tsel == 11 || tsel == 13) && N % 256 == 0 && epilogue != EPI_F32 && !p.wide16) tsel = 10;
+  if (tsel == 13 && N % 256 == 0) {
+    if (epilogue == EPI_F16) launch4p<EPI_F16>(p, s);
+    else if (epilogue == EPI_GELU_F16) launch4p<EPI_GELU_F16>(p, s);
+    else launch4p<EPI_F32>(p, s);
+    return psam_launch_status();
+  }
   if (tsel == 11 && N % 256 == 0) {
     if (epilogue == EPI_F16) launch8kp<EPI_F16>(p, s);
     else if (epilogue == EPI_GELU_F16) launch8kp<EPI_GELU_F16>(p, s);
