@@ -123,9 +123,14 @@ int psam_small_linear(const float* x, const float* x2, const float* W, const flo
 /* softmax(q k^T / sqrt(hd)) v with <= 16 keys (token self-attention; image->token attention). transformer.py:151-182 */
 int psam_small_attention(const void* q, const float* k, const float* v, void* out, int B, int Tq, int Tk, int NH, int hd,
                          int ldq, int ldk, int ldv, int ldo, int q_f16, void* stream);
-/* token -> image cross attention over Nk <= 4096 keys (K, V half).  transformer.py:163-167, 98-103 */
+/* token -> image cross attention over Nk <= 4096 keys; K, V fp32 (kv_f32 = 1) or half.  transformer.py:163-167, 98-103 */
 int psam_t2i_attention(const float* q, const void* K, const void* V, float* out, int B, int T, int Nk, int NH,
-                       void* stream);
+                       int kv_f32, void* stream);
+/* out = (a [+ a2[m % a2_mod]]) w^T + bias [+ resid], all fp32 on the exact-fp32 MFMA: the decoder's projections of the
+ * 4096 image tokens (keys [+ key_pe]) and ConvTranspose2d #1 as a GEMM. K % 32 == 0, N % 64 == 0, lds % 4 == 0.
+ * transformer.py:163-167,176-180,98-103,218-240 (k_proj / v_proj / q_proj / out_proj); mask_decoder.py:54,137 */
+int psam_gemm_f32(const float* a, const float* a2, int a2_mod, const float* w, const float* bias, const float* resid,
+                  float* out, int M, int N, int K, int lda, int ldw, int ldo, void* stream);
 /* y = [LayerNorm](x[src row] + add_vec); emits fp32 y, half y, half (y + pe[row % pe_mod]). With in_mod > 0 the input
  * is one [in_mod,256] embedding per image and prompt row/in_mod reads image img_of_prompt[prompt] (null: image 0).
  * mask_decoder.py:126-127; transformer.py:164,178,180 */

@@ -39,7 +39,8 @@ SIGNATURES = {
     "psam_cast_f16": [c_void_p, c_void_p, c_longlong, c_void_p],
     "psam_small_linear": [c_void_p] * 6 + [c_int] * 4 + [c_longlong] * 4 + [c_int] * 3 + [c_void_p],
     "psam_small_attention": [c_void_p] * 4 + [c_int] * 10 + [c_void_p],
-    "psam_t2i_attention": [c_void_p] * 4 + [c_int] * 4 + [c_void_p],
+    "psam_t2i_attention": [c_void_p] * 4 + [c_int] * 5 + [c_void_p],
+    "psam_gemm_f32": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p],
     "psam_ln_pe": [c_void_p] * 8 + [c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p],
     "psam_dense_pe": [c_void_p, c_int, c_int, c_void_p, c_void_p],
     "psam_prompt_tokens": [c_void_p] * 5 + [c_int, c_int, c_float, c_void_p, c_void_p],

@@ -113,12 +113,14 @@ class TVDeeplabRes101Encoder(nn.Module):
         self._cache = None
 
     def _apply(self, fn, *a, **k):
+        self._weights_epoch = getattr(self, "_weights_epoch", 0) + 1
         self._cache = None
         return super()._apply(fn, *a, **k)
 
-    def load_state_dict(self, *a, **k):
+    def _load_from_state_dict(self, *a, **k):   # also reached by a parent's recursive load
+        self._weights_epoch = getattr(self, "_weights_epoch", 0) + 1
         self._cache = None
-        return super().load_state_dict(*a, **k)
+        return super()._load_from_state_dict(*a, **k)
 
     def _packed(self):
         if self._cache is not None:

@@ -132,6 +132,127 @@ extern "C" int psam_small_linear(const float* x, const float* x2, const float* W
 }
 
 // =====================================================================================================
+// gemm_f32: out[m,n] = sum_k (a[m,k] [+ a2[m % a2_mod, k]]) * w[n,k] + bias[n] [+ resid[m,n]], everything fp32, on the
+// exact-fp32 matrix instruction (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain, 157 TFLOP/s peak).
+// The image side of the two-way decoder (transformer.py:163-167,176-180,98-103: k/v/q projections of the 4096 image
+// tokens, the i2t out-projection; mask_decoder.py:137 ConvTranspose #1 as a GEMM) runs here so that sigmoid(low_res_masks)
+// stays inside the 1e-3 parity budget: with fp16 operands (the encoder's GEMM) this stage alone measured 0.8e-3..1.2e-3.
+// 3.2 GFLOP per prompt set = ~25 us at this rate; the encoder's 6 TFLOP per slice stay on the fp16 MFMA.
+// Tile BM x BN (4 waves as 2 x 2, wave tile BM/2 x BN/2 in 32x32 blocks), K slabs of 32 staged through LDS ([row][33]
+// floats: the one-dword fragment reads of a 32-lane half hit 32 different banks), next slab prefetched into registers
+// under the MFMAs. W is the MFMA's A operand, so a lane ends up with 4 consecutive output columns of one row (16-byte stores).
+#define GF_LD 33
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ a, const float* __restrict__ a2, int a2_mod,
+                                                       const float* __restrict__ w, const float* __restrict__ bias,
+                                                       const float* __restrict__ resid, float* __restrict__ out, int M,
+                                                       int N, int K, int lda, int ldw, int ldo) {
+  constexpr int MI = BM / 64, NI = BN / 64;       // 32x32 blocks per wave in m / n
+  constexpr int AV = BM * 8 / 256, WV = BN * 8 / 256;   // float4 loads per thread and slab
+  __shared__ float As[BM * GF_LD], Ws[BN * GF_LD];
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, lr = lane & 31, lk = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float4 av[AV], wv[WV];
+  auto load_slab = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < AV; ++i) {
+      const int idx = t + 256 * i, row = idx >> 3, c4 = (idx & 7) * 4;
+      const int m = m0 + row;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < M) {
+        v = *reinterpret_cast<const float4*>(a + (size_t)m * lda + k0 + c4);
+        if (a2) {
+          const float4 p = *reinterpret_cast<const float4*>(a2 + (size_t)(m % a2_mod) * lda + k0 + c4);
+          v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
+      }
+      av[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < WV; ++i) {
+      const int idx = t + 256 * i, row = idx >> 3, c4 = (idx & 7) * 4;
+      wv[i] = *reinterpret_cast<const float4*>(w + (size_t)(n0 + row) * ldw + k0 + c4);   // N % BN == 0
+    }
+  };
+  load_slab(0);
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    __syncthreads();   // every wave is done reading the previous slab
+#pragma unroll
+    for (int i = 0; i < AV; ++i) {
+      const int idx = t + 256 * i, row = idx >> 3, c4 = (idx & 7) * 4;
+      float* d = As + row * GF_LD + c4;
+      d[0] = av[i].x; d[1] = av[i].y; d[2] = av[i].z; d[3] = av[i].w;
+    }
+#pragma unroll
+    for (int i = 0; i < WV; ++i) {
+      const int idx = t + 256 * i, row = idx >> 3, c4 = (idx & 7) * 4;
+      float* d = Ws + row * GF_LD + c4;
+      d[0] = wv[i].x; d[1] = wv[i].y; d[2] = wv[i].z; d[3] = wv[i].w;
+    }
+    __syncthreads();
+    if (k0 + 32 < K) load_slab(k0 + 32);
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) {
+      float xf[MI], wf[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) xf[i] = As[(wm * (BM / 2) + i * 32 + lr) * GF_LD + 2 * s2 + lk];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) wf[j] = Ws[(wn * (BN / 2) + j * 32 + lr) * GF_LD + 2 * s2 + lk];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[j], xf[i], acc[i][j], 0, 0, 0);
+    }
+  }
+  // acc[i][j][r]: m = m0 + wm*BM/2 + i*32 + lr ; n = n0 + wn*BN/2 + j*32 + (r&3) + 8*(r>>2) + 4*lk
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = m0 + wm * (BM / 2) + i * 32 + lr;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + wn * (BN / 2) + j * 32 + 8 * q + 4 * lk;
+        float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+        if (bias) {
+          const float4 b = *reinterpret_cast<const float4*>(bias + n);
+          v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        }
+        if (resid) {
+          const float4 r = *reinterpret_cast<const float4*>(resid + (size_t)m * ldo + n);
+          v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        *reinterpret_cast<float4*>(out + (size_t)m * ldo + n) = v;
+      }
+  }
+}
+
+extern "C" int psam_gemm_f32(const float* a, const float* a2, int a2_mod, const float* w, const float* bias,
+                             const float* resid, float* out, int M, int N, int K, int lda, int ldw, int ldo, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || (K % 32) || (N % 64) || (lda % 4) || (ldw % 4) || (ldo % 4) || (a2 && a2_mod <= 0))
+    return PSAM_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  // large tiles once they fill the 256 CUs; 64x64 tiles for the per-slice calls (M = 4096: 32 x 1 large tiles otherwise)
+  const long long big = (long long)((M + 127) / 128) * (N / 128);
+  if ((N % 128) == 0 && big >= 256)
+    hipLaunchKernelGGL((gemm_f32_kernel<128, 128>), dim3((M + 127) / 128, N / 128), dim3(256), 0, s, a, a2, a2_mod, w, bias,
+                       resid, out, M, N, K, lda, ldw, ldo);
+  else
+    hipLaunchKernelGGL((gemm_f32_kernel<64, 64>), dim3((M + 63) / 64, N / 64), dim3(256), 0, s, a, a2, a2_mod, w, bias,
+                       resid, out, M, N, K, lda, ldw, ldo);
+  return psam_launch_status();
+}
+
+// =====================================================================================================
 // small_attention: softmax(q k^T / sqrt(hd)) v with <= 16 keys; one thread per (batch, query row, head).
 // Used for the token self-attention (Tq = Tk = T, hd 32) and for image->token cross attention
 // (Tq = 4096 image tokens, q fp16 from the GEMM, hd 16; transformer.py:176-180).
@@ -208,8 +329,27 @@ extern "C" int psam_small_attention(const void* q, const float* k, const float* 
 // t2i_attention: token -> image cross attention (transformer.py:163-167, 98-103). q fp32 [B,T,NH*16];
 // K, V fp16 [B*Nk, NH*16] (outputs of the k_proj / v_proj GEMMs); out fp32 [B,T,NH*16].
 // One block per (t, head, b); 256 threads x up to 16 keys each; two passes over register-resident scores.
-__global__ __launch_bounds__(256) void t2i_attention_kernel(const float* __restrict__ q, const half_t* __restrict__ K,
-                                                            const half_t* __restrict__ V, float* __restrict__ out, int T,
+template <typename KT>
+__device__ __forceinline__ void load16(const KT* __restrict__ p, float* v);
+template <>
+__device__ __forceinline__ void load16<half_t>(const half_t* __restrict__ p, float* v) {
+  const half8_t* hp = reinterpret_cast<const half8_t*>(p);
+  const half8_t k0 = hp[0], k1 = hp[1];
+#pragma unroll
+  for (int d = 0; d < 8; ++d) { v[d] = (float)k0[d]; v[8 + d] = (float)k1[d]; }
+}
+template <>
+__device__ __forceinline__ void load16<float>(const float* __restrict__ p, float* v) {
+  const float4* fp = reinterpret_cast<const float4*>(p);
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const float4 x = fp[d];
+    v[4 * d] = x.x; v[4 * d + 1] = x.y; v[4 * d + 2] = x.z; v[4 * d + 3] = x.w;
+  }
+}
+template <typename KT>
+__global__ __launch_bounds__(256) void t2i_attention_kernel(const float* __restrict__ q, const KT* __restrict__ K,
+                                                            const KT* __restrict__ V, float* __restrict__ out, int T,
                                                             int Nk, int NH) {
   constexpr int HD = 16;
   const int t = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
@@ -229,11 +369,11 @@ __global__ __launch_bounds__(256) void t2i_attention_kernel(const float* __restr
     const int key = tid + 256 * j;
     s[j] = -INFINITY;
     if (key < Nk) {
-      const half8_t* kp = reinterpret_cast<const half8_t*>(K + ((size_t)b * Nk + key) * C + h * HD);
-      half8_t k0 = kp[0], k1 = kp[1];
+      float kv[HD];
+      load16<KT>(K + ((size_t)b * Nk + key) * C + h * HD, kv);
       float a = 0.f;
 #pragma unroll
-      for (int d = 0; d < 8; ++d) a += qv[d] * (float)k0[d] + qv[8 + d] * (float)k1[d];
+      for (int d = 0; d < HD; ++d) a += qv[d] * kv[d];
       s[j] = a * inv;
       mx = fmaxf(mx, s[j]);
     }
@@ -253,13 +393,10 @@ __global__ __launch_bounds__(256) void t2i_attention_kernel(const float* __restr
     if (key < Nk) {
       const float p = expf(s[j] - M);
       l += p;
-      const half8_t* vp = reinterpret_cast<const half8_t*>(V + ((size_t)b * Nk + key) * C + h * HD);
-      half8_t v0 = vp[0], v1 = vp[1];
+      float vv[HD];
+      load16<KT>(V + ((size_t)b * Nk + key) * C + h * HD, vv);
 #pragma unroll
-      for (int d = 0; d < 8; ++d) {
-        o[d] += p * (float)v0[d];
-        o[8 + d] += p * (float)v1[d];
-      }
+      for (int d = 0; d < HD; ++d) o[d] += p * vv[d];
     }
   }
   l = wave_sum(l);
@@ -279,11 +416,16 @@ __global__ __launch_bounds__(256) void t2i_attention_kernel(const float* __restr
   }
 }
 
+// kv_f32 = 1: K / V are fp32 (outputs of psam_gemm_f32, the default decoder path); 0: fp16 (outputs of psam_gemm_f16).
 extern "C" int psam_t2i_attention(const float* q, const void* K, const void* V, float* out, int B, int T, int Nk, int NH,
-                                  void* stream) {
+                                  int kv_f32, void* stream) {
   if (B <= 0 || T <= 0 || Nk <= 0 || Nk > 4096) return PSAM_ERR_ARG;
-  hipLaunchKernelGGL(t2i_attention_kernel, dim3(T, NH, B), dim3(256), 0, (hipStream_t)stream, q, (const half_t*)K,
-                     (const half_t*)V, out, T, Nk, NH);
+  if (kv_f32)
+    hipLaunchKernelGGL(t2i_attention_kernel<float>, dim3(T, NH, B), dim3(256), 0, (hipStream_t)stream, q, (const float*)K,
+                       (const float*)V, out, T, Nk, NH);
+  else
+    hipLaunchKernelGGL(t2i_attention_kernel<half_t>, dim3(T, NH, B), dim3(256), 0, (hipStream_t)stream, q, (const half_t*)K,
+                       (const half_t*)V, out, T, Nk, NH);
   return psam_launch_status();
 }
 

@@ -99,15 +99,17 @@ class DinoVisionTransformer(nn.Module):
 
     # -- weight packing (fp16 GEMM operands); rebuilt whenever parameters change -----------------------------
     def _apply(self, fn, *a, **k):
+        self._weights_epoch = getattr(self, "_weights_epoch", 0) + 1
         self._packed = None
         self._pos_cache = {}
         self._ws = {}
         return super()._apply(fn, *a, **k)
 
-    def load_state_dict(self, *a, **k):
+    def _load_from_state_dict(self, *a, **k):   # also reached by a parent's recursive load (FewShotSeg.load_state_dict)
+        self._weights_epoch = getattr(self, "_weights_epoch", 0) + 1
         self._packed = None
         self._pos_cache = {}
-        return super().load_state_dict(*a, **k)
+        return super()._load_from_state_dict(*a, **k)
 
     def _pack(self):
         if self._packed is not None:

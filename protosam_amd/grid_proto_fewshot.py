@@ -95,6 +95,11 @@ class FewShotSeg(nn.Module):
         `<p>.weight = W + scale * up @ down` (scale = 1.0, inject_trainable_lora's default; util/lora.py:34-59,638-672)."""
         return super().load_state_dict(collapse_lora_state_dict(state_dict), strict=strict, **kw)
 
+    def _load_from_state_dict(self, *a, **k):
+        # the cached support banks were built with the previous encoder weights (keyed on the input tensors only)
+        self._sup_cache = []
+        return super()._load_from_state_dict(*a, **k)
+
     # ---- features ------------------------------------------------------------------------------------------------
     def _grid(self):
         """(S, g): encoder input side and the side of the feature map the classifier sees (>= 32, :96-98)."""
@@ -138,8 +143,9 @@ class FewShotSeg(nn.Module):
         (the reference caller re-uploads the support every slice, validation_protosam.py:374-385) is recognised by an
         on-device equality test instead of a re-encode."""
         if self.cache_support:
+            epoch = getattr(self.encoder, "_weights_epoch", 0)   # bumped whenever the encoder's weights are (re)loaded / moved
             for i, (k_supp, k_fg, k_bg, k_pool, k_ver, bank, tok) in enumerate(self._sup_cache):
-                if k_pool != pool_w or k_supp.shape != supp.shape or k_fg.shape != fg.shape:
+                if k_pool != (pool_w, epoch) or k_supp.shape != supp.shape or k_fg.shape != fg.shape:
                     continue
                 same_obj = (k_supp is supp and k_fg is fg and k_ver == (supp._version, fg._version))
                 if same_obj or (k_supp is not supp and torch.equal(k_supp, supp) and torch.equal(k_fg, fg)
@@ -157,7 +163,8 @@ class FewShotSeg(nn.Module):
             bg2 = bg.reshape(bg.shape[-2], bg.shape[-1]).float().contiguous()
         bank = self.cls_unit.build_bank(tok, C, g, g, fg2, pool_w, FG_THRESH, force_mode=-1, bank=None, bg_mask=bg2)
         if self.cache_support:
-            self._sup_cache.insert(0, (supp, fg, bg, pool_w, (supp._version, fg._version), bank, tok))
+            self._sup_cache.insert(0, (supp, fg, bg, (pool_w, getattr(self.encoder, "_weights_epoch", 0)),
+                                       (supp._version, fg._version), bank, tok))
             del self._sup_cache[4:]
         return bank, tok
 

@@ -422,9 +422,29 @@ def small_attention(q, k, v, out, B, Tq, Tk, NH, hd, ldq, ldk, ldv, ldo):
 
 
 def t2i_attention(q, K, V, out, B, T, Nk, NH):
-    _req(q, torch.float32, "q"); _req(K, torch.float16, "K"); _req(V, torch.float16, "V"); _req(out, torch.float32, "out")
-    st = _lib.lib().psam_t2i_attention(_ptr(q), _ptr(K), _ptr(V), _ptr(out), B, T, Nk, NH, _stream())
+    _req(q, torch.float32, "q"); _req(K, K.dtype, "K"); _req(V, K.dtype, "V"); _req(out, torch.float32, "out")
+    assert K.dtype in (torch.float16, torch.float32)
+    st = _lib.lib().psam_t2i_attention(_ptr(q), _ptr(K), _ptr(V), _ptr(out), B, T, Nk, NH,
+                                      1 if K.dtype == torch.float32 else 0, _stream())
     _lib.check(st, "psam_t2i_attention")
+    return out
+
+
+def gemm_f32(a, w, bias=None, out=None, resid=None, a2=None, a2_mod=0):
+    """out[M,N] = (a[M,K] [+ a2[m % a2_mod]]) @ w[N,K]^T + bias [+ resid]; everything fp32 (exact-fp32 MFMA)."""
+    _req(a, torch.float32, "a"); _req(w, torch.float32, "w"); _req(bias, torch.float32, "bias")
+    _req(resid, torch.float32, "resid"); _req(a2, torch.float32, "a2")
+    assert a.dim() == 2 and w.dim() == 2 and w.shape[1] == a.shape[1]
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    _req(out, torch.float32, "out")
+    assert out.shape == (M, N) and (resid is None or (resid.shape == (M, N) and resid.stride(0) == out.stride(0)))
+    assert a2 is None or (a2.stride(0) == a.stride(0) and a2_mod > 0)
+    st = _lib.lib().psam_gemm_f32(_ptr(a), _ptr(a2), a2_mod, _ptr(w), _ptr(bias), _ptr(resid), _ptr(out), M, N, K,
+                                 a.stride(0), w.stride(0), out.stride(0), _stream())
+    _lib.check(st, "psam_gemm_f32")
     return out
 
 

@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .protosam import MAX_COMPONENTS, ModelWrapper
+from .protosam import MAX_COMPONENTS, MAX_COMPONENTS_LARGE, ModelWrapper
 from .segment_anything import sam_model_registry
 
 
@@ -99,6 +99,12 @@ class ProtoMedSAM(nn.Module):
         feat_tok = sam.image_encoder.encode_patches(bufs["patches"], 1)[0]
         bufs["event"].synchronize()
         tab = cw.tab_host.numpy()
+        if int(tab[0]) > int(tab[1]):   # more components than the fast table holds (cca searches ALL of them, utils.py:496-541)
+            if getattr(self, "_ccl_big", None) is None:
+                self._ccl_big = ops.CclWorkspace(1024, 1024, MAX_COMPONENTS_LARGE, dev)
+            tab = ops.ccl(pred[0], p2[0, 1], self._ccl_big, fg_sum=bufs["fg_sum"]).tab.cpu().numpy()
+            if int(tab[0]) > int(tab[1]):
+                raise RuntimeError(f"{int(tab[0])} connected components exceed the table capacity {MAX_COMPONENTS_LARGE}")
         n = int(tab[1])
         self.last_stats = dict(n_components=int(tab[0]))
         if n == 0:                                                                         # :194-197

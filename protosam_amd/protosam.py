@@ -47,7 +47,9 @@ POINT_MODES = (CONF_MODE, CENTROID_MODE, BOTH_MODE)
 TYPE_ALPNET = "alpnet"
 TYPE_SAM = "sam"
 
-MAX_COMPONENTS = 256
+MAX_COMPONENTS = 256          # fast path: table rows per slice that travel D2H every step
+MAX_COMPONENTS_LARGE = 4096   # psam_ccl's limit; used for a slice that overflows the fast table
+DECODER_CHUNK = 256           # prompt sets per decoder call (workspace ~ 25 MB per prompt set)
 MAX_NEG_COMPONENTS = 64   # psam_neg_points launches one tile grid per component
 
 
@@ -326,6 +328,25 @@ class ProtoSAM(nn.Module):
             self._ccl = ops.CclWorkspace(1024, 1024, MAX_COMPONENTS, dev, slots=max(B, 1))
         return self._bufs[key]
 
+    def _ccl_overflow(self, b, bufs, output_p, pred, S):
+        """Slice `b` has more than MAX_COMPONENTS connected components: label it again with a MAX_COMPONENTS_LARGE table
+        (synchronous, rare) and refresh the per-slice side products that were derived from the truncated labelling."""
+        dev = pred.device
+        if getattr(self, "_ccl_big", None) is None:
+            self._ccl_big = ops.CclWorkspace(S, S, MAX_COMPONENTS_LARGE, dev, slots=1)
+        big = self._ccl_big
+        ops.ccl(pred[b], output_p[b, 1], big, fg_sum=bufs["fg_sum"][b:b + 1], slot=0)
+        if self.use_neg_points:
+            ops.neg_points(big, output_p[b, 0], big.tabs[0], MAX_NEG_COMPONENTS, keys=bufs["neg_keys"][b])
+            bufs["neg_keys_host"][b].copy_(bufs["neg_keys"][b])
+        if self._mask_only:
+            bufs["lab256"][b].copy_(big.labels.view(S, S)[::4, ::4])
+        tab = big.tabs[0].cpu().numpy()
+        if int(tab[0]) > int(tab[1]):
+            raise RuntimeError(f"{int(tab[0])} connected components in one coarse mask exceed the table capacity "
+                               f"{MAX_COMPONENTS_LARGE} (csrc/ccl.hip)")
+        return tab
+
     def _side_stream(self, dev):
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=dev)
@@ -433,6 +454,10 @@ class ProtoSAM(nn.Module):
         stats = []
         for b in range(B):
             tab = tabs[b]
+            if int(tab[0]) > int(tab[1]):
+                # more components than the fast table holds (cv2 + the reference's per-component loop have no limit,
+                # util/utils.py:474-494, ProtoSAM.py:505): redo this slice with the large table
+                tab = self._ccl_overflow(b, bufs, output_p, pred, S)
             n_found, n = int(tab[0]), int(tab[1])
             stats.append(dict(n_components=n_found, fg_pixels=int(tab[2]), n_prompts=0))
             if n == 0:                                                          # ProtoSAM.py:612-613
@@ -468,9 +493,15 @@ class ProtoSAM(nn.Module):
             dense = sam.prompt_encoder.embed_masks_tokens(prompt[:, None])               # [P, 4096, 256]
             src = (feat_tok[iop] + dense).contiguous()                                    # mask_decoder.py:126-127
             tokens = dpk["out_tok"].unsqueeze(0).expand(P, -1, -1).contiguous()
-            masks, iou, _ = sam.mask_decoder.predict_masks_tokens(
-                src, pe["pe_tok"], tokens, torch.zeros(256, dtype=torch.float32, device=dev),
-                img_of_prompt=torch.arange(P, dtype=torch.int32, device=dev))
+            masks = torch.empty((P, 4, 256, 256), dtype=torch.float32, device=dev)
+            iou = torch.empty((P, 4), dtype=torch.float32, device=dev)
+            zero_dense = torch.zeros(256, dtype=torch.float32, device=dev)
+            for c0 in range(0, P, DECODER_CHUNK):
+                c1 = min(c0 + DECODER_CHUNK, P)
+                sam.mask_decoder.predict_masks_tokens(
+                    src[c0:c1], pe["pe_tok"], tokens[c0:c1].contiguous(), zero_dense,
+                    img_of_prompt=torch.arange(c1 - c0, dtype=torch.int32, device=dev), masks_out=masks[c0:c1],
+                    iou_out=iou[c0:c1])
             best = iou[:, 1:].argmax(dim=1)                                               # score.argmax(), :494
             chosen = masks[torch.arange(P, device=dev), best + 1].unsqueeze(1).contiguous()   # [P,1,256,256]
             iou_host = iou[:, 1:].max(dim=1).values.cpu().numpy()
@@ -495,7 +526,7 @@ class ProtoSAM(nn.Module):
                 tokens = ops.prompt_tokens(torch.from_numpy(cg).to(dev, non_blocking=True),
                                            torch.from_numpy(lg).to(dev, non_blocking=True), pe["G"], pe["type_emb"],
                                            dpk["out_tok"], len(idx), Ns, float(S))
-                if len(groups) == 1:
+                if len(groups) == 1 and P <= DECODER_CHUNK:
                     masks, iou, _ = sam.mask_decoder.predict_masks_tokens(feat_tok, pe["pe_tok"], tokens, pe["no_mask"],
                                                                           img_of_prompt=iop_all)
                 else:
@@ -503,10 +534,14 @@ class ProtoSAM(nn.Module):
                         masks = torch.empty((P, 4, 256, 256), dtype=torch.float32, device=dev)
                         iou = torch.empty((P, 4), dtype=torch.float32, device=dev)
                     it = torch.tensor(idx, dtype=torch.int64, device=dev)
-                    m_g, i_g, _ = sam.mask_decoder.predict_masks_tokens(feat_tok, pe["pe_tok"], tokens, pe["no_mask"],
-                                                                        img_of_prompt=iop_all[it].contiguous())
-                    masks[it] = m_g
-                    iou[it] = i_g
+                    iop_g = iop_all[it].contiguous()
+                    for c0 in range(0, len(idx), DECODER_CHUNK):      # bounded decoder workspace however many components
+                        c1 = min(c0 + DECODER_CHUNK, len(idx))
+                        m_g, i_g, _ = sam.mask_decoder.predict_masks_tokens(
+                            feat_tok, pe["pe_tok"], tokens[c0:c1].contiguous(), pe["no_mask"],
+                            img_of_prompt=iop_g[c0:c1].contiguous())
+                        masks[it[c0:c1]] = m_g
+                        iou[it[c0:c1]] = i_g
             sel = 0 if self.use_cca else 1                                      # multimask_output = not use_cca; index 0
             iou_host = iou[:, sel].cpu().numpy()
             for (b, start, cnt) in spans:
@@ -538,6 +573,12 @@ class ProtoSAM(nn.Module):
                                      fg_sum=bufs["fg_sum"])
         cw = ops.ccl(pred[0], prob[0, 1], bufs["ccl"], fg_sum=bufs["fg_sum"])
         tab = cw.tab.cpu().numpy()
+        if int(tab[0]) > int(tab[1]):                            # more components than the fast table holds: see forward_batch
+            bufs["ccl_big"] = bufs.get("ccl_big") or ops.CclWorkspace(H, H, MAX_COMPONENTS_LARGE, dev, slots=1)
+            cw = ops.ccl(pred[0], prob[0, 1], bufs["ccl_big"], fg_sum=bufs["fg_sum"])
+            tab = cw.tab.cpu().numpy()
+            if int(tab[0]) > int(tab[1]):
+                raise RuntimeError(f"{int(tab[0])} connected components exceed the table capacity {MAX_COMPONENTS_LARGE}")
         n = int(tab[1])
         rows = tab[ops.CC_HDR:ops.CC_HDR + ops.CC_STRIDE * n].reshape(n, ops.CC_STRIDE)
         if not self.use_cca:

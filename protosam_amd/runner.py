@@ -85,6 +85,8 @@ def run_slices(model, vol, sup_imgs, sup_masks, zs, device, out=None, batch=1):
         for k, (pred, scores) in enumerate(res):
             if pred.shape[-1] == S:
                 out[i + k] = pred.to(torch.uint8)
+            else:   # empty coarse mask: the reference hands back the all-zero 1024x1024 arg-max map (ProtoSAM.py:612-613)
+                out[i + k].zero_()
             stats[i + k] = st[k].get("n_prompts", 0) if k < len(st) else 0
         i = j
     return out, stats

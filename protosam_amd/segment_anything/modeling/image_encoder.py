@@ -82,9 +82,11 @@ class ImageEncoderViT(nn.Module):
         self._packed, self._ws = None, {}
         return super()._apply(fn, *a, **k)
 
-    def load_state_dict(self, *a, **k):
+    def _load_from_state_dict(self, *a, **k):
+        # runs for this module on EVERY load, also a recursive one started at a parent (Sam / ProtoSAM.load_state_dict):
+        # nn.Module.load_state_dict never calls a child's load_state_dict
         self._packed = None
-        return super().load_state_dict(*a, **k)
+        return super()._load_from_state_dict(*a, **k)
 
     def _pack(self):
         if self._packed is not None:

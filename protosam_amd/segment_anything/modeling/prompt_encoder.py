@@ -42,9 +42,9 @@ class PromptEncoder(nn.Module):
         self._cache = None
         return super()._apply(fn, *a, **k)
 
-    def load_state_dict(self, *a, **k):
+    def _load_from_state_dict(self, *a, **k):   # also reached by a parent's recursive load
         self._cache = None
-        return super().load_state_dict(*a, **k)
+        return super()._load_from_state_dict(*a, **k)
 
     def _packed(self):
         if self._cache is None:

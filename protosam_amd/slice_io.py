@@ -16,6 +16,7 @@ specification (348-byte header, `dim`, `datatype`, `pixdim`, `vox_offset`, `scl_
 reader, geometry is reported in LPS (x and y flipped from NIfTI's RAS) and `scl_slope != 0` rescales the voxels.
 """
 import gzip
+import os
 import struct
 
 import numpy as np
@@ -61,8 +62,23 @@ def read_nifti(path, peel_info=False):
         raise ValueError(f"{path}: expected a 3-D volume, dim = {dim}")
     nx, ny, nz = dim[1:4]
     dt = np.dtype(_DTYPES[datatype]).newbyteorder(end)
-    off = int(vox_offset) if raw[344:348] == b"n+1\0" else 0
-    vox = np.frombuffer(raw, dtype=dt, count=nx * ny * nz, offset=off).reshape(nz, ny, nx)
+    if raw[344:348] == b"n+1\0":
+        data, off = raw, int(vox_offset)
+    else:   # "ni1": the two-file form, voxels live in the sibling .img (offset vox_offset there, normally 0)
+        img = None
+        for a, b in ((".hdr.gz", ".img.gz"), (".hdr", ".img")):
+            if str(path).endswith(a):
+                img = str(path)[:-len(a)] + b
+                break
+        if img is None or not os.path.exists(img):
+            raise ValueError(f"{path}: two-file NIfTI (magic 'ni1') without a readable .img beside it")
+        with _open(img, "rb") as f:
+            data = f.read()
+        off = int(vox_offset)
+    need = off + nx * ny * nz * dt.itemsize
+    if off < 0 or len(data) < need:
+        raise ValueError(f"{path}: voxel data truncated ({len(data)} bytes, header promises {need})")
+    vox = np.frombuffer(data, dtype=dt, count=nx * ny * nz, offset=off).reshape(nz, ny, nx)
     vox = vox.astype(dt.newbyteorder("="), copy=False)
     scaled = slope != 0.0 and not (slope == 1.0 and inter == 0.0)
     if scaled:
