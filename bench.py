@@ -2,7 +2,10 @@
 """Headline benchmark: query-slices/sec (512x512), end-to-end ProtoSAM inference (BASELINE.json).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+      N > 1 without a launcher: this process stays off the GPU and starts N fresh ranks itself
+      (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...),
+      relays rank 0's JSON line and exits with the ranks' status. Under a launcher (WORLD_SIZE in the
+      environment) it is one rank of that job.
 
 Workload (config 4 of BASELINE.json, the one the metric is quoted on; it fits one GPU because slices are independent):
 DINOv2 ViT-B/14 encoder + ALP prototype match + SAM ViT-H image encoder + prompt encoder + two-way mask decoder on
@@ -10,31 +13,33 @@ DINOv2 ViT-B/14 encoder + ALP prototype match + SAM ViT-H image encoder + prompt
 point_mode='both', use_cca=False). A "step" is one pass of `ProtoSAM.forward` over a batch of `--batch` query slices
 per rank, followed by the all-gather of the step's uint8 masks. Inputs are resident in HBM when the timed region starts.
 Support features / prototype banks are cached per z-part (values identical to the reference's per-slice re-encode,
-SURVEY Q18); `--no-support-cache` measures the reference's behaviour.
+SURVEY Q18); the line also carries the reference-shaped numbers: `per_slice_forward` (one `ProtoSAM.forward` per slice, what
+validation_protosam.py:387 does) and `no_support_cache` (support re-encoded for every slice, grid_proto_fewshot.py:181-184).
 
 Prints ONE JSON line on rank 0, with `roofline` (dominant kernel = the MFMA GEMM, timed live with HIP events on its own
-stream) and `cpu_baseline` (the CPU oracle on a bounded sample of the same workload, timed on this host's cores).
+stream), `roofline_hbm` (the HBM-bound kernels: achieved algorithmic GB/s), per-stage times, and `cpu_baseline` (the CPU
+oracle on a bounded sample of the same workload, timed on this host's cores at all cores and at 1 thread).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F16_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0     # HBM3E peak (6.3 TB/s achievable by a float4 copy), same guide
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
@@ -46,9 +51,52 @@ def main():
     ap.add_argument("--slices", type=int, default=64)
     ap.add_argument("--no-support-cache", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the per-slice / no-cache / stage / HBM-roofline legs")
+    ap.add_argument("--cpu-slices", type=int, default=3, help="slices of the CPU baseline at all cores")
+    ap.add_argument("--cpu-1thread-slices", type=int, default=1, help="slices of the CPU baseline at 1 thread "
+                    "(validation_protosam.py:299); 0 skips it")
     ap.add_argument("--cpu-sam-depth", type=int, default=None, help="debug: truncate both models' SAM depth")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def step_slices(s, parts, B, world, rank):
+    """Slice indices rank `rank` processes in step `s`: a step = one window of world*B consecutive slices of one z-part (the
+    caller walks a scan part by part, validation_protosam.py:352-362); rank r takes z = r (mod world) of the window (SURVEY
+    8e). The union over ranks does not depend on `world` for a given world*B."""
+    pz = parts[s % 3]
+    base = (s // 3) * B * world
+    zs = [pz[(base + j * world + rank) % len(pz)] for j in range(B)]
+    zs.sort()
+    return zs
+
+
+def launch_ranks(args):
+    """No launcher, --gpus N > 1: start N fresh rank processes. This parent never initialises the GPU."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("launching:", " ".join(cmd))
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    if lines:
+        print(lines[-1], flush=True)
+    elif p.returncode == 0:
+        log("no JSON line from rank 0")
+        return 1
+    return p.returncode
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
+
+    import torch
+    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -60,8 +108,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
 
-    from protosam_amd import ops
-    from protosam_amd.runner import build_protosam, gather_masks, run_slices, support_set
+    from protosam_amd import ops, protosam as psmod
+    from protosam_amd.runner import build_protosam, gather_masks, part_assign, run_slices, support_set
     from protosam_amd.synth import synth_volume
 
     t0 = time.time()
@@ -76,18 +124,11 @@ def main():
 
     B = args.batch
     out = torch.zeros((B, 512, 512), dtype=torch.uint8, device=dev)
-
-    from protosam_amd.runner import part_assign
     parts = [[z for z in range(args.slices) if part_assign(z, args.slices) == pt] for pt in range(3)]
 
-    def step(s):
-        # a step = one window of W*B consecutive slices of one z-part (the caller walks a scan part by part,
-        # validation_protosam.py:352-362); rank r takes the slices z = r (mod W) of the window
-        pz = parts[s % 3]
-        base = (s // 3) * B * world
-        zs = [pz[(base + j * world + rank) % len(pz)] for j in range(B)]
-        zs.sort()
-        masks, st = run_slices(model, vol_d, sup_imgs, sup_masks, zs, dev, out=out, batch=args.micro)
+    def step(s, micro=None):
+        zs = step_slices(s, parts, B, world, rank)
+        masks, st = run_slices(model, vol_d, sup_imgs, sup_masks, zs, dev, out=out, batch=micro or args.micro)
         full = gather_masks(masks, world)
         return zs, full, st
 
@@ -104,11 +145,14 @@ def main():
         dist.barrier()
     timer = ops.KernelTimer() if rank == 0 else None
     ops.GEMM_TIMER = timer
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     torch.cuda.synchronize()
     t1 = time.perf_counter()
+    step_ev[0].record()
     ncomp = []
     for s in range(args.steps):
         zs, full, st = step(args.warmup + s)
+        step_ev[s + 1].record()
         ncomp += st
     torch.cuda.synchronize()
     if world > 1:
@@ -125,31 +169,26 @@ def main():
             dist.destroy_process_group()
         return
 
+    import numpy as np
+    step_ms = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)]
     n_slices_done = world * B * args.steps
     value = n_slices_done / elapsed
     nl, tg, fl = timer.summary()
     achieved = fl / tg / 1e12 if tg > 0 else 0.0
-    # HBM-side bytes per GEMM launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same
-    # command, gfx950 read correction applied; see profiles/r01_n_gemm_pmc_traffic.json). None if the file is absent.
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_n_gemm_pmc_traffic.json")) as f:
-            traffic = json.load(f)["all_gemm_launches"]["bytes_per_launch_avg"]
-    except Exception:
-        pass
-    roofline = {"bound": "mfma", "kernel": "psam_gemm_f16 (gemm8kp_f16_kernel persistent 256x256x64 8-phase / gemm_f16_kernel 128x128x64)",
+    roofline = {"bound": "mfma", "kernel": "psam_gemm_f16 (fp16 operands, fp32 accumulate; every Linear / conv-as-GEMM of the "
+                                           "two ViT encoders)",
                 "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic, "launches": nl,
+                "frac": round(achieved / PEAK_F16_TFLOPS, 4),
+                # HBM bytes per launch come from rocprofv3 PMC passes, which cannot run inside this process: the measured figure
+                # for this round's kernel is in profiles/ (DESIGN.md cites the file); never read from a stale file here
+                "traffic": None, "launches": nl,
                 "avg_launch_us": round(tg / max(nl, 1) * 1e6, 2), "flop_per_launch_avg": round(fl / max(nl, 1)),
                 "gemm_time_share": round(tg / elapsed, 3)}
-    cpu = None
-    parity = None
-    if world == 1 and not args.no_cpu_baseline:
-        cpu, parity = cpu_baseline(model, alp_sd, vol, svol, slab, args, dev)
     res = {
         "metric": "query-slices/sec (512x512) end-to-end ProtoSAM infer",
         "value": round(value, 3), "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "ms_per_step_std": round(float(np.std(step_ms)), 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"ProtoSAM.forward per 512x512 slice: DINOv2 ViT-B/14 + ALP + SAM {args.sam} "
                                f"(encoder + prompt encoder + mask decoder), synthetic CT-like volume",
@@ -157,8 +196,14 @@ def main():
                    "support_cached": not args.no_support_cache,
                    "mean_components_per_slice": round(sum(ncomp) / max(len(ncomp), 1), 2),
                    "flags": "use_bbox use_points point_mode=both use_cca=False", "weights": "seeded random (1234)"},
-        "roofline": roofline, "cpu_baseline": cpu,
+        "roofline": roofline,
     }
+    if world == 1 and not args.no_extras:     # single-GPU legs (they would need the other ranks for the all-gather otherwise)
+        res.update(extras(args, model, step, ops, psmod, B, torch))
+    cpu = parity = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu, parity = cpu_baseline(model, alp_sd, vol, svol, slab, args, dev)
+    res["cpu_baseline"] = cpu
     if parity is not None:
         res["parity_vs_cpu_oracle"] = parity
     print(json.dumps(res), flush=True)
@@ -166,53 +211,128 @@ def main():
         dist.destroy_process_group()
 
 
+def extras(args, model, step, ops, psmod, B, torch):
+    """Single-rank legs after the headline measurement (rank 0 only, no collectives): the reference-shaped numbers, per-stage
+    GPU time and the HBM-side roofline entries. Each leg is a couple of steps."""
+    out = {}
+    s0 = args.warmup + args.steps
+
+    def timed(n, **kw):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for i in range(n):
+            step(s0 + i, **kw)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t
+    # (a) stage times + HBM-side kernels, on the headline configuration (2 steps with the timers on)
+    names = ("layernorm", "attention_window", "attention_global", "alp_sim", "prob_argmax", "ccl")
+    for n in names:
+        ops.TIMERS[n] = ops.KernelTimer()
+    psmod.STAGE_TIMER = psmod.StageTimer()
+    nst = 2
+    timed(nst)
+    stages = psmod.STAGE_TIMER.summary()
+    psmod.STAGE_TIMER = None
+    out["stage_ms_per_step"] = {k: round(v / nst, 3) for k, v in stages.items()}
+    hbm = []
+    for n in names:
+        nl, tt, by = ops.TIMERS[n].summary()
+        if nl == 0 or tt <= 0:
+            continue
+        e = {"kernel": n, "bound": "hbm", "achieved": round(by / tt / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+             "frac": round(by / tt / 1e9 / PEAK_HBM_GBS, 4), "launches_per_step": nl // nst,
+             "avg_launch_us": round(tt / nl * 1e6, 2), "bytes_per_launch": round(by / nl)}
+        fl = ops.TIMERS[n].summary2()
+        if fl > 0:   # the attention kernels are also priced against the MFMA roofline
+            e["mfma_tflops"] = round(fl / tt / 1e12, 1)
+            e["mfma_frac"] = round(fl / tt / 1e12 / PEAK_F16_TFLOPS, 4)
+        hbm.append(e)
+    ops.TIMERS.clear()
+    out["roofline_hbm"] = hbm
+    # (b) the reference-shaped call pattern: one ProtoSAM.forward per slice (validation_protosam.py:387)
+    timed(1, micro=1)
+    dt = timed(1, micro=1)
+    out["per_slice_forward"] = {"value": round(B / dt, 2), "unit": "slices/s",
+                                "note": "micro_batch 1: one ProtoSAM.forward call per slice, support cached"}
+    # (c) support re-encoded for every slice as the reference does (grid_proto_fewshot.py:181-184, SURVEY Q18)
+    alp = model.coarse_segmentation_model.model
+    if alp.cache_support:
+        alp.cache_support = False
+        alp._sup_cache = []
+        try:
+            timed(1)
+            dt = timed(2)
+            out["no_support_cache"] = {"value": round(2 * B / dt, 2), "unit": "slices/s",
+                                       "note": "headline configuration with the support image re-encoded for every slice"}
+        finally:
+            alp.cache_support = True
+    return out
+
+
 def cpu_baseline(model, alp_sd, vol, svol, slab, args, dev):
-    """CPU oracle (kind 'port': our pinned restatement of the reference) on a bounded sample: ONE slice of the same
-    workload with all host threads. Doubles as a full-depth parity check of the GPU result for that slice."""
+    """CPU oracle (kind 'port': our restatement, pinned against the reference) on a bounded sample of the same workload:
+    `--cpu-slices` slices with all host threads (capped at 32) and `--cpu-1thread-slices` at one thread, which is how the
+    reference runs (`torch.set_num_threads(1)`, validation_protosam.py:299). Doubles as a full-depth parity check."""
     import numpy as np
+    import torch
     from oracle import alp as oalp, dinov2 as odino, glue
-    from protosam_amd.runner import part_assign, support_set
-    from protosam_amd.synth import synth_state_dict
+    from protosam_amd.metrics import dice
+    from protosam_amd.runner import part_assign, run_slices, support_set
     # all host cores up to 32: beyond that PyTorch's intra-op parallelism stops scaling on these layer sizes
     cores = min(os.cpu_count() or 1, 32)
-    torch.set_num_threads(cores)
-    z = args.slices // 2
+    n = args.slices
+    zs_all = [int((i + 0.5) * n / max(args.cpu_slices, 1)) for i in range(args.cpu_slices)]
     sup_imgs, sup_masks = support_set(svol, slab)
-    part = part_assign(z, args.slices)
-    q = vol[z][None, None].repeat(1, 3, 1, 1).contiguous()
     enc_sd = {k[len("encoder."):]: v for k, v in alp_sd.items() if k.startswith("encoder.")}
     sam_sd = {k: v.detach().cpu().float() for k, v in model.sam.state_dict().items()}
     enc = lambda im: odino.forward_features(im, enc_sd, "dinov2_b14")["x_norm_patchtokens"]  # noqa: E731
-    taps = {}
-    with torch.no_grad():
-        t0 = time.perf_counter()
-        logits = oalp.fewshot_forward(enc, sup_imgs[part], sup_masks[part], q, 512)
-        pred_ref, scores_ref = glue.protosam_forward(q, logits, sam_sd, args.sam, use_bbox=True, use_points=True,
-                                                     point_mode="both", use_cca=False,
-                                                     encoder_depth=args.cpu_sam_depth, taps=taps)
-        dt = time.perf_counter() - t0
-    log(f"cpu_baseline: 1 slice in {dt:.1f}s on {cores} threads")
-    # GPU result for the same slice
-    from protosam_amd.runner import run_slices
+
+    def oracle_slice(z, taps):
+        q = vol[z][None, None].repeat(1, 3, 1, 1).contiguous()
+        part = part_assign(z, n)
+        with torch.no_grad():
+            logits = oalp.fewshot_forward(enc, sup_imgs[part], sup_masks[part], q, 512)
+            return glue.protosam_forward(q, logits, sam_sd, args.sam, use_bbox=True, use_points=True, point_mode="both",
+                                         use_cca=False, encoder_depth=args.cpu_sam_depth, taps=taps)
     sup_d = [s.to(dev) for s in sup_imgs]
     msk_d = [m.to(dev) for m in sup_masks]
-    masks, _ = run_slices(model, vol.to(dev), sup_d, msk_d, [z], dev)
-    g = masks[0].cpu().float()
-    r = pred_ref.float()
-    tp = (g * r).sum()
-    dice = float(2 * tp / (2 * tp + ((1 - g) * r).sum() + (g * (1 - r)).sum() + 1e-8))
-    st = model.last_stats
-    parity = {"slice": z, "dice_final_mask": round(dice, 5), "flipped_pixels": int((g != r).sum()),
-              "components": int(st.get("n_prompts", 0))}
-    if "low_res" in st and len(taps.get("low_res", [])) == st["low_res"].shape[0]:
-        low = st["low_res"][:, st["sel"]].cpu()
-        low_ref = torch.stack([l[0] for l in taps["low_res"]])
-        parity["max_abs_dprob_low_res"] = float((torch.sigmoid(low) - torch.sigmoid(low_ref)).abs().max())
-        parity["max_abs_dscore"] = float(np.abs(np.array([float(v) for v in st["iou"][:, st["sel"]].cpu()]) -
-                                                np.array(scores_ref)).max())
-    cpu = {"value": round(1.0 / dt, 5), "unit": "slices/s", "cores": cores, "kind": "port",
-           "sample": f"1 slice (z={z}) of the same volume through the full CPU oracle pipeline (fp32, {cores} threads), "
-                     f"{dt:.1f} s"}
+    vol_d = vol.to(dev)
+    torch.set_num_threads(cores)
+    t_all, parities = 0.0, []
+    for z in zs_all:
+        taps = {}
+        t0 = time.perf_counter()
+        pred_ref, scores_ref = oracle_slice(z, taps)
+        t_all += time.perf_counter() - t0
+        masks, _ = run_slices(model, vol_d, sup_d, msk_d, [z], dev)         # GPU result for the same slice
+        g, r = masks[0].cpu().float(), pred_ref.float()
+        st = model.last_stats
+        p = {"slice": z, "dice_final_mask": round(dice(g, r), 5), "flipped_pixels": int((g != r).sum()),
+             "components": int(st.get("n_prompts", 0))}
+        if "low_res" in st and len(taps.get("low_res", [])) == st["low_res"].shape[0]:
+            low = st["low_res"][:, st["sel"]].cpu()
+            low_ref = torch.stack([l[0] for l in taps["low_res"]])
+            p["max_abs_dprob_low_res"] = float((torch.sigmoid(low) - torch.sigmoid(low_ref)).abs().max())
+            p["max_abs_dscore"] = float(np.abs(st["iou"][:, st["sel"]].cpu().numpy() - np.array(scores_ref)).max())
+        parities.append(p)
+    log(f"cpu_baseline: {len(zs_all)} slices in {t_all:.1f}s on {cores} threads")
+    cpu = {"value": round(len(zs_all) / t_all, 5), "unit": "slices/s", "cores": cores, "kind": "port",
+           "sample": f"{len(zs_all)} slices (z = {zs_all}) of the same volume through the full CPU oracle pipeline "
+                     f"(fp32, {cores} threads), {t_all:.1f} s"}
+    if args.cpu_1thread_slices > 0:
+        torch.set_num_threads(1)
+        t0 = time.perf_counter()
+        for z in zs_all[:args.cpu_1thread_slices]:
+            oracle_slice(z, {})
+        t1 = time.perf_counter() - t0
+        torch.set_num_threads(cores)
+        log(f"cpu_baseline: {args.cpu_1thread_slices} slice(s) in {t1:.1f}s on 1 thread")
+        cpu["one_thread"] = {"value": round(args.cpu_1thread_slices / t1, 5), "unit": "slices/s", "cores": 1,
+                             "sample": f"{args.cpu_1thread_slices} slice(s), torch.set_num_threads(1) as "
+                                       f"validation_protosam.py:299, {t1:.1f} s"}
+    worst = max((p.get("max_abs_dprob_low_res", 0.0) for p in parities), default=0.0)
+    parity = {"slices": parities, "worst_max_abs_dprob_low_res": worst, "bound": 1e-3,
+              "min_dice_final_mask": min(p["dice_final_mask"] for p in parities)}
     return cpu, parity
 
 

@@ -87,6 +87,9 @@ int psam_alp_sim(const float* qry, long long q_bstride, int ld, int B, int npix,
 int psam_patchify_bilinear(const float* img, int B, int C, int H, int W, int S, int P, int Kpad, void* out, void* stream);
 /* F.interpolate(x, (OH,OW), 'bilinear', align_corners=False), fp32 planes. grid_proto_fewshot.py:272-273; ProtoSAM.py:592-594 */
 int psam_bilinear_nchw(const float* in, int planes, int IH, int IW, int OH, int OW, float* out, void* stream);
+/* The same resize in the conventions of the vendored SAM copies' postprocess_masks: mode 0 as above, 1 = bilinear
+ * align_corners=True (SamBatched, modeling/sam.py:313-320), 2 = nearest (vendored Sam, modeling/sam.py:154-160). */
+int psam_resize2d(const float* in, int planes, int IH, int IW, int OH, int OW, int mode, float* out, void* stream);
 /* token-major feature-map resize fp32 [B][ih*iw,C] -> [B][oh*ow,C] (the 32x32 upsample of grid_proto_fewshot.py:96-98) */
 int psam_bilinear_tokens(const float* in, long long in_bstride, int ld, int B, int ih, int iw, int C, int oh, int ow,
                          float* out, void* stream);

@@ -104,6 +104,32 @@ def cca(pred, logits):
     return (2, np.where(cc[1] != max_key, 0, 1).astype(np.int32), cc[2][[0, max_key]], cc[3][[0, max_key]])
 
 
+def cca_pred(pred, logits):
+    """util/utils.py:496-541 with return_conf=True: (pred restricted to the most confident component, its confidence);
+    all zeros and 0 when there is no component."""
+    cc, conf = get_connected_components(pred, logits)
+    max_conf, max_key = conf[0], 0
+    for k, v in conf.items():
+        if v > max_conf:
+            max_conf, max_key = v, k
+    if max_conf == 0:
+        return pred * np.zeros_like(pred), max_conf
+    keep = (np.where(cc[1] != max_key, 0, 1) == 1).astype(np.uint8)
+    return pred * keep, max_conf
+
+
+def coarse_pred_only(output_logits, original_size, use_cca):
+    """ProtoSAM.py:580-590 / ProtoMedSAM.py:163-172 in eval mode -> (pred int64 [H,W], [conf]). `shape[-2:] != original_size`
+    compares a Size with an int there, so the bilinear resize always runs (the identity when the sizes agree)."""
+    output_logits = F.interpolate(output_logits, size=original_size, mode="bilinear")
+    pred = output_logits.argmax(dim=1)[0]
+    conf = confidence_from_logits(output_logits)
+    if use_cca:
+        _pred, conf = cca_pred(pred.numpy(), output_logits)
+        pred = torch.from_numpy(_pred)
+    return pred, [conf]
+
+
 def bbox_per_cc(cc):
     """ProtoSAM.py:242-264: XYXY [min_x, min_y, max_x, max_y] per label >= 1."""
     out = []

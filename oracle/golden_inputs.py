@@ -76,3 +76,70 @@ def mask_prompt_case():
     yy, xx = torch.meshgrid(torch.arange(256.0), torch.arange(256.0), indexing="ij")
     m[1, 0][((yy - 150) / 40) ** 2 + ((xx - 100) / 70) ** 2 <= 1] = 10.0
     return m
+
+
+# ---- orchestration cases: reference ProtoSAM.forward / ProtoMedSAM.forward / SamPredictor run end to end ----------------
+ORCH_SAM_DEPTH = 2            # ViT-B block stack truncated to [window, window] so the CPU reference runs in seconds
+ORCH_SAM_SEED = 1234
+ORCH_SIZE = 512
+# flag sets of ProtoSAM.__init__ the reference is run with (validation_protosam.py:220-232 passes exactly these names)
+ORCH_FLAGS = {
+    "default": dict(use_bbox=True, use_points=True, point_mode="both", use_cca=False),
+    "cca": dict(use_bbox=True, use_points=True, point_mode="both", use_cca=True),
+    "conf_pts": dict(use_bbox=False, use_points=True, point_mode="conf", use_cca=False),
+    "centroid_box": dict(use_bbox=True, use_points=True, point_mode="centroid", use_cca=False),
+    "box_only": dict(use_bbox=True, use_points=False, use_cca=False),
+    "mask": dict(use_bbox=False, use_points=False, use_mask=True, use_cca=False),
+    "mask_cca": dict(use_bbox=False, use_points=False, use_mask=True, use_cca=True),
+    "neg": dict(use_bbox=True, use_points=True, point_mode="both", use_cca=False, use_neg_points=True),
+}
+
+
+def orch_query():
+    """The query slice [1,3,512,512] every orchestration case uses (one SAM encoding serves all of them)."""
+    return fewshot_pair(ORCH_SIZE)[2]
+
+
+def orch_coarse_logits(seed=3, size=ORCH_SIZE, thr=1.0, gain=6.0):
+    """[1,2,S,S] stand-in for the coarse model's logits: a smooth random field with several separate foreground blobs
+    (one of them tiny), scaled like ALP logits so that softmax probabilities cover (0,1) around the blob borders."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(seed)
+    f = torch.randn((1, 1, size // 64, size // 64), generator=g)
+    f = F.interpolate(f, size=(size, size), mode="bicubic", align_corners=False)[0, 0]
+    f = (f - f.mean()) / f.std()
+    # a 3x4-pixel component of its own; values all different: on a plateau `torch.topk` (ProtoSAM.py:281) may return any
+    # of the tied pixels (CPU and CUDA differ), while the oracle and the HIP path take the first one in raster order
+    # (and kept below the level where softmax saturates to exactly 1.0f - logit difference > ~16.6 - for the same reason)
+    f[40:43, 60:64] = 1.7 + 0.01 * torch.arange(12.0).reshape(3, 4).flip(1)
+    # bounded (|logit difference| <= 2 * gain) so that no probability saturates to exactly 1.0f: see the tie note above
+    fg = gain * torch.tanh((f - thr) / 1.5)
+    return torch.stack([-fg, fg])[None].contiguous()
+
+
+def orch_empty_logits(size=ORCH_SIZE):
+    z = torch.zeros((1, 2, size, size))
+    z[:, 0] = 5.0
+    return z
+
+
+def predictor_cases():
+    """(name, image HxW, point_coords, point_labels, box, mask_input?, multimask_output, return_logits)"""
+    import numpy as np
+    return [
+        ("sq_pts_box", (1024, 1024), np.array([[400.0, 500.0], [520.5, 480.0]]), np.array([1, 1]),
+         np.array([300, 350, 700, 800]), False, True, False),
+        ("sq_box_single", (1024, 1024), None, None, np.array([300, 350, 700, 800]), False, False, True),
+        ("rect_pts_neg", (600, 900), np.array([[360.0, 300.0], [540.0, 180.0]]), np.array([1, 0]), None, False, True, False),
+        ("sq_mask_in", (1024, 1024), None, None, None, True, True, False),
+    ]
+
+
+def predictor_image(hw, seed=0):
+    """uint8 HWC image of size hw."""
+    import numpy as np
+    g = torch.Generator().manual_seed(100 + seed + hw[0])
+    f = torch.nn.functional.interpolate(torch.randn((1, 3, hw[0] // 32 + 1, hw[1] // 32 + 1), generator=g), size=hw,
+                                        mode="bilinear")[0]
+    f = (f - f.min()) / (f.max() - f.min()) * 255
+    return f.permute(1, 2, 0).numpy().astype(np.uint8)

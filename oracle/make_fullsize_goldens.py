@@ -1,0 +1,140 @@
+"""Full-depth oracle taps for BASELINE.json configs 3 / 4 / 5 (test infrastructure; see oracle/__init__.py).
+
+  python oracle/make_fullsize_goldens.py [3] [4] [5]        # writes tests/golden/fullsize_cfg{3,4,5}.npz
+
+The CPU oracle (pinned against the reference by oracle/validate_against_reference.py) is run ONCE, here in the build
+container, at the configurations' full model depth on seeded synthetic slices; `tests/test_fullsize_gpu.py` runs the HIP
+path on the same slices on the GPU box and compares against these records (sigmoid(low_res_masks) within 1e-3, Dice of the
+final mask). Running the full-depth oracle inside the GPU tests instead would cost minutes of host time per run.
+
+Inputs come from the seeded generators in protosam_amd/synth.py + protosam_amd/runner.py (`synth_volume`, `support_set`,
+`part_assign`: the caller's data contract of validation_protosam.py:346-388), weights from `synth_state_dict(seed 1234)`;
+both are reproduced bit for bit on any machine.
+
+  config 3: DINOv2 ViT-B/14 x12 + ALP + SAM ViT-B x12, 512x512 MRI-like volume of 32 slices, default flags + use_cca
+  config 4: ... + SAM ViT-H x32, 512x512x64 CT-like volume (the benchmark's workload)
+  config 5: DINOv2 ViT-B/14 x12 at 1022^2 (73x73 grid) + MedSAM ViT-B x12, 1024x1024 slice with four organs = four classes
+            as four 1-way passes sharing one encoder forward (validation.py:207; n_ways == 1, grid_proto_fewshot.py:172)
+Records per case: sigmoid(low_res_masks) of the kept mask token as uint16 fixed point (p * 65535: 8e-6 resolution on the
+quantity the 1e-3 bound applies to), final mask (packed bits), scores, coarse foreground probability map every 4th pixel.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+
+def prob16(low):
+    """sigmoid(logits) -> uint16 fixed point."""
+    return torch.round(torch.sigmoid(low.double()) * 65535.0).numpy().astype(np.uint16)
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+CFG3_SLICES = (5, 16, 27)
+CFG4_SLICES = (8, 32, 56)
+CFG5_SEED = 2
+
+
+def _weights(sam_type, image_size):
+    from protosam_amd.grid_proto_fewshot import FewShotSeg
+    from protosam_amd.runner import ALP_CFG
+    from protosam_amd.segment_anything import sam_model_registry
+    from protosam_amd.synth import synth_state_dict
+    alp_sd = synth_state_dict(FewShotSeg(image_size, None, dict(ALP_CFG)), 1234)
+    enc_sd = {k[len("encoder."):]: v for k, v in alp_sd.items() if k.startswith("encoder.")}
+    sam_sd = synth_state_dict(sam_model_registry[sam_type](), 1234)
+    return enc_sd, sam_sd
+
+
+def volume_config(cfg):
+    """-> (sam_type, n_slices, kind, slices, flag sets) of configs 3 / 4."""
+    if cfg == 3:
+        return "vit_b", 32, "mri", CFG3_SLICES, {"default": dict(use_cca=False), "cca": dict(use_cca=True)}
+    return "vit_h", 64, "ct", CFG4_SLICES, {"default": dict(use_cca=False)}
+
+
+def make_volume_config(cfg):
+    from oracle import alp as oalp, dinov2 as odino, glue
+    from protosam_amd.runner import part_assign, support_set
+    from protosam_amd.synth import synth_volume
+    sam_type, n, kind, slices, flagsets = volume_config(cfg)
+    enc_sd, sam_sd = _weights(sam_type, 512)
+    vol, lab = synth_volume(n, 512, seed=0, kind=kind)
+    svol, slab = synth_volume(n, 512, seed=1, kind=kind)
+    sup_imgs, sup_masks = support_set(svol, slab)
+    enc = lambda im: odino.forward_features(im, enc_sd, "dinov2_b14")["x_norm_patchtokens"]  # noqa: E731
+    out = {}
+    for z in slices:
+        t0 = time.time()
+        q = vol[z][None, None].repeat(1, 3, 1, 1).contiguous()
+        part = part_assign(z, n)
+        with torch.no_grad():
+            logits = oalp.fewshot_forward(enc, sup_imgs[part], sup_masks[part], q, 512)
+            feats = None
+            for fname, fl in flagsets.items():
+                taps = {}
+                pred, scores = glue.protosam_forward(q, logits, sam_sd, sam_type, use_bbox=True, use_points=True,
+                                                     point_mode="both", taps=taps, features=feats, **fl)
+                feats = taps["features"]
+                k = f"z{z}_{fname}"
+                out[k + "_mask"] = np.packbits(pred.numpy().astype(bool))
+                out[k + "_scores"] = np.array(scores, dtype=np.float32)
+                out[k + "_prob"] = prob16(torch.stack([l[0] for l in taps["low_res"]]))
+        out[f"z{z}_coarse_p"] = torch.round(logits.double().softmax(1)[0, 1, ::4, ::4] * 65535.0).numpy().astype(np.uint16)
+        print(f"config {cfg} z={z}: {len(scores)} component(s), fg {int(pred.sum())} px, {time.time() - t0:.0f}s", flush=True)
+    path = os.path.join(GOLD, f"fullsize_cfg{cfg}.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
+def cfg5_inputs():
+    """support image, the four classes' support masks, query image (protosam_amd.synth.synth_pair_multi: four organs of
+    different contrast in one 1024 x 1024 slice)."""
+    from protosam_amd.synth import synth_pair_multi
+    s_img, s_masks, q_img, _ = synth_pair_multi(1024, seed=CFG5_SEED)
+    return s_img, s_masks, q_img
+
+
+def make_config5():
+    from oracle import alp as oalp, dinov2 as odino, glue
+    S = 1024
+    enc_sd, sam_sd = _weights("vit_b", S)
+    s_img, s_masks, q_img = cfg5_inputs()
+    # the four classes share the support / query encoding (one DINOv2 forward at 1022^2 each); resize_to_patch_multiple
+    # creates a fresh tensor per call, so the memo is keyed on content
+    feats_tok = {}
+
+    def enc_by_content(im):
+        key = float(im.double().sum()), tuple(im.shape)
+        if key not in feats_tok:
+            feats_tok[key] = odino.forward_features(im, enc_sd, "dinov2_b14")["x_norm_patchtokens"]
+        return feats_tok[key]
+    out = {}
+    t0 = time.time()
+    for ci, m in enumerate(s_masks):
+        with torch.no_grad():
+            logits = oalp.fewshot_forward(enc_by_content, s_img, m, q_img, S)
+            taps = {}
+            seg, conf = glue.protomedsam_forward(q_img, logits, sam_sd, "vit_b", use_cca=True, taps=taps)
+        k = f"class{ci}"
+        out[k + "_mask"] = np.packbits(seg.numpy().astype(bool))
+        out[k + "_coarse_p"] = torch.round(logits.double().softmax(1)[0, 1, ::4, ::4] * 65535.0).numpy().astype(np.uint16)
+        if "low" in taps:
+            out[k + "_prob"] = prob16(taps["low"][0])
+            out[k + "_conf"] = np.asarray(conf[0], dtype=np.float32)
+        print(f"config 5 class {ci}: fg {int(seg.sum())} px, {time.time() - t0:.0f}s", flush=True)
+    path = os.path.join(GOLD, "fullsize_cfg5.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(os.cpu_count() or 1)
+    which = [int(a) for a in sys.argv[1:]] or [3, 4, 5]
+    for c in which:
+        make_config5() if c == 5 else make_volume_config(c)

@@ -408,6 +408,268 @@ def check_rotate(gold):
     gold["rotate_back"] = rutils.reverse_tensor(lg, rh, rw, -15).numpy()
 
 
+def _install_cv2_restatements():
+    """cv2 is absent: give the stub module the three functions the hot path calls, from the oracle's restatements (the
+    same move as `batched_nms` above). What this pins is the REFERENCE'S OWN orchestration around them - prompt assembly,
+    label conventions, per-component loops, selection rules - not cv2 itself (stated as unpinned in oracle/glue.py)."""
+    from oracle import glue
+    cv2 = sys.modules["cv2"]
+    cv2.INTER_NEAREST, cv2.COLOR_BGR2RGB = 0, 4
+
+    def connectedComponentsWithStats(img, connectivity=8):
+        assert connectivity == 8
+        return glue.connected_components_with_stats(img)
+
+    def dilate(img, kernel, iterations=1):
+        assert kernel.shape == (3, 3) and kernel.all()
+        return glue.dilate3x3(img, iterations)
+
+    def resize(img, dsize, interpolation=None):
+        assert interpolation == cv2.INTER_NEAREST
+        h, w = img.shape[:2]
+        ys = np.minimum(np.floor(np.arange(dsize[1]) * (h / dsize[1])).astype(np.int64), h - 1)
+        xs = np.minimum(np.floor(np.arange(dsize[0]) * (w / dsize[0])).astype(np.int64), w - 1)
+        return img[ys][:, xs]
+
+    cv2.connectedComponentsWithStats, cv2.dilate, cv2.resize = connectedComponentsWithStats, dilate, resize
+
+
+class _FixedCoarse:
+    """A ModelWrapper stand-in whose logits are given: the reference only calls `model(input)` (ProtoSAM.py:548)."""
+
+    def __init__(self, logits):
+        self.logits = logits
+
+    def __call__(self, inp):
+        return self.logits.clone()
+
+
+def _truncate_vendored_registry(depth):
+    """The vendored registry builds the full ViT-B (12 blocks); the orchestration cases use its first `depth` blocks."""
+    import segment_anything  # noqa: F401
+    bs = sys.modules["segment_anything.build_sam"]   # (the package re-exports a FUNCTION of the same name)
+    if not hasattr(bs, "_orig_build_sam"):
+        bs._orig_build_sam = bs._build_sam
+    def small(encoder_embed_dim, encoder_depth, encoder_num_heads, encoder_global_attn_indexes, checkpoint=None):
+        return bs._orig_build_sam(encoder_embed_dim, depth, encoder_num_heads,
+                                  [i for i in encoder_global_attn_indexes if i < depth], checkpoint)
+    bs._build_sam = small
+
+
+def _pack(mask):
+    return np.packbits(np.asarray(mask).astype(bool))
+
+
+def check_orchestration(gold, tmpdir):
+    """The reference's own ProtoSAM.forward (models/ProtoSAM.py:536-678, incl. :242-289, :349-466, :468-533), SamPredictor
+    (models/segment_anything/predictor.py:34-241), ProtoMedSAM.forward (models/ProtoMedSAM.py:122-222), cca /
+    get_connected_components (util/utils.py:474-541) executed end to end on CPU, against oracle/glue.py + odec.predict."""
+    import matplotlib
+    matplotlib.use("Agg")
+    _install_cv2_restatements()
+    from oracle import alp as oalp, dinov2 as odino, glue, golden_inputs as gi
+    from oracle import sam_image_encoder as oenc, sam_prompt_decoder as odec
+    from protosam_amd.synth import synth_state_dict
+    _truncate_vendored_registry(gi.ORCH_SAM_DEPTH)
+    import models.ProtoSAM as ref_ps
+    import models.ProtoMedSAM as ref_pm
+    from segment_anything import SamPredictor, sam_model_registry
+    print("orchestration: reference ProtoSAM.forward / SamPredictor / ProtoMedSAM.forward vs oracle/glue.py")
+    sam0 = sam_model_registry["vit_b"]()
+    sam_sd = synth_state_dict(sam0, gi.ORCH_SAM_SEED)
+    ckpt = os.path.join(tmpdir, "sam_vit_b_synth.pth")
+    torch.save(sam_sd, ckpt)
+    D = gi.ORCH_SAM_DEPTH
+    q = gi.orch_query()
+    S = gi.ORCH_SIZE
+
+    # -- SamPredictor.set_image / predict ---------------------------------------------------------------------------------
+    sam0.load_state_dict(sam_sd)
+    predictor = SamPredictor(sam0.eval())
+    feats_by_hw = {}
+    for name, hw, pc, pl, box, with_mask, mm, rl in gi.predictor_cases():
+        img = gi.predictor_image(hw)
+        with torch.no_grad():
+            predictor.set_image(img)
+            mk = gi.mask_prompt_case()[0].numpy() if with_mask else None
+            m_r, s_r, low_r = predictor.predict(point_coords=pc, point_labels=pl, box=box, mask_input=mk,
+                                                multimask_output=mm, return_logits=rl)
+            if hw not in feats_by_hw:
+                rz = glue.apply_image(img)
+                assert tuple(rz.shape[:2]) == tuple(predictor.input_size)
+                feats_by_hw[hw] = (oenc.image_encoder(glue.sam_preprocess(rz), sam_sd, model_type="vit_b", depth=D),
+                                   tuple(rz.shape[:2]))
+                close(feats_by_hw[hw][0], predictor.get_image_embedding(), 2e-5, f"predictor {hw}: image embedding")
+            feats, in_size = feats_by_hw[hw]
+            m_o, s_o, low_o = odec.predict(sam_sd, feats, pc, pl, box, mm, hw, variant="batched", mask_input=mk,
+                                           input_size=in_size)
+        close(low_o, low_r, 5e-4, f"predictor {name}: low_res logits")
+        close(s_o, s_r, 2e-5, f"predictor {name}: iou predictions")
+        if rl:   # return_logits=True hands back the post-processed logits instead of the thresholded masks
+            m_full = odec.postprocess_masks(low_o[None], in_size, hw, "batched")[0]
+            close(m_full, m_r, 5e-3, f"predictor {name}: full-size logits")
+        else:
+            d = int((m_o.numpy() != m_r).sum())
+            print(f"  [{'ok' if d <= 4 else 'FAIL'}] predictor {name}: {d} differing mask pixels of {m_r.size}")
+            assert d <= 4
+        gold[f"pred_{name}_low"] = low_r[..., ::2, ::2].astype(np.float16)
+        gold[f"pred_{name}_iou"] = s_r.astype(np.float32)
+    with torch.no_grad():
+        predictor.reset_image()
+    try:
+        predictor.predict(point_coords=np.array([[1.0, 2.0]]), point_labels=np.array([1]))
+        raise SystemExit("predict before set_image must raise")
+    except RuntimeError:
+        print("  [ok] predict before set_image raises RuntimeError")
+
+    # -- ProtoSAM.forward, every flag set, on given coarse logits --------------------------------------------------------
+    logits = gi.orch_coarse_logits()
+    qf = F_interp(q)
+    feats = oenc.image_encoder(glue.sam_preprocess(glue.quantise_image(qf)), sam_sd, model_type="vit_b", depth=D)
+    # Shim 5 (scoped to this check): the reference runs with CUDA tensors (validation_protosam.py:303,367), where
+    # `x.detach().cpu()` is a COPY. On CPU tensors it aliases, and ProtoSAM.py:361-362 (`bg_p = output_p[0, 0].detach().cpu();
+    # bg_p[bg_p < 0.95] = 0`) would then zero `output_p` itself in place, so that the ring search at :409-410 runs over zeros.
+    # `.cpu()` is made a copy here so that the CPU run has the device semantics the oracle (and the HIP path) follow.
+    orig_cpu = torch.Tensor.cpu
+    torch.Tensor.cpu = lambda self, *a, **k: orig_cpu(self, *a, **k).clone()
+    try:
+        _protosam_flag_cases(gold, ref_ps, gi, glue, q, S, D, logits, sam_sd, ckpt, feats)
+    finally:
+        torch.Tensor.cpu = orig_cpu
+    inp = ref_ps.InputFactory.create_input(ref_ps.TYPE_ALPNET, q, support_images=[q], support_labels=[torch.zeros(1, S, S)],
+                                           isval=True, val_wsize=2)
+    _orchestration_rest(gold, tmpdir, ref_ps, ref_pm, gi, glue, oalp, odino, q, S, D, logits, sam_sd, ckpt, feats, inp)
+
+
+def _protosam_flag_cases(gold, ref_ps, gi, glue, q, S, D, logits, sam_sd, ckpt, feats):
+    for name, kw in gi.ORCH_FLAGS.items():
+        ref_model = ref_ps.ProtoSAM(image_size=(1024, 1024), coarse_segmentation_model=_FixedCoarse(logits),
+                                    sam_pretrained_path=ckpt, num_points_for_sam=1, use_sam_trans=True, **kw).eval()
+        inp = ref_ps.InputFactory.create_input(ref_ps.TYPE_ALPNET, q, support_images=[q], support_labels=[torch.zeros(1, S, S)],
+                                               isval=True, val_wsize=2)
+        with torch.no_grad():
+            pred_r, scores_r = ref_model(q, inp, degrees_rotate=0)
+            taps = {}
+            pred_o, scores_o = glue.protosam_forward(q, logits, sam_sd, "vit_b", postprocess="batched", encoder_depth=D,
+                                                     features=feats, taps=taps,
+                                                     **{k: v for k, v in kw.items()})
+        assert pred_r.shape == pred_o.shape == (S, S) and pred_r.dtype == torch.float32
+        d = int((pred_r != pred_o).sum())
+        print(f"  [{'ok' if d == 0 else 'FAIL'}] ProtoSAM.forward {name}: {len(scores_r)} prompt sets, {d} differing pixels, "
+              f"fg {int(pred_r.sum())}")
+        assert d == 0 and len(scores_r) == len(scores_o)
+        close(np.array(scores_o, dtype=np.float64), np.array([float(v) for v in scores_r]), 1e-5, f"ProtoSAM.forward {name}: scores")
+        gold[f"orch_{name}_mask"] = _pack(pred_r.numpy())
+        gold[f"orch_{name}_scores"] = np.array([float(v) for v in scores_r], dtype=np.float32)
+        # the oracle's low-res logits (bit-equal to the reference's by the mask / score checks above), every 4th pixel
+        gold[f"orch_{name}_low"] = torch.stack([torch.as_tensor(l) for l in taps["low_res"]])[..., ::4, ::4].numpy().astype(np.float16)
+
+
+def _orchestration_rest(gold, tmpdir, ref_ps, ref_pm, gi, glue, oalp, odino, q, S, D, logits, sam_sd, ckpt, feats, inp):
+    # empty coarse mask: the 1024 x 1024 arg-max map, un-resized, and [0] (ProtoSAM.py:612-613)
+    ref_model = ref_ps.ProtoSAM(image_size=(1024, 1024), coarse_segmentation_model=_FixedCoarse(gi.orch_empty_logits()),
+                                sam_pretrained_path=ckpt, use_bbox=True, use_points=True, point_mode="both").eval()
+    with torch.no_grad():
+        pred_r, scores_r = ref_model(q, inp)
+        pred_o, scores_o = glue.protosam_forward(q, gi.orch_empty_logits(), sam_sd, "vit_b", features=feats)
+    assert tuple(pred_r.shape) == tuple(pred_o.shape) == (1024, 1024) and int(pred_r.sum()) == 0 and scores_r == scores_o == [0]
+    print("  [ok] ProtoSAM.forward with an empty coarse mask: [1024,1024] zeros, [0]")
+    # coarse_pred_only (ProtoSAM.py:580-590)
+    for use_cca in (False, True):
+        ref_model = ref_ps.ProtoSAM(image_size=(1024, 1024), coarse_segmentation_model=_FixedCoarse(logits),
+                                    sam_pretrained_path=ckpt, use_bbox=True, use_points=True, coarse_pred_only=True,
+                                    use_cca=use_cca).eval()
+        with torch.no_grad():
+            pred_r, conf_r = ref_model(q, inp)
+        pred_o, conf_o = glue.coarse_pred_only(logits, S, use_cca)
+        assert torch.equal(torch.as_tensor(pred_r).long(), torch.as_tensor(pred_o).long())
+        close(conf_o[0], conf_r[0], 1e-6, f"coarse_pred_only use_cca={use_cca}: confidence")
+        gold[f"orch_coarse_only_{int(use_cca)}"] = np.array([float(conf_r[0]), float(torch.as_tensor(pred_r).sum())])
+    # constructor errors (ProtoSAM.py:197,200-201)
+    for bad, exc in ((dict(use_points=False, use_bbox=False, use_mask=False), AssertionError),
+                     (dict(point_mode="nearest"), ValueError)):
+        try:
+            ref_ps.ProtoSAM((1024, 1024), None, ckpt, **bad)
+            raise SystemExit("constructor must raise")
+        except exc:
+            pass
+
+    # -- the real coarse model in the loop: reference ALPNetWrapper(FewShotSeg) -> ProtoSAM.forward ----------------------
+    depth = gi.FEWSHOT_DEPTH
+    enc_sd = gi.fewshot_encoder_sd()
+    torch.hub.load = lambda repo, name, **k: _HubAdapter("dinov2_b14", enc_sd, depth)
+    from models.grid_proto_fewshot import FewShotSeg
+    cfg = {"which_model": "dinov2_b14", "cls_name": "grid_proto", "proto_grid_size": 8, "lora": 0, "align": False,
+           "debug": False, "use_coco_init": False}
+    s_img, s_m, q_img, _ = gi.fewshot_pair(S)
+    ref_alp = ref_ps.ALPNetWrapper(FewShotSeg(S, None, cfg).eval())
+    ref_model = ref_ps.ProtoSAM(image_size=(1024, 1024), coarse_segmentation_model=ref_alp, sam_pretrained_path=ckpt,
+                                num_points_for_sam=1, use_sam_trans=True, **gi.ORCH_FLAGS["default"]).eval()
+    inp = ref_ps.InputFactory.create_input(ref_ps.TYPE_ALPNET, q_img, support_images=[s_img], support_labels=[s_m],
+                                           isval=True, val_wsize=2)
+    enc = lambda im: odino.forward_features(im, enc_sd, "dinov2_b14", depth=depth)["x_norm_patchtokens"]  # noqa: E731
+    with torch.no_grad():
+        pred_r, scores_r = ref_model(q_img, inp, degrees_rotate=0)
+        lg_o = oalp.fewshot_forward(enc, s_img, s_m, q_img, S)
+        pred_o, scores_o = glue.protosam_forward(q_img, lg_o, sam_sd, "vit_b", postprocess="batched", encoder_depth=D,
+                                                 features=feats, **gi.ORCH_FLAGS["default"])
+    d = int((pred_r != pred_o).sum())
+    print(f"  [{'ok' if d <= 2 else 'FAIL'}] FewShotSeg -> ProtoSAM.forward: {len(scores_r)} prompt sets, {d} differing pixels")
+    assert d <= 2 and len(scores_r) == len(scores_o)
+    close(np.array(scores_o), np.array([float(v) for v in scores_r]), 2e-5, "FewShotSeg -> ProtoSAM.forward: scores")
+    gold["orch_alp_mask"] = _pack(pred_r.numpy())
+    gold["orch_alp_scores"] = np.array([float(v) for v in scores_r], dtype=np.float32)
+
+    # -- ProtoMedSAM.forward (box prompts, [0,1] hand-off, sigmoid before the resize) ------------------------------------
+    ckpt_med = os.path.join(tmpdir, "medsam_vit_b_synth.pth")
+    torch.save(sam_sd, ckpt_med)
+    for use_cca in (True,):
+        ref_med = ref_pm.ProtoMedSAM((1024, 1024), _FixedCoarse(logits), ckpt_med, use_cca=use_cca).eval()
+        with torch.no_grad():
+            seg_r, conf_r = ref_med(q, inp)
+            seg_o, conf_o = glue.protomedsam_forward(q, logits, sam_sd, "vit_b", use_cca=use_cca, encoder_depth=D)
+        d = int((torch.as_tensor(seg_r).long() != seg_o.long()).sum())
+        print(f"  [{'ok' if d <= 2 else 'FAIL'}] ProtoMedSAM.forward use_cca={use_cca}: {d} differing pixels, fg {int(seg_r.sum())}")
+        assert d <= 2 and tuple(seg_r.shape) == (S, S)
+        close(np.asarray(conf_o[0]), np.asarray(conf_r[0]), 2e-5, "ProtoMedSAM.forward: confidence")
+        gold["orch_medsam_mask"] = _pack(torch.as_tensor(seg_r).numpy())
+        gold["orch_medsam_conf"] = np.asarray(conf_r[0], dtype=np.float32)
+    with torch.no_grad():
+        seg_r, conf_r = ref_pm.ProtoMedSAM((1024, 1024), _FixedCoarse(gi.orch_empty_logits()), ckpt_med, use_cca=True).eval()(q, inp)
+        seg_o, conf_o = glue.protomedsam_forward(q, gi.orch_empty_logits(), sam_sd, "vit_b", use_cca=True, encoder_depth=D)
+    assert tuple(seg_r.shape) == tuple(seg_o.shape) == (S, S) and int(seg_r.sum()) == 0 and conf_r == conf_o == [0]
+    print("  [ok] ProtoMedSAM.forward with an empty coarse mask: [512,512] zeros, [0]")
+
+    # -- the caller's metric (validation_protosam.py:169-185) -------------------------------------------------------------
+    check_metric(gold)
+
+
+def F_interp(q):
+    return torch.nn.functional.interpolate(q, size=(1024, 1024), mode="bilinear")
+
+
+def check_metric(gold):
+    """`get_dice_iou_precision_recall` lives in validation_protosam.py, which imports sacred at module level (absent): the
+    function's source lines are executed from the file itself, nothing else of the module is."""
+    import ast
+    from protosam_amd.metrics import get_dice_iou_precision_recall as ours
+    src = open(os.path.join(REF, "validation_protosam.py")).read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "get_dice_iou_precision_recall"][0]
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "validation_protosam.py", "exec"), ns)
+    ref = ns["get_dice_iou_precision_recall"]
+    g = torch.Generator().manual_seed(9)
+    a = (torch.rand((64, 64), generator=g) > 0.6).float()
+    b = (torch.rand((64, 64), generator=g) > 0.5).float()
+    r, o = ref(a, b), ours(a, b)
+    assert set(r) == set(o)
+    for k in r:
+        close(o[k], r[k], 0, f"get_dice_iou_precision_recall: {k}")
+    z = ref(a, torch.zeros_like(b))
+    assert z == ours(a, torch.zeros_like(b)) == {"dice": 0, "precision": 0, "recall": 0}
+    gold["metric_vals"] = np.array([float(r[k]) for k in ("dice", "iou", "precision", "recall")], dtype=np.float64)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--write-golden", action="store_true")
@@ -426,6 +688,9 @@ def main():
     check_glue(gold)
     check_amg(gold)
     check_rotate(gold)
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmpdir:
+        check_orchestration(gold, tmpdir)
     if args.write_golden:
         os.makedirs(GOLD, exist_ok=True)
         path = os.path.join(GOLD, "reference_outputs.npz")

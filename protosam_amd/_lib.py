@@ -31,6 +31,7 @@ SIGNATURES = {
                      c_void_p, c_void_p, c_int, c_void_p],
     "psam_patchify_bilinear": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "psam_bilinear_nchw": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "psam_resize2d": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "psam_bilinear_tokens": [c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "psam_prob_argmax": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "psam_broadcast_rows": [c_void_p, c_int, c_void_p, c_int, c_longlong, c_longlong, c_void_p],

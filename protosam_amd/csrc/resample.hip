@@ -95,6 +95,42 @@ extern "C" int psam_bilinear_nchw(const float* in, int planes, int IH, int IW, i
   return psam_launch_status();
 }
 
+// F.interpolate(x, (OH,OW)) of fp32 planes in the two other conventions the vendored SAM copies use for the second stage of
+// postprocess_masks: mode 1 = bilinear align_corners=True (SamBatched, modeling/sam.py:313-320: src = dst*(in-1)/(out-1)),
+// mode 2 = nearest (vendored Sam, modeling/sam.py:154-160: src = min(floor(dst*in/out), in-1)); mode 0 = psam_bilinear_nchw.
+__global__ void resize2d_kernel(const float* __restrict__ in, int IH, int IW, int OH, int OW, int mode,
+                                float* __restrict__ out) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  const int pl = blockIdx.z;
+  if (x >= OW) return;
+  const float* p = in + (size_t)pl * IH * IW;
+  float v;
+  if (mode == 2) {
+    const float sh = (float)IH / (float)OH, sw = (float)IW / (float)OW;
+    int sy = (int)floorf((float)y * sh), sx = (int)floorf((float)x * sw);
+    sy = sy < IH - 1 ? sy : IH - 1;
+    sx = sx < IW - 1 ? sx : IW - 1;
+    v = p[(size_t)sy * IW + sx];
+  } else {
+    Lin ly, lx;
+    const float sh = OH > 1 ? (float)(IH - 1) / (float)(OH - 1) : 0.f, sw = OW > 1 ? (float)(IW - 1) / (float)(OW - 1) : 0.f;
+    const float fy = sh * (float)y, fx = sw * (float)x;
+    ly.i0 = min((int)fy, IH - 1); ly.i1 = ly.i0 + (ly.i0 < IH - 1 ? 1 : 0); ly.l1 = fy - (float)ly.i0; ly.l0 = 1.f - ly.l1;
+    lx.i0 = min((int)fx, IW - 1); lx.i1 = lx.i0 + (lx.i0 < IW - 1 ? 1 : 0); lx.l1 = fx - (float)lx.i0; lx.l0 = 1.f - lx.l1;
+    v = bilerp(p, IW, ly, lx);
+  }
+  out[((size_t)pl * OH + y) * OW + x] = v;
+}
+extern "C" int psam_resize2d(const float* in, int planes, int IH, int IW, int OH, int OW, int mode, float* out,
+                             void* stream) {
+  if (planes <= 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0 || mode < 0 || mode > 2) return PSAM_ERR_ARG;
+  if (mode == 0) return psam_bilinear_nchw(in, planes, IH, IW, OH, OW, out, stream);
+  hipLaunchKernelGGL(resize2d_kernel, dim3((OW + 255) / 256, OH, planes), dim3(256), 0, (hipStream_t)stream, in, IH, IW, OH,
+                     OW, mode, out);
+  return psam_launch_status();
+}
+
 // logits [B,2,IH,IW] -> (bilinear to OH,OW unless equal) -> softmax -> prob [B,2,OH,OW], pred u8 [B,OH,OW]
 // fg_sum[b] (optional): number of foreground pixels (int32, atomically accumulated; caller zeroes it).
 // Each thread produces four consecutive pixels of a row (16-byte probability stores, one 4-byte label store); the

@@ -29,12 +29,30 @@ class KernelTimer:
         self.records.append((e0, e1, work))
 
     def summary(self):
-        """(n_launches, total_seconds, total_work) -- call after a device synchronize."""
+        """(n_launches, total_seconds, total_work) -- call after a device synchronize. `work` may be a tuple (bytes, flops):
+        the first member is summed here, `summary2` sums the second."""
         t = sum(a.elapsed_time(b) for a, b, _ in self.records) * 1e-3
-        return len(self.records), t, float(sum(w for _, _, w in self.records))
+        return len(self.records), t, float(sum((w[0] if isinstance(w, tuple) else w) for _, _, w in self.records))
+
+    def summary2(self):
+        return float(sum(w[1] for _, _, w in self.records if isinstance(w, tuple)))
 
 
 GEMM_TIMER = None  # set to a KernelTimer to time psam_gemm_f16 launches
+# further optional per-entry timers for bench.py's HBM-side roofline entries: name -> KernelTimer, work = ALGORITHMIC bytes
+# of the launch (inputs read once + outputs written once). Names: layernorm, alp_sim, prob_argmax, ccl, attention_window,
+# attention_global.
+TIMERS = {}
+
+
+def _tstart(name):
+    t = TIMERS.get(name)
+    return None if t is None else (t, t.start())
+
+
+def _tstop(h, work):
+    if h is not None:
+        h[0].stop(h[1], work)
 
 # packed qkv layout between the projection GEMM and the attention kernels: the reference's token-major [B,N,3,H,hd]
 # (default) or head-major [3,H,B*N,hd] (PSAM_QKV_HEAD_MAJOR=1: contiguous per-head rows for the attention kernels, but
@@ -191,9 +209,11 @@ def layernorm(x, weight, bias, eps, out=None, out_dtype=torch.float16, out2=None
     if out is None:
         out = torch.empty((M + zero_tail_rows, D), dtype=out_dtype, device=x.device)
     o2 = out.reshape(-1, out.shape[-1]) if out.dim() != 2 else out
+    h = _tstart("layernorm")
     st = _lib.lib().psam_layernorm(_ptr(x2), _ptr(weight), _ptr(bias), _ptr(o2), _ptr(out2), M, D, x2.stride(0),
                                   o2.stride(0), float(eps), 0 if out.dtype == torch.float16 else 1,
                                   zero_tail_rows, _stream())
+    _tstop(h, M * D * (4 + out.element_size()) + 8 * D)
     _lib.check(st, "psam_layernorm")
     return out
 
@@ -207,8 +227,14 @@ def attention(qkv, B, N, H, hd, scale, out=None, mode=0, rel_h=None, rel_w=None,
     assert qkv.is_contiguous()
     if out is None:
         out = torch.empty((B, N, H * hd), dtype=torch.float16, device=qkv.device)
+    h = _tstart("attention_window" if mode == 2 else "attention_global")
     st = _lib.lib().psam_attention_f16(_ptr(qkv), _ptr(out), _ptr(rel_h), _ptr(rel_w), _ptr(relq), _ptr(rpack), _ptr(pad_row), B, N,
                                       H, hd, float(scale), mode, gh, gw, ws, 1 if head_major else 0, _stream())
+    # qkv read once, out written once (fp16) + the global kernel's rel-pos terms (fp32 [B,H,N,64] x 2); work2 = FLOPs
+    # 4*B*H*N*Nk*hd with Nk = the window's 196 keys (14x14) or all N keys
+    nk = ws * ws if mode == 2 else N
+    _tstop(h, (B * N * 4 * H * hd * 2 + (2 * B * H * N * 64 * 4 if (mode == 1 and rel_h is not None) else 0),
+               4.0 * B * H * N * nk * hd))
     _lib.check(st, "psam_attention_f16")
     return out
 
@@ -292,8 +318,10 @@ def alp_sim(qry, q_bstride, ld, B, npix, C, bank, pred=None, part=None, eps=1e-4
         part = torch.empty(2 * B * npt * npix_pad * 3, dtype=torch.float32, device=qry.device)
     if pred is None:
         pred = torch.empty((B, 2, npix), dtype=torch.float32, device=qry.device)
+    h = _tstart("alp_sim")
     st = _lib.lib().psam_alp_sim(_ptr(qry), q_bstride, ld, B, npix, C, _ptr(bank.bank), bank.cap, _ptr(bank.meta),
                                 float(eps), float(sim_scale), _ptr(part), _ptr(pred), which_only, _stream())
+    _tstop(h, B * npix * C * 4 + 2 * bank.cap * C * 4 + B * 2 * npix * 4)     # bank at capacity: an upper bound
     _lib.check(st, "psam_alp_sim")
     return pred
 
@@ -321,6 +349,18 @@ def bilinear_nchw(x, OH, OW, out=None):
     return out
 
 
+def resize2d(x, OH, OW, mode, out=None):
+    """F.interpolate of fp32 [..., H, W] planes: mode 0 bilinear, 1 bilinear align_corners=True, 2 nearest."""
+    _req(x, torch.float32, "x")
+    assert x.is_contiguous()
+    planes = x.numel() // (x.shape[-1] * x.shape[-2])
+    if out is None:
+        out = torch.empty(tuple(x.shape[:-2]) + (OH, OW), dtype=torch.float32, device=x.device)
+    st = _lib.lib().psam_resize2d(_ptr(x), planes, x.shape[-2], x.shape[-1], OH, OW, mode, _ptr(out), _stream())
+    _lib.check(st, "psam_resize2d")
+    return out
+
+
 def prob_argmax(logits, OH, OW, prob=None, pred=None, fg_sum=None):
     _req(logits, torch.float32, "logits")
     assert logits.is_contiguous() and logits.dim() == 4 and logits.shape[1] == 2
@@ -329,8 +369,10 @@ def prob_argmax(logits, OH, OW, prob=None, pred=None, fg_sum=None):
         prob = torch.empty((B, 2, OH, OW), dtype=torch.float32, device=logits.device)
     if pred is None:
         pred = torch.empty((B, OH, OW), dtype=torch.uint8, device=logits.device)
+    h = _tstart("prob_argmax")
     st = _lib.lib().psam_prob_argmax(_ptr(logits), B, logits.shape[2], logits.shape[3], OH, OW, _ptr(prob), _ptr(pred),
                                     _ptr(fg_sum), _stream())
+    _tstop(h, B * (2 * logits.shape[2] * logits.shape[3] * 4 + OH * OW * 9))
     _lib.check(st, "psam_prob_argmax")
     return prob, pred
 
@@ -596,9 +638,11 @@ def ccl(pred_u8, pfg, ws, fg_sum=None, slot=0):
     """pred uint8 [H,W], pfg fp32 [H,W] -> ws.labels (int32 [H*W]) and ws.tabs[slot] (fp64 table, see csrc/ccl.hip)."""
     assert pred_u8.dtype == torch.uint8 and pred_u8.is_cuda and pred_u8.is_contiguous()
     _req(pfg, torch.float32, "pfg")
+    h = _tstart("ccl")
     st = _lib.lib().psam_ccl(_ptr(pred_u8), _ptr(pfg), ws.H, ws.W, ws.cap, _ptr(ws.labels), _ptr(ws.parent),
                             _ptr(ws.counters), _ptr(ws.roots), _ptr(ws.acc_i), _ptr(ws.acc_u), _ptr(ws.acc_d),
                             _ptr(fg_sum), _ptr(ws.tabs[slot]), _stream())
+    _tstop(h, ws.H * ws.W * (1 + 4 + 4))      # pred u8 + p_fg fp32 in, labels int32 out (the table is a few KB)
     _lib.check(st, "psam_ccl")
     return ws
 

@@ -53,6 +53,35 @@ DECODER_CHUNK = 256           # prompt sets per decoder call (workspace ~ 25 MB 
 MAX_NEG_COMPONENTS = 64   # psam_neg_points launches one tile grid per component
 
 
+class StageTimer:
+    """Optional per-stage GPU timing of `forward_batch` (bench.py): HIP events on the launch stream at the stage boundaries;
+    the time between two consecutive marks is booked on the later one. Off (None) by default: no events are recorded."""
+
+    def __init__(self):
+        self.marks = []
+
+    def mark(self, name):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.marks.append((name, e))
+
+    def summary(self):
+        """{stage: total ms} -- call after a device synchronize."""
+        out = {}
+        for (_, e0), (name, e1) in zip(self.marks[:-1], self.marks[1:]):
+            if name != "start":
+                out[name] = out.get(name, 0.0) + e0.elapsed_time(e1)
+        return out
+
+
+STAGE_TIMER = None
+
+
+def _mark(name):
+    if STAGE_TIMER is not None:
+        STAGE_TIMER.mark(name)
+
+
 class SegmentationInput(ABC):
     @abstractmethod
     def set_query_images(self, query_images):
@@ -405,7 +434,9 @@ class ProtoSAM(nn.Module):
             with torch.cuda.stream(side):
                 feat_tok = self._sam_features(query_images, bufs, B, S)
                 bufs["sam_done"].record(side)
+        _mark("start")
         output_logits = self._coarse_logits(query_images, coarse_model_input, degrees_rotate)   # [B,2,H,W]
+        _mark("coarse: DINOv2 + ALP")
         # 1. (bilinear to 1024) -> softmax -> argmax                               ProtoSAM.py:592-602
         bufs["fg_sum"].zero_()
         output_p, pred = ops.prob_argmax(output_logits.float().contiguous(), S, S, prob=bufs["prob"], pred=bufs["pred"],
@@ -427,6 +458,7 @@ class ProtoSAM(nn.Module):
             nkh = bufs.setdefault("neg_keys_host", torch.empty((B, MAX_NEG_COMPONENTS + 1), dtype=torch.int64).pin_memory())
             nkh.copy_(bufs["neg_keys"], non_blocking=True)
         bufs["event"].record()
+        _mark("softmax / argmax + connected components")
         # 3./4. image hand-off + SAM image encoder (already running on the side stream, or enqueued here before the host looks
         #       at the component tables)
         #       A slice whose coarse mask is empty never reaches SAM (ProtoSAM.py:612-613 returns before `set_image`): only the
@@ -443,6 +475,7 @@ class ProtoSAM(nn.Module):
                 feat_row = [-1] * B
                 for i, b in enumerate(keep):
                     feat_row[b] = i
+        _mark("image hand-off + SAM image encoder")
         # 5. host: number of components and prompts per slice
         bufs["event"].synchronize()
         if side is not None:
@@ -543,12 +576,14 @@ class ProtoSAM(nn.Module):
                         masks[it[c0:c1]] = m_g
                         iou[it[c0:c1]] = i_g
             sel = 0 if self.use_cca else 1                                      # multimask_output = not use_cca; index 0
+            _mark("prompt encoder + mask decoder")
             iou_host = iou[:, sel].cpu().numpy()
             for (b, start, cnt) in spans:
                 # 7. upsample -> > 0 -> union over components -> nearest to the input size   ProtoSAM.py:669-676
                 out = ops.mask_union(masks[start:start + cnt], sel, S, original_size, sam.variant_id(),
                                      sam.mask_threshold)
                 results[b] = (out, [np.float32(v) for v in iou_host[start:start + cnt]])
+            _mark("post-processing (upsample, threshold, union)")
             if B == 1:
                 self.last_stats.update(low_res=masks, iou=iou, sel=sel)
             else:

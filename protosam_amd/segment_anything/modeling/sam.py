@@ -62,6 +62,4 @@ class Sam(nn.Module):
             up = up[..., :ih, :iw].contiguous()
         if (oh, ow) == (ih, iw):
             return up
-        if self.postprocess_variant == "upstream":
-            return ops.bilinear_nchw(up, oh, ow)
-        raise NotImplementedError("second-stage resize for the vendored variants when original_size != input_size")
+        return ops.resize2d(up, oh, ow, self.variant_id())

@@ -116,3 +116,27 @@ def synth_volume(n_slices=32, size=512, seed=0, kind="mri"):
         vol[z], lab[z] = img, m
     vol = (vol - vol.mean()) / vol.std()
     return torch.from_numpy(vol), torch.from_numpy(lab)
+
+
+MULTI_ORGANS = ((0.30, 0.30, 0.10, 0.13, 1.6), (0.68, 0.70, 0.13, 0.10, -1.4), (0.30, 0.72, 0.09, 0.14, 0.9),
+                (0.72, 0.28, 0.11, 0.09, -0.8))
+
+
+def synth_pair_multi(size=1024, seed=0):
+    """A support/query pair with FOUR organs (ellipses of different contrast; slightly moved / scaled in the query) for the
+    multi-class configuration (BASELINE config 5): the reference handles classes as an outer loop of 1-way problems over the
+    same images (validation.py:207; n_ways == 1 asserted, grid_proto_fewshot.py:172).
+    Returns support [1,3,S,S], [4 x fg mask [1,S,S]], query [1,3,S,S], [4 x query gt [1,S,S]]."""
+    rng = np.random.RandomState(seed + 177)
+    imgs, masks = [], []
+    for j in range(2):
+        img = 0.4 * _smooth_field(size, seed + j) + 0.05 * rng.randn(size, size).astype(np.float32)
+        ms = []
+        for (cy, cx, ry, rx, a) in MULTI_ORGANS:
+            m = ellipse_mask(size, cy + 0.02 * j, cx - 0.015 * j, ry * (1 - 0.05 * j), rx * (1 + 0.04 * j))
+            img = img * (1 - m) + (a + 0.15 * _smooth_field(size, seed + 10 + j, 6)) * m
+            ms.append(torch.from_numpy(m[None]))
+        img = (img - img.mean()) / img.std()
+        imgs.append(torch.from_numpy(np.repeat(img[None, None], 3, axis=1).astype(np.float32)))
+        masks.append(ms)
+    return imgs[0], masks[0], imgs[1], masks[1]

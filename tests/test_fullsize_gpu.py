@@ -1,0 +1,127 @@
+"""GPU: BASELINE.json configs 3 / 4 / 5 at FULL model depth against the CPU oracle's records
+(tests/golden/fullsize_cfg{3,4,5}.npz, written by oracle/make_fullsize_goldens.py in the build container; the oracle itself is
+pinned to the reference by oracle/validate_against_reference.py).
+
+  config 3: DINOv2 ViT-B/14 x12 + ALP + SAM ViT-B x12 on the 32-slice MRI-like volume (default flags and use_cca)
+  config 4: ... + SAM ViT-H x32 on the 64-slice CT-like volume (the benchmark's workload)
+  config 5: DINOv2 ViT-B/14 x12 at 1022^2 + MedSAM ViT-B x12, 1024x1024 slice, four classes
+
+The north-star tolerance is asserted as written: |sigmoid(low_res_masks) - reference| <= 1e-3 and the coarse probability map
+within 1e-3; the final mask is compared as Dice (thresholds are discontinuities: a handful of border pixels may flip).
+Also: the batched volume runner equals the per-slice `ProtoSAM.forward` over the WHOLE volume (slices are independent).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 1e-3
+
+
+def _unpack(bits, S):
+    return torch.from_numpy(np.unpackbits(bits)[:S * S].reshape(S, S).astype(np.float32))
+
+
+def _volume_setup(dev, cfg):
+    from oracle.make_fullsize_goldens import volume_config
+    from protosam_amd.runner import build_protosam, support_set
+    from protosam_amd.synth import synth_volume
+    sam_type, n, kind, slices, flagsets = volume_config(cfg)
+    model, _ = build_protosam(dev, sam_type=sam_type, image_size=512, seed=1234)
+    vol, _ = synth_volume(n, 512, seed=0, kind=kind)
+    svol, slab = synth_volume(n, 512, seed=1, kind=kind)
+    sup_imgs, sup_masks = support_set(svol.to(dev), slab.to(dev))
+    return model, vol.to(dev), sup_imgs, sup_masks, n, slices, flagsets
+
+
+@pytest.mark.parametrize("cfg", [3, 4])
+def test_config_full_depth_vs_oracle_record(dev, cfg):
+    from protosam_amd.metrics import dice
+    from protosam_amd.runner import run_slices
+    gold = np.load(os.path.join(GOLD, f"fullsize_cfg{cfg}.npz"))
+    model, vol_d, sup_imgs, sup_masks, n, slices, flagsets = _volume_setup(dev, cfg)
+    worst = 0.0
+    for fname, fl in flagsets.items():
+        model.use_cca = fl["use_cca"]
+        for z in slices:
+            masks, _ = run_slices(model, vol_d, sup_imgs, sup_masks, [z], dev)       # per-slice ProtoSAM.forward
+            st = model.last_stats
+            k = f"z{z}_{fname}"
+            ref_prob = torch.from_numpy(gold[k + "_prob"].astype(np.float32) / 65535.0)
+            ref_scores = gold[k + "_scores"]
+            assert st["n_prompts"] == ref_prob.shape[0] == len(ref_scores), (st["n_prompts"], ref_prob.shape)
+            prob = torch.sigmoid(st["low_res"][:, st["sel"]].cpu())
+            perr = (prob - ref_prob).abs().max().item()
+            serr = float(np.abs(st["iou"][:, st["sel"]].cpu().numpy() - ref_scores).max())
+            ref_mask = _unpack(gold[k + "_mask"], 512)
+            d = dice(masks[0].cpu().float(), ref_mask)
+            flips = int((masks[0].cpu().float() != ref_mask).sum())
+            print(f"config {cfg} {fname} z={z}: {st['n_prompts']} comp, max |dprob(low_res)| {perr:.2e}, scores {serr:.2e}, "
+                  f"Dice {d:.5f} ({flips} px)")
+            worst = max(worst, perr)
+            assert perr <= TOL, (cfg, fname, z, perr)
+            assert serr <= TOL and d >= 0.998
+    print(f"config {cfg}: worst max |dprob(low_res)| {worst:.2e} (bound {TOL:.0e})")
+
+
+@pytest.mark.parametrize("cfg", [3, 4])
+def test_volume_runner_equals_per_slice_forward(dev, cfg):
+    """`run_slices` with 16-slice batches over the whole 32- / 64-slice volume == one `ProtoSAM.forward` per slice."""
+    from protosam_amd.metrics import dice
+    from protosam_amd.runner import run_slices
+    model, vol_d, sup_imgs, sup_masks, n, _, _ = _volume_setup(dev, cfg)
+    zs = list(range(n))
+    batched, st_b = run_slices(model, vol_d, sup_imgs, sup_masks, zs, dev, batch=16)
+    batched = batched.clone()
+    single, st_s = run_slices(model, vol_d, sup_imgs, sup_masks, zs, dev, batch=1)
+    assert st_b == st_s                                                   # same number of prompt sets on every slice
+    diff = (batched != single).flatten(1).sum(1).cpu()
+    ds = [dice(batched[z].cpu().float(), single[z].cpu().float()) for z in zs]
+    print(f"config {cfg}: {n} slices, worst per-slice difference {int(diff.max())} px, worst Dice {min(ds):.5f}, "
+          f"{sum(st_b)} prompt sets")
+    assert int(diff.max()) <= 16 and min(ds) >= 0.9995
+
+
+def test_config5_full_depth_vs_oracle_record(dev):
+    from oracle.make_fullsize_goldens import cfg5_inputs
+    from protosam_amd.grid_proto_fewshot import FewShotSeg
+    from protosam_amd.metrics import dice
+    from protosam_amd.protomedsam import ProtoMedSAM
+    from protosam_amd.protosam import ALPNetWrapper, InputFactory, TYPE_ALPNET
+    from protosam_amd.runner import ALP_CFG
+    from protosam_amd.synth import synth_state_dict
+    gold = np.load(os.path.join(GOLD, "fullsize_cfg5.npz"))
+    S = 1024
+    alp = FewShotSeg(S, None, dict(ALP_CFG))
+    alp.load_state_dict(synth_state_dict(alp, 1234))
+    alp = alp.to(dev).eval()
+    assert alp.config["feature_hw"] == [73, 73]
+    model = ProtoMedSAM((1024, 1024), ALPNetWrapper(alp), "random:vit_b:1234", use_cca=True).to(dev).eval()
+    s_img, s_masks, q_img = cfg5_inputs()
+    ran = 0
+    for ci, m in enumerate(s_masks):
+        inp = InputFactory.create_input(TYPE_ALPNET, q_img, support_images=[s_img], support_labels=[m], isval=True,
+                                        val_wsize=2)
+        inp.to(dev)
+        logits = alp(inp.supp_imgs, inp.fore_mask, inp.back_mask, inp.qry_imgs, True, 2)[0]
+        cp = logits.float().softmax(1)[0, 1, ::4, ::4].cpu()
+        cerr = (cp - torch.from_numpy(gold[f"class{ci}_coarse_p"].astype(np.float32) / 65535.0)).abs().max().item()
+        seg, conf = model(q_img.to(dev), inp)
+        ref_mask = _unpack(gold[f"class{ci}_mask"], S)
+        assert seg.shape == (S, S) and seg.dtype == torch.uint8
+        if f"class{ci}_prob" not in gold.files:                           # empty coarse mask for this class
+            assert int(seg.sum()) == 0 and cerr <= TOL
+            continue
+        ran += 1
+        prob = torch.sigmoid(model.last_stats["low_res"][:, 0].cpu())
+        perr = (prob - torch.from_numpy(gold[f"class{ci}_prob"].astype(np.float32) / 65535.0)).abs().max().item()
+        d = dice(seg.cpu().float(), ref_mask)
+        ce = float(np.abs(np.asarray(conf[0]) - gold[f"class{ci}_conf"]).max())
+        print(f"config 5 class {ci}: coarse prob err {cerr:.2e}, max |dprob(low_res)| {perr:.2e}, conf err {ce:.2e}, "
+              f"Dice {d:.5f} ({int((seg.cpu().float() != ref_mask).sum())} px of {int(ref_mask.sum())})")
+        assert cerr <= TOL and perr <= TOL and ce <= TOL and d >= 0.998
+    assert ran == 4

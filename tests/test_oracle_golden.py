@@ -164,3 +164,92 @@ def test_rotation_helpers(gold):
     assert [rh, rw] == gold["rotate_size"].tolist()
     _close(r, gold["rotate_out"], 1e-6)
     _close(orot.reverse_tensor(lg, rh, rw, -15), gold["rotate_back"], 1e-6)
+
+
+# ---- orchestration: the reference's own ProtoSAM.forward / SamPredictor / ProtoMedSAM.forward outputs ------------------
+@pytest.fixture(scope="module")
+def orch():
+    """Shared state of the orchestration replays: SAM state dict, query, the oracle's image embedding (computed once)."""
+    from oracle import glue, golden_inputs as gi, sam_image_encoder as oenc
+    from protosam_amd.segment_anything import sam_model_registry
+    from protosam_amd.synth import synth_state_dict
+    torch.set_num_threads(8)
+    sd = synth_state_dict(sam_model_registry["vit_b"](encoder_depth=gi.ORCH_SAM_DEPTH), gi.ORCH_SAM_SEED)
+    q = gi.orch_query()
+    q1024 = torch.nn.functional.interpolate(q, size=(1024, 1024), mode="bilinear")
+    with torch.no_grad():
+        feats = oenc.image_encoder(glue.sam_preprocess(glue.quantise_image(q1024)), sd, model_type="vit_b",
+                                   depth=gi.ORCH_SAM_DEPTH)
+    return dict(sd=sd, q=q, feats=feats)
+
+
+def _unpack(bits, shape):
+    return np.unpackbits(bits)[:shape[0] * shape[1]].reshape(shape).astype(bool)
+
+
+@pytest.mark.parametrize("name", ["default", "cca", "conf_pts", "centroid_box", "box_only", "mask", "mask_cca", "neg"])
+def test_protosam_forward_vs_reference_record(gold, orch, name):
+    """oracle/glue.protosam_forward == the reference's ProtoSAM.forward (models/ProtoSAM.py:536-678) run on CPU in the build
+    container for every flag set: final mask bit for bit, scores to 1e-5."""
+    from oracle import glue, golden_inputs as gi
+    kw = gi.ORCH_FLAGS[name]
+    with torch.no_grad():
+        pred, scores = glue.protosam_forward(orch["q"], gi.orch_coarse_logits(), orch["sd"], "vit_b", postprocess="batched",
+                                             encoder_depth=gi.ORCH_SAM_DEPTH, features=orch["feats"], **kw)
+    ref = _unpack(gold[f"orch_{name}_mask"], (gi.ORCH_SIZE, gi.ORCH_SIZE))
+    assert np.array_equal(pred.numpy().astype(bool), ref)
+    np.testing.assert_allclose(np.array(scores, dtype=np.float64), gold[f"orch_{name}_scores"], atol=1e-5, rtol=0)
+
+
+def test_protosam_edge_cases_vs_reference_record(gold, orch):
+    from oracle import glue, golden_inputs as gi
+    pred, scores = glue.protosam_forward(orch["q"], gi.orch_empty_logits(), orch["sd"], "vit_b", features=orch["feats"])
+    assert tuple(pred.shape) == (1024, 1024) and int(pred.sum()) == 0 and scores == [0]      # ProtoSAM.py:612-613
+    for use_cca in (False, True):                                                              # ProtoSAM.py:580-590
+        pred, conf = glue.coarse_pred_only(gi.orch_coarse_logits(), gi.ORCH_SIZE, use_cca)
+        rec = gold[f"orch_coarse_only_{int(use_cca)}"]
+        assert abs(conf[0] - rec[0]) < 1e-6 and int(torch.as_tensor(pred).sum()) == int(rec[1])
+
+
+def test_protomedsam_forward_vs_reference_record(gold, orch):
+    from oracle import glue, golden_inputs as gi
+    with torch.no_grad():
+        seg, conf = glue.protomedsam_forward(orch["q"], gi.orch_coarse_logits(), orch["sd"], "vit_b", use_cca=True,
+                                             encoder_depth=gi.ORCH_SAM_DEPTH)
+    ref = _unpack(gold["orch_medsam_mask"], (gi.ORCH_SIZE, gi.ORCH_SIZE))
+    assert int((seg.numpy().astype(bool) != ref).sum()) <= 2
+    np.testing.assert_allclose(np.asarray(conf[0]), gold["orch_medsam_conf"], atol=2e-5, rtol=0)
+    seg, conf = glue.protomedsam_forward(orch["q"], gi.orch_empty_logits(), orch["sd"], "vit_b", use_cca=True,
+                                         encoder_depth=gi.ORCH_SAM_DEPTH)
+    assert tuple(seg.shape) == (gi.ORCH_SIZE, gi.ORCH_SIZE) and int(seg.sum()) == 0 and conf == [0]   # ProtoMedSAM.py:194-197
+
+
+def test_predictor_vs_reference_record(gold, orch):
+    """oracle `predict` == the vendored SamPredictor.predict (predictor.py:92-241) on square / non-square images, with
+    points, boxes and mask inputs."""
+    from oracle import glue, golden_inputs as gi, sam_image_encoder as oenc, sam_prompt_decoder as odec
+    cache = {}
+    for name, hw, pc, pl, box, with_mask, mm, rl in gi.predictor_cases():
+        if hw not in cache:
+            rz = glue.apply_image(gi.predictor_image(hw))
+            with torch.no_grad():
+                cache[hw] = (oenc.image_encoder(glue.sam_preprocess(rz), orch["sd"], model_type="vit_b",
+                                                depth=gi.ORCH_SAM_DEPTH), tuple(rz.shape[:2]))
+        feats, in_size = cache[hw]
+        mk = gi.mask_prompt_case()[0].numpy() if with_mask else None
+        with torch.no_grad():
+            _, iou, low = odec.predict(orch["sd"], feats, pc, pl, box, mm, hw, variant="batched", mask_input=mk,
+                                       input_size=in_size)
+        np.testing.assert_allclose(iou.numpy(), gold[f"pred_{name}_iou"], atol=2e-5, rtol=0)
+        np.testing.assert_allclose(low[..., ::2, ::2].numpy(), gold[f"pred_{name}_low"].astype(np.float32), atol=2e-2, rtol=2e-3)
+
+
+def test_metric_vs_reference_record(gold):
+    from protosam_amd.metrics import dice, get_dice_iou_precision_recall
+    g = torch.Generator().manual_seed(9)
+    a = (torch.rand((64, 64), generator=g) > 0.6).float()
+    b = (torch.rand((64, 64), generator=g) > 0.5).float()
+    r = get_dice_iou_precision_recall(a, b)
+    np.testing.assert_array_equal(np.array([float(r[k]) for k in ("dice", "iou", "precision", "recall")]), gold["metric_vals"])
+    assert get_dice_iou_precision_recall(a, torch.zeros_like(b)) == {"dice": 0, "precision": 0, "recall": 0}
+    assert dice(a, a) > 0.999999 and dice(torch.zeros(4, 4), torch.zeros(4, 4)) == 1.0

@@ -1,0 +1,132 @@
+"""GPU: the HIP path against outputs RECORDED FROM THE REFERENCE ITSELF (tests/golden/reference_outputs.npz, written by
+oracle/validate_against_reference.py running /root/reference's ProtoSAM.forward, ProtoMedSAM.forward and SamPredictor on
+CPU in the build container). No oracle in between: final masks, scores and low-res logits of the reference are the target.
+The recorded runs use the vendored registry (`SamBatched`: bilinear align_corners=True post-processing), ViT-B truncated to
+two blocks, and given coarse logits (oracle/golden_inputs.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_outputs.npz")
+TOL_PROB = 1e-3          # north-star tolerance on the output probability map, sigmoid(low_res_masks)
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+class FixedCoarse:
+    """Coarse-model stand-in returning given logits (the reference run used the same stand-in)."""
+
+    def __init__(self, logits):
+        self.logits = logits
+
+    def __call__(self, inp):
+        return self.logits.clone()
+
+
+def _unpack(bits, shape):
+    return torch.from_numpy(np.unpackbits(bits)[:shape[0] * shape[1]].reshape(shape).astype(np.float32))
+
+
+def _model(dev, cls, **kw):
+    from oracle import golden_inputs as gi
+    spec = f"random:vit_b:{gi.ORCH_SAM_SEED}:{gi.ORCH_SAM_DEPTH}"
+    m = cls((1024, 1024), FixedCoarse(gi.orch_coarse_logits().to(dev)), spec, **kw).to(dev).eval()
+    sam = getattr(m, "sam", None) or m.medsam
+    sam.postprocess_variant = "batched"      # what the vendored registry builds (build_sam.py:66)
+    return m
+
+
+@pytest.mark.parametrize("name", ["default", "cca", "conf_pts", "centroid_box", "box_only", "mask", "mask_cca", "neg"])
+def test_protosam_forward_vs_reference(dev, gold, name):
+    from oracle import golden_inputs as gi
+    from protosam_amd.metrics import dice
+    from protosam_amd.protosam import InputFactory, ProtoSAM, TYPE_ALPNET
+    kw = gi.ORCH_FLAGS[name]
+    model = _model(dev, ProtoSAM, num_points_for_sam=1, use_sam_trans=True, **kw)
+    q = gi.orch_query().to(dev)
+    inp = InputFactory.create_input(TYPE_ALPNET, q, support_images=[q], support_labels=[torch.zeros(1, 512, 512)],
+                                    isval=True, val_wsize=2)
+    pred, scores = model(q, inp, degrees_rotate=0)
+    ref = _unpack(gold[f"orch_{name}_mask"], (512, 512))
+    ref_scores = gold[f"orch_{name}_scores"]
+    assert pred.shape == (512, 512) and len(scores) == len(ref_scores)
+    d = dice(pred.cpu(), ref)
+    flips = int((pred.cpu() != ref).sum())
+    serr = float(np.abs(np.array(scores, dtype=np.float64) - ref_scores).max())
+    st = model.last_stats
+    low = st["low_res"].cpu()                                   # [P, 4, 256, 256] (mask token 0 + the three multimask ones)
+    ref_low = torch.from_numpy(gold[f"orch_{name}_low"].astype(np.float32))   # [P, C, 64, 64]: every 4th pixel
+    sl = low[:, 1:] if ref_low.shape[1] == 3 else low[:, 0:1]
+    # the record is fp16: 2^-11 relative on a logit is <= 2.5e-4 on the probability at |logit| < 1, less beyond
+    perr = (torch.sigmoid(sl[..., ::4, ::4]) - torch.sigmoid(ref_low)).abs().max().item()
+    print(f"{name}: {len(scores)} prompt sets, Dice vs REFERENCE {d:.5f} ({flips} px), scores {serr:.2e}, "
+          f"max |dprob(low_res)| {perr:.2e}")
+    assert d > 0.999 and serr < 1e-3 and perr < TOL_PROB + 2.5e-4
+
+
+def test_protosam_edge_cases_vs_reference(dev, gold):
+    from oracle import golden_inputs as gi
+    from protosam_amd.protosam import InputFactory, ProtoSAM, TYPE_ALPNET
+    q = gi.orch_query().to(dev)
+    inp = InputFactory.create_input(TYPE_ALPNET, q, support_images=[q], support_labels=[torch.zeros(1, 512, 512)],
+                                    isval=True, val_wsize=2)
+    m = _model(dev, ProtoSAM, use_bbox=True, use_points=True, point_mode="both")
+    m.coarse_segmentation_model = FixedCoarse(gi.orch_empty_logits().to(dev))
+    pred, scores = m(q, inp)
+    assert tuple(pred.shape) == (1024, 1024) and int(pred.sum()) == 0 and scores == [0]
+    for use_cca in (False, True):
+        m = _model(dev, ProtoSAM, use_bbox=True, use_points=True, coarse_pred_only=True, use_cca=use_cca)
+        pred, conf = m(q, inp)
+        rec = gold[f"orch_coarse_only_{int(use_cca)}"]
+        assert tuple(pred.shape) == (512, 512) and abs(float(conf[0]) - rec[0]) < 1e-5 and int(pred.sum()) == int(rec[1])
+
+
+def test_protomedsam_forward_vs_reference(dev, gold):
+    from oracle import golden_inputs as gi
+    from protosam_amd.metrics import dice
+    from protosam_amd.protomedsam import ProtoMedSAM
+    from protosam_amd.protosam import InputFactory, TYPE_ALPNET
+    q = gi.orch_query().to(dev)
+    inp = InputFactory.create_input(TYPE_ALPNET, q, support_images=[q], support_labels=[torch.zeros(1, 512, 512)],
+                                    isval=True, val_wsize=2)
+    m = _model(dev, ProtoMedSAM, use_cca=True)
+    seg, conf = m(q, inp)
+    ref = _unpack(gold["orch_medsam_mask"], (512, 512))
+    d = dice(seg.cpu().float(), ref)
+    cerr = float(np.abs(np.asarray(conf[0]) - gold["orch_medsam_conf"]).max())
+    print(f"ProtoMedSAM vs REFERENCE: Dice {d:.5f} ({int((seg.cpu().float() != ref).sum())} px), conf err {cerr:.2e}")
+    assert seg.dtype == torch.uint8 and d > 0.999 and cerr < 1e-3
+    m.coarse_segmentation_model = FixedCoarse(gi.orch_empty_logits().to(dev))
+    seg, conf = m(q, inp)
+    assert tuple(seg.shape) == (512, 512) and int(seg.sum()) == 0 and conf == [0]
+
+
+def test_predictor_vs_reference(dev, gold):
+    """SamPredictor.set_image / predict (predictor.py:34-241) on square and non-square images against the vendored
+    predictor's recorded low-res logits and IoU predictions."""
+    from oracle import golden_inputs as gi
+    from protosam_amd.segment_anything import SamPredictor, sam_model_registry
+    from protosam_amd.synth import synth_state_dict
+    sam = sam_model_registry["vit_b"](encoder_depth=gi.ORCH_SAM_DEPTH)
+    sam.load_state_dict(synth_state_dict(sam, gi.ORCH_SAM_SEED))
+    sam = sam.to(dev).eval()
+    sam.postprocess_variant = "batched"
+    p = SamPredictor(sam)
+    for name, hw, pc, pl, box, with_mask, mm, rl in gi.predictor_cases():
+        p.set_image(gi.predictor_image(hw))
+        mk = gi.mask_prompt_case()[0].numpy() if with_mask else None
+        masks, iou, low = p.predict(point_coords=pc, point_labels=pl, box=box, mask_input=mk, multimask_output=mm,
+                                    return_logits=rl)
+        assert masks.shape == (3 if mm else 1,) + tuple(hw) and masks.dtype == (np.float32 if rl else np.bool_)
+        ref_low = torch.from_numpy(gold[f"pred_{name}_low"].astype(np.float32))
+        perr = (torch.sigmoid(torch.from_numpy(low)[..., ::2, ::2]) - torch.sigmoid(ref_low)).abs().max().item()
+        ierr = float(np.abs(iou - gold[f"pred_{name}_iou"]).max())
+        print(f"predictor {name}: max |dprob(low_res)| {perr:.2e}, iou err {ierr:.2e}")
+        assert perr < TOL_PROB + 2.5e-4 and ierr < 1e-3

@@ -64,3 +64,63 @@ def test_part_assignment_and_support_set():
     vol = torch.arange(9.0).view(9, 1, 1).expand(9, 4, 4).contiguous()
     imgs, masks = support_set(vol, vol)
     assert [int(i[0, 0, 0, 0]) for i in imgs] == [1, 4, 7] and imgs[0].shape == (1, 3, 4, 4) and masks[0].shape == (1, 4, 4)
+
+
+def _bench_worker(rank, world, port, B, n_slices, steps, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    from protosam_amd.runner import gather_masks, part_assign
+    parts = [[z for z in range(n_slices) if part_assign(z, n_slices) == pt] for pt in range(3)]
+    ok = True
+    for s in range(steps):
+        zs = bench.step_slices(s, parts, B, world, rank)
+        local = torch.stack([_fake_mask(z) for z in zs])
+        full = gather_masks(local, world)                                  # rank-major [world*B, S, S]
+        all_zs = [z for r in range(world) for z in bench.step_slices(s, parts, B, world, r)]
+        one_rank = bench.step_slices(s, parts, B * world, 1, 0)            # the same window on ONE rank with batch world*B
+        ok &= sorted(all_zs) == sorted(one_rank)
+        ok &= all(torch.equal(full[i], _fake_mask(z)) for i, z in enumerate(all_zs))
+        ok &= len({z for z in zs}) == len(zs) or len(parts[s % 3]) < B * world   # no slice twice unless the part wraps
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_bench_step_indexing_world2_equals_single_rank():
+    """bench.py's N > 1 step indexing: the window of step s gathered from 2 ranks (z = r mod 2) holds exactly the slices a
+    1-rank run with twice the batch processes in step s, each rank's rows where the all-gather puts them."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, 8, 64, 7, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)
+
+
+def test_bench_launches_its_own_ranks(monkeypatch, capsys):
+    """`python bench.py --gpus N` without a launcher starts N ranks through torch.distributed.run BEFORE touching the GPU and
+    relays rank 0's line (the command is intercepted here: there is no GPU in the build container)."""
+    import subprocess
+    import sys
+    import bench
+    seen = {}
+
+    def fake_run(cmd, env=None, stdout=None, text=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return subprocess.CompletedProcess(cmd, 0, stdout='noise\n{"metric": "m", "n_gpus": 4}\n')
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert capsys.readouterr().out.strip() == '{"metric": "m", "n_gpus": 4}'
+    assert "torch.cuda" not in str(getattr(bench, "__dict__", {}).get("torch", ""))   # parent path imports no torch at module level
