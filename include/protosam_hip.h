@@ -58,6 +58,8 @@ int psam_layernorm(const float* x, const float* w, const float* b, void* y, floa
 int psam_attention_f16(const void* qkv, void* out, const float* rel_h, const float* rel_w, const void* relq,
                        const void* rpack, const void* pad_row, int B, int N, int H, int hd, float scale, int mode, int gh,
                        int gw, int ws, int head_major, void* stream);
+/* softmax code path of psam_attention_f16: 1 = V2 (default), 0 = the serial round-1 form (A/B, tests) */
+int psam_attention_set_variant(int v);
 
 /* rel_h[b,h,n,k] = q . Rh[qy - k + K-1], rel_w likewise (UNSCALED q), as an MFMA GEMM against the whole table followed by
  * a scatter. Rpack half [2 (h,w)][2 (hi,lo)][RP][HDP] (RP = 128 global / 32 windowed, zero padded).

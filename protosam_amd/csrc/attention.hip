@@ -54,7 +54,10 @@ struct AttnArgs {
 // cross-address-space memcpys that keep the staging array in memory (promoted to LDS / scratch)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-template <int HD, int MODE, int NW, bool FULL = false>
+// V2: softmax section restructured for instruction-level parallelism (see compute_tile). Both forms are kept selectable
+// (PSAM_ATTN_V2=0/1) for within-process A/B; they agree to rounding (the row sum of V2 is taken over the fp16-rounded
+// probabilities that enter the PV product, by the matrix pipe).
+template <int HD, int MODE, int NW, bool FULL = false, bool V2 = false>
 // HIP's second launch-bound argument is the minimum number of WAVES PER SIMD (not CUDA's blocks per multiprocessor): the
 // 7-wave window kernel needs 4 per SIMD (<= 128 VGPRs) for two workgroups to be co-resident on a CU
 __global__ __launch_bounds__(NW * 64, (MODE == 2 ? 4 : 2)) void attn_kernel(AttnArgs p) {
@@ -361,6 +364,12 @@ __global__ __launch_bounds__(NW * 64, (MODE == 2 ? 4 : 2)) void attn_kernel(Attn
   const float sl2 = p.scale * LOG2E;
   float mrun[2] = {-INFINITY, -INFINITY};
   float lrun[2] = {0.f, 0.f};
+  // V2: row sums on the matrix pipe, l^T += 1 . P^T (every row of the 16 x 16 result holds the complete sum over the 32 keys of
+  // the k-step, all four lane groups included), rescaled together with O^T
+  f32x4 lt[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  half8_t ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (half_t)1.f;
 
   if (!(p.dbg & 1)) load_tile(0);
   __syncthreads();  // pad-column zeroing + rel tables visible
@@ -417,6 +426,7 @@ __global__ __launch_bounds__(NW * 64, (MODE == 2 ? 4 : 2)) void attn_kernel(Attn
 #pragma unroll
         for (int e = 0; e < 8; ++e) pf[qt][NTT / 2][e] = (half_t)0.f;
     }
+    if constexpr (!V2) {
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       // bias that is constant over this lane's keys of the tile is added to the row max instead of to every element
@@ -471,8 +481,77 @@ __global__ __launch_bounds__(NW * 64, (MODE == 2 ? 4 : 2)) void attn_kernel(Attn
       }
       lrun[qt] += ps;
     }
+    } else {
+      // One straight-line block for BOTH query tiles: the per-tile decision is a single wave-uniform branch (alpha == 1 for
+      // rows that did not grow), so the two tiles' max / exp / convert chains interleave; maxima and sums are reduced as
+      // trees (the serial `ps += pv` / `mx = max(mx, sv)` chains were 16 dependent operations per tile with two waves per
+      // SIMD to hide them); the row sum itself is left to the matrix pipe (below).
+      float bh2[2] = {0.f, 0.f}, mx[2];
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        if (MODE == 1) bh2[qt] = relh_q[qt][kbase / KT] * LOG2E;
+        float mt[NTT];
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) {
+          float4 rw4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (MODE == 1)
+            rw4 = *reinterpret_cast<const float4*>(
+                &relw_s[(wv * 32 + qt * 16 + li) * RWLD + ((((tt >> 1) * 8 + g * 2 + (tt & 1)) ^ li) << 2)]);
+          const float rwv[4] = {rw4.x, rw4.y, rw4.z, rw4.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float sv = MODE == 1 ? fmaf(st[tt][qt][r], sl2, rwv[r]) : st[tt][qt][r] * sl2;
+            if (!FULL && last_partial) {
+              const int kidx = kbase + (tt >> 1) * 32 + g * 8 + (tt & 1) * 4 + r;
+              if (kidx >= nkeys) sv = -INFINITY;
+            }
+            st[tt][qt][r] = sv;
+          }
+          mt[tt] = fmaxf(fmaxf(st[tt][qt][0], st[tt][qt][1]), fmaxf(st[tt][qt][2], st[tt][qt][3]));
+        }
+        float m = mt[0];
+        if constexpr (NTT == 2) m = fmaxf(mt[0], mt[1]);
+        if constexpr (NTT == 4) m = fmaxf(fmaxf(mt[0], mt[1]), fmaxf(mt[2], mt[3]));
+        mx[qt] = m;
+      }
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        mx[qt] = fmaxf(mx[qt], __shfl_xor(mx[qt], 16, 64));
+        mx[qt] = fmaxf(mx[qt], __shfl_xor(mx[qt], 32, 64));
+        mx[qt] += bh2[qt];
+      }
+      if (!__all(mx[0] <= mrun[0] + RESCALE_THR && mx[1] <= mrun[1] + RESCALE_THR)) {
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          const float mnew = fmaxf(mrun[qt], mx[qt]);
+          const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
+          mrun[qt] = mnew;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lt[qt][r] *= alpha;
+#pragma unroll
+          for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ot[d][qt][r] *= alpha;
+        }
+      }
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        const float moff = mrun[qt] - bh2[qt];  // exp2(sv + bh2 - mrun)
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            pf[qt][tt >> 1][(tt & 1) * 4 + r] = (half_t)__builtin_amdgcn_exp2f(st[tt][qt][r] - moff);
+      }
+    }
 
     // O^T += V^T P^T
+    if constexpr (V2) {
+#pragma unroll
+      for (int s2 = 0; s2 < (NTT + 1) / 2; ++s2)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) lt[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf[qt][s2], lt[qt], 0, 0, 0);
+    }
 #pragma unroll
     for (int d = 0; d < DT; ++d) {
 #pragma unroll
@@ -508,9 +587,14 @@ __global__ __launch_bounds__(NW * 64, (MODE == 2 ? 4 : 2)) void attn_kernel(Attn
   // ---- normalise and store: lane holds O^T[d = dt*16 + g*4 + r][q = li] ---------------------------
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
-    float l = lrun[qt];
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    float l;
+    if constexpr (V2) {
+      l = lt[qt][0];      // complete row sum of query column li (identical in the four rows and lane groups)
+    } else {
+      l = lrun[qt];
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+    }
     const float inv = 1.0f / l;
     if (qvalid[qt]) {
       half_t* op = p.out + ((size_t)b * N + qtok[qt]) * ((size_t)H * HD) + (size_t)h * HD;
@@ -524,13 +608,20 @@ __global__ __launch_bounds__(NW * 64, (MODE == 2 ? 4 : 2)) void attn_kernel(Attn
   }
 }
 
-template <int HD>
+static int g_attn_v2 = -1;
+extern "C" int psam_attention_set_variant(int v) {   // 0: serial softmax chains (round 1), 1: V2 (default); A/B and tests
+  g_attn_v2 = v ? 1 : 0;
+  return PSAM_OK;
+}
+
+template <int HD, bool V2>
 static int launch_attn(AttnArgs p, int mode, hipStream_t s) {
   if (mode == 2) {
     constexpr int NW = 7;
     p.nqb = 1;
     const int groups8 = (p.B * p.nwin + 7) / 8;
-    hipLaunchKernelGGL((attn_kernel<HD, 2, NW>), dim3(groups8 * 8 * p.H), dim3(NW * 64), 0, s, p);
+    // the window kernel sits at its 128-VGPR budget (two workgroups per CU): V2's extra live state spills there, so it keeps V1
+    hipLaunchKernelGGL((attn_kernel<HD, 2, NW, false, false>), dim3(groups8 * 8 * p.H), dim3(NW * 64), 0, s, p);
   } else {
     constexpr int NW = 4;
     p.nqb = (p.N + NW * 32 - 1) / (NW * 32);
@@ -538,11 +629,11 @@ static int launch_attn(AttnArgs p, int mode, hipStream_t s) {
     dim3 grid(groups8 * 8 * p.nqb), block(NW * 64);
     const bool full = (p.N % 64) == 0;
     if (mode == 1) {
-      if (full) hipLaunchKernelGGL((attn_kernel<HD, 1, NW, true>), grid, block, 0, s, p);
-      else hipLaunchKernelGGL((attn_kernel<HD, 1, NW>), grid, block, 0, s, p);
+      if (full) hipLaunchKernelGGL((attn_kernel<HD, 1, NW, true, V2>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((attn_kernel<HD, 1, NW, false, V2>), grid, block, 0, s, p);
     } else {
-      if (full) hipLaunchKernelGGL((attn_kernel<HD, 0, NW, true>), grid, block, 0, s, p);
-      else hipLaunchKernelGGL((attn_kernel<HD, 0, NW>), grid, block, 0, s, p);
+      if (full) hipLaunchKernelGGL((attn_kernel<HD, 0, NW, true, V2>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((attn_kernel<HD, 0, NW, false, V2>), grid, block, 0, s, p);
     }
   }
   return psam_launch_status();
@@ -587,8 +678,14 @@ extern "C" int psam_attention_f16(const void* qkv, void* out, const float* rel_h
     p.nwin = p.nwx * ((gh + ws - 1) / ws);
   }
   hipStream_t s = (hipStream_t)stream;
-  if (hd == 64) return launch_attn<64>(p, mode, s);
-  if (hd == 80) return launch_attn<80>(p, mode, s);
+  if (g_attn_v2 < 0) { const char* e = getenv("PSAM_ATTN_V2"); g_attn_v2 = e ? (atoi(e) != 0) : 1; }
+  if (g_attn_v2) {
+    if (hd == 64) return launch_attn<64, true>(p, mode, s);
+    if (hd == 80) return launch_attn<80, true>(p, mode, s);
+  } else {
+    if (hd == 64) return launch_attn<64, false>(p, mode, s);
+    if (hd == 80) return launch_attn<80, false>(p, mode, s);
+  }
   return PSAM_ERR_ARG;
 }
 

@@ -239,6 +239,11 @@ def attention(qkv, B, N, H, hd, scale, out=None, mode=0, rel_h=None, rel_w=None,
     return out
 
 
+def attention_set_variant(v):
+    """1 = V2 softmax (default), 0 = round-1 serial form; for A/B and the equivalence test."""
+    _lib.check(_lib.lib().psam_attention_set_variant(int(v)), "psam_attention_set_variant")
+
+
 def pack_rel_tables(rel_pos_h, rel_pos_w, windowed, hd):
     """fp32 (2K-1, hd) tables -> fp16 [2 (h,w)][2 (hi,lo)][RP][HDP] for psam_relpos (one-time weight packing)."""
     RP = 32 if windowed else 128

@@ -280,3 +280,36 @@ def test_window_attention_fused_relpos(dev):
         err = (a.float() - b.float()).abs().max().item()
         print(f"H{H} hd{hd}: fused vs two-kernel max abs diff {err:.2e}")
         assert err < 2e-3 and torch.isfinite(b.float()).all()
+
+
+@pytest.mark.parametrize("mode,N,H,hd,B", [(0, 1297, 12, 64, 2), (0, 200, 3, 80, 1), (1, 4096, 2, 80, 1), (1, 4096, 2, 64, 1)])
+def test_attention_softmax_variants_agree(dev, mode, N, H, hd, B):
+    """V2 (tree reductions, one rescale decision for both query tiles, row sums on the matrix pipe) against the round-1 serial
+    form and the fp32 reference, including rows whose maximum jumps late in the key sequence (the lazy-rescale branch: a key
+    aligned with a query far beyond the 2^8 threshold, guide rule 26) and jumps that hit only ONE of a wave's two query tiles."""
+    from protosam_amd import ops
+    qkv = _rand((B, N, 3, H, hd), dev, 0.5, 31)
+    for (qi, ki, gain) in ((17, N - 70, 40.0), (40, 130, 25.0), (N - 3, N // 2, 60.0)):   # rows 17 / 40: tiles 0 / 1 of wave 0
+        qkv[0, ki, 1, 0] = qkv[0, qi, 0, 0] * gain
+    qkv = qkv.half()
+    scale = hd ** -0.5
+    kw, rel = {}, None
+    if mode == 1:
+        g = 64
+        rel_h = _rand((B, H, N, g), dev, 0.7, 32)
+        rel_w = _rand((B, H, N, g), dev, 0.7, 33)
+        rel_h[0, 0, 100, 50] = 30.0                                                        # a spike in the bias itself
+        kw = dict(mode=1, rel_h=rel_h, rel_w=rel_w, gh=g, gw=g)
+        rel = (rel_h.view(B, H, N, g, 1) + rel_w.view(B, H, N, 1, g)).reshape(B, H, N, N)
+    outs = []
+    for v in (0, 1):
+        ops.attention_set_variant(v)
+        try:
+            outs.append(ops.attention(qkv, B, N, H, hd, scale, **kw).float())
+        finally:
+            ops.attention_set_variant(1)
+    ref = _ref_attn_global(qkv, B, N, H, hd, scale, rel=rel)
+    for o in outs:
+        assert torch.isfinite(o).all()
+        torch.testing.assert_close(o, ref, rtol=2e-3, atol=2e-3)
+    assert (outs[0] - outs[1]).abs().max().item() < 2e-3
