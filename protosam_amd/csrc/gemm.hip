@@ -1819,6 +1819,178 @@ static void launch8kp(const GemmArgs& p, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Tile 14: tile 11 with TWO phases of 16 MFMAs per K-tile instead of four of 8 (same 256x256x64 macro tile, 8 waves as 2 x 4,
+// wave tile 128x64, same ring, persistent walk and epilogues; results bit-identical to tiles 10 / 11: every accumulator sees
+// its k16 steps in the same order).
+// Why: per barrier interval one wave row issues MFMAs (8 x 32 = 256 cycles in tile 11) while the other reads fragments and
+// issues DMA; the measured interval is ~370 cycles, and the part above 256 is per-interval latency (the load row's LDS read
+// latency + DMA issue + the barrier hand-off), not throughput - an interval with nothing but its barriers costs ~250 cycles
+// (tools/abl_matrix.sh). Twice the work per interval amortises it: 512 MFMA cycles against 16 / 8 ds_read_b128 + 4 DMA.
+//   phase A(t): MFMA rows 0..63 of the wave tile x 64 columns x K = 64   (16 MFMA; A0, B0, B1 fragments: 16 ds_read_b128)
+//   phase B(t): MFMA rows 64..127                                       (16 MFMA; A1 fragments: 8 reads, B fragments kept)
+// DMA issue (two half-tiles per load part, in consumption order, 4 - 6 intervals ahead of the first read):
+//   load A(t): B0(t+1) B1(t+1)      load B(t): A1(t+1) A0(t+2)          prologue: A0(0) B0(0) B1(0) A1(0) A0(1)
+// Counted waits at the END of a load part, before its barrier (what the NEXT load part reads has landed for every wave once
+// the barrier is passed): after load A vmcnt(6) - only A0(t+1) and this part's four stay in flight, A1(t) is in; after load B
+// vmcnt(4). lgkmcnt(0) also sits BEFORE the barrier: the lagging wave row's reads of A0(t) retire before the leading row,
+// one interval later, refills that half-tile with A0(t+2).
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm8q_f16_kernel(GemmArgs p, int total) {
+  extern __shared__ __attribute__((aligned(16))) half_t ring[];  // [buf 2][A0 A1 B0 B1][128][64] + 8 x 4 KiB slabs
+  constexpr int HT = 128 * 64;
+  const int ntn = p.N / 256;
+  const int ntm = (p.M + 255) / 256;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = wv >> 2, wc = wv & 3;
+  const int lr = lane & 31, lg = lane >> 5;
+  half_t* slab = ring + 8 * HT + wv * 2048;
+  const int nk = p.K / 64;
+  const unsigned bh = 32u * (unsigned)p.ldw;
+  const int arow0 = wr * 64 + lr, brow0 = wc * 32 + lr;
+
+  int idx = blockIdx.x, tm = 0, tn = 0;
+  while (idx < total && !tile_map(idx, ntm, ntn, p.map_mode, tm, tn)) idx += gridDim.x;
+  if (idx >= total) return;
+
+  unsigned aoff[2][2], boff[2];
+  auto offsets = [&](int m0, int n0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int lrow = j * 64 + (t >> 3);
+      const int chunk = (t & 7) ^ ((lrow >> 1) & 7);
+      const int arow = (lrow >> 6) * 128 + (lrow & 63);
+      const int brow = (lrow >> 5) * 64 + (lrow & 31);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int am = m0 + arow + h * 64;
+        am = am < p.M ? am : p.M - 1;
+        aoff[j][h] = (unsigned)am * (unsigned)p.lda + chunk * 8;
+      }
+      boff[j] = (unsigned)(n0 + brow) * (unsigned)p.ldw + chunk * 8;
+    }
+  };
+  auto stage = [&](int which, int kt) {  // 0 A0, 1 A1, 2 B0, 3 B1
+    half_t* dst = ring + ((kt & 1) * 4 + which) * HT + wv * 512;
+    const int h = which & 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const half_t* g = which < 2 ? p.A + (aoff[j][h] + (unsigned)kt * 64u) : p.W + (boff[j] + h * bh + (unsigned)kt * 64u);
+      glds16(g, dst + j * 4096);
+    }
+  };
+  auto prologue = [&]() {
+    stage(0, 0); stage(2, 0); stage(3, 0); stage(1, 0);
+    if (nk > 1) stage(0, 1);
+  };
+
+  offsets(tm * 256, tn * 256);
+  prologue();
+
+  half8_t fa[2][4];   // [i][k16]
+  half8_t fb[2][4];   // [b][k16]
+
+#define RDQ_A(bufp, h)                                                                                            \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int k4 = 0; k4 < 4; ++k4)                   \
+      fa[i][k4] = *reinterpret_cast<const half8_t*>(&(bufp)[(h) * HT + lds_off64(arow0 + i * 32, k4 * 2 + lg)]);
+#define RDQ_B(bufp)                                                                                               \
+  _Pragma("unroll") for (int b = 0; b < 2; ++b) _Pragma("unroll") for (int k4 = 0; k4 < 4; ++k4)                   \
+      fb[b][k4] = *reinterpret_cast<const half8_t*>(&(bufp)[(2 + b) * HT + lds_off64(brow0, k4 * 2 + lg)]);
+#define MMAQ(a)                                                                                                   \
+  _Pragma("unroll") for (int k4 = 0; k4 < 4; ++k4) _Pragma("unroll") for (int i = 0; i < 2; ++i)                   \
+      _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                               \
+          acc[a][i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[b][k4], fa[i][k4], acc[a][i][b], 0, 0, 0);
+#define Q_SYNC_IN()                                       \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+  __builtin_amdgcn_sched_barrier(0);                      \
+  __builtin_amdgcn_s_barrier();                           \
+  __builtin_amdgcn_sched_barrier(0);                      \
+  __builtin_amdgcn_s_setprio(1);
+#define Q_SYNC_OUT()                                      \
+  __builtin_amdgcn_s_setprio(0);                          \
+  __builtin_amdgcn_sched_barrier(0);                      \
+  __builtin_amdgcn_s_barrier();                           \
+  asm volatile("" ::: "memory");
+
+  bool first = true;
+  for (;;) {
+    const int m0 = tm * 256, n0 = tn * 256;
+    f32x16 acc[2][2][2];  // [a][i][b]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][i][b][r] = 0.f;
+
+    // first tile: A0(0) B0(0) B1(0) have landed, A1(0) A0(1) may still fly. Later tiles: see tile 11 (stores and loads share
+    // the counter, so wait for all; the DMAs landed during the epilogue)
+    if (first) { if (nk > 1) wait_vmcnt<4>(); else wait_vmcnt<2>(); } else { wait_vmcnt<0>(); }
+    first = false;
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger the second wave row by one barrier
+    asm volatile("" ::: "memory");
+
+    for (int kt = 0; kt < nk; ++kt) {
+      const half_t* buf = ring + (kt & 1) * 4 * HT;
+      const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+      // ---- load A: B0 B1 A0 fragments of K-tile kt; DMA B0 B1 of kt + 1
+      RDQ_B(buf) __builtin_amdgcn_sched_barrier(0); RDQ_A(buf, 0) __builtin_amdgcn_sched_barrier(0);
+      if (more1) { stage(2, kt + 1); stage(3, kt + 1); }
+      if (more1) wait_vmcnt<6>(); else wait_vmcnt<0>();
+      Q_SYNC_IN();
+      MMAQ(0)
+      Q_SYNC_OUT();
+      // ---- load B: A1 fragments; DMA A1 of kt + 1, A0 of kt + 2
+      RDQ_A(buf, 1) __builtin_amdgcn_sched_barrier(0);
+      if (more1) stage(1, kt + 1);
+      if (more2) stage(0, kt + 2);
+      if (more2) { wait_vmcnt<4>(); } else if (more1) { wait_vmcnt<2>(); } else { wait_vmcnt<0>(); }
+      Q_SYNC_IN();
+      MMAQ(1)
+      Q_SYNC_OUT();
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the stagger: every wave is done with the ring here
+
+    // next tile of this workgroup: request its first half-tiles now
+    int nidx = idx + gridDim.x, ntm_ = 0, ntn_ = 0;
+    while (nidx < total && !tile_map(nidx, ntm, ntn, p.map_mode, ntm_, ntn_)) nidx += gridDim.x;
+    const bool have = nidx < total;
+    if (have) {
+      offsets(ntm_ * 256, ntn_ * 256);
+      prologue();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    persist_epilogue<EPI>(acc, slab, m0 + wr * 128, n0 + wc * 64, lane, p);
+    if (!have) break;
+    idx = nidx; tm = ntm_; tn = ntn_;
+  }
+#undef RDQ_A
+#undef RDQ_B
+#undef MMAQ
+#undef Q_SYNC_IN
+#undef Q_SYNC_OUT
+}
+
+template <int EPI>
+static void launch8q(const GemmArgs& p, hipStream_t s) {
+  constexpr int LDS = 2 * 4 * 128 * 64 * 2 + 8 * 4096;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm8q_f16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr = true;
+  }
+  const int ntm = (p.M + 255) / 256, ntn = p.N / 256;
+  GemmArgs q = p;
+  q.map_mode = pick_map_mode(ntm, ntn);
+  const int total = tile_map_grid(ntm, ntn, q.map_mode);
+  hipLaunchKernelGGL((gemm8q_f16_kernel<EPI>), dim3(total < 256 ? total : 256), dim3(512), LDS, s, q, total);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Tile 13: FOUR waves (one per SIMD), 128x128 wave tiles, same 256x256x64 macro tile, DMA ring and persistent walk as tile
 // 11. Why: tools/micro/mfma_shadow_bench.hip - one wave per SIMD, back-to-back 32x32x16 MFMAs with this kernel's load mix
 // in their shadows (2 ds_read_b128 + 1 LDS-DMA per 4 MFMAs, two fragment sets alternating without copies) runs 35.3
@@ -2047,7 +2219,10 @@ static int pick_tile(int M, int N, int K, int epilogue) {
     // 256-tiles fill their rounds completely (65536x1280x1280: 603 vs 525 TFLOP/s; 32768x1280x1280, 2.5 rounds: 653 vs 689)
     const bool short_f32 = epilogue == EPI_F32 && K < 2048;
     // 10 = 8-phase with K-split phases (7 = its quadrant-phase predecessor); 11 = its persistent form (fp16 outputs)
-    if (K >= 1024 && t256 * 100 >= rounds * 256 * (short_f32 ? 95 : 80)) {
+    // K >= 768: DINOv2-B's shapes at 16 slices (M = 20752) measured 5-45 % faster on the persistent 256-tile kernel than on the
+    // 128-tile one (tools/gemm_tiles.py 1,11: qkv 790-820 vs 750, proj 730-760 vs 500-620, fc1 870 vs 740 TFLOP/s; fp32 epilogue
+    // 557 vs 497); per-slice calls (M = 1297) fail the fill test and stay on the 128-tile kernel (350 vs 200)
+    if (K >= 768 && t256 * 100 >= rounds * 256 * (short_f32 ? 95 : 80)) {
       static int f32p = -1;
       if (f32p < 0) { const char* e = getenv("PSAM_GEMM_F32_PERSIST"); f32p = e ? atoi(e) : 1; }
       return epilogue == EPI_F32 && !f32p ? 10 : 11;
@@ -2091,10 +2266,10 @@ static int gemm_dispatch(const void* A, const void* W, const float* bias, void* 
   dim3 grid(tile_map_grid(ntm, ntn, p.map_mode)), block(256);
   hipStream_t s = (hipStream_t)stream;
   int tsel = epilogue == EPI_RELU_F16 ? 1 : pick_tile(M, N, K, epilogue);
-  if (head_hd && tsel != 1 && tsel != 7 && tsel != 8 && tsel != 10 && tsel != 11 && tsel != 13) tsel = 1;   // the head-major store lives in the staged epilogue  // the ReLU epilogue lives in the 128x128 kernel
+  if (head_hd && tsel != 1 && tsel != 7 && tsel != 8 && tsel != 10 && tsel != 11 && tsel != 13 && tsel != 14) tsel = 1;   // the head-major store lives in the staged epilogue  // the ReLU epilogue lives in the 128x128 kernel
   // the slab epilogues store fp16 rows with 16-byte instructions when the layout allows (tiles 7 / 8 / 10 require it)
   p.wide16 = (ldo % 8) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (!head_hd || head_hd % 8 == 0);
-  if ((tsel == 7 || tsel == 8 || tsel == 10 || tsel == 11 || tsel == 13) && epilogue != EPI_F32 && !p.wide16) tsel = 1;
+  if ((tsel == 7 || tsel == 8 || tsel == 10 || tsel == 11 || tsel == 13 || tsel == 14) && epilogue != EPI_F32 && !p.wide16) tsel = 1;
   if ((tsel == 3 || tsel == 5) && N % 256 == 0) {
     if (tsel == 3) {
       if (epilogue == EPI_F16) launch256<EPI_F16, 256, 1>(p, s);
@@ -2107,11 +2282,17 @@ static int gemm_dispatch(const void* A, const void* W, const float* bias, void* 
     }
     return psam_launch_status();
   }
-  if ((tsel == 11 || tsel == 13) && N % 256 == 0 && epilogue != EPI_F32 && !p.wide16) tsel = 10;
+  if ((tsel == 11 || tsel == 13 || tsel == 14) && N % 256 == 0 && epilogue != EPI_F32 && !p.wide16) tsel = 10;
   if (tsel == 13 && N % 256 == 0) {
     if (epilogue == EPI_F16) launch4p<EPI_F16>(p, s);
     else if (epilogue == EPI_GELU_F16) launch4p<EPI_GELU_F16>(p, s);
     else launch4p<EPI_F32>(p, s);
+    return psam_launch_status();
+  }
+  if (tsel == 14 && N % 256 == 0) {
+    if (epilogue == EPI_F16) launch8q<EPI_F16>(p, s);
+    else if (epilogue == EPI_GELU_F16) launch8q<EPI_GELU_F16>(p, s);
+    else launch8q<EPI_F32>(p, s);
     return psam_launch_status();
   }
   if (tsel == 11 && N % 256 == 0) {

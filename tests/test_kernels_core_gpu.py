@@ -38,7 +38,7 @@ def test_gemm(dev, M, N, K, epi):
         torch.testing.assert_close(out, resid + gamma * ref, rtol=1e-4, atol=2e-4)
 
 
-@pytest.mark.parametrize("tile", [2, 3, 5, 6, 7, 8, 9, 10, 11, 13])
+@pytest.mark.parametrize("tile", [2, 3, 5, 6, 7, 8, 9, 10, 11, 13, 14])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (1297, 768, 768), (4096, 1280, 1280), (1000, 512, 192)])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_gemm_large_tiles(dev, tile, M, N, K, epi):
@@ -80,7 +80,7 @@ def test_gemm_persistent_tile_walks_many_tiles(dev, M, N, K, epi):
     resid = _rand((M, N), dev, 1.0, 24) if epi == 2 else None
     gamma = _rand((N,), dev, 1.0, 25) if epi == 2 else None
     outs = []
-    for tile in (10, 11, 13):
+    for tile in (10, 11, 13, 14):
         ops.gemm_set_tile(tile)
         try:
             if epi == 2:
@@ -90,7 +90,7 @@ def test_gemm_persistent_tile_walks_many_tiles(dev, M, N, K, epi):
                 outs.append(ops.gemm(a, w, bias, epilogue=e))
         finally:
             ops.gemm_set_tile(0)
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
     ref = a.float() @ w.float().t() + bias
     if epi == 1:
         ref = torch.nn.functional.gelu(ref)
@@ -236,7 +236,7 @@ def test_head_major_qkv_layout(dev):
     w = _rand((3 * D, D), dev, 0.05, 42).half()
     bias = _rand((3 * D,), dev, 0.5, 43)
     tokm = ops.gemm(x, w, bias, epilogue=ops.EPI_F16)                              # [B*N, 3*H*hd]
-    for tile in (1, 10, 11, 13):
+    for tile in (1, 10, 11, 13, 14):
         ops.gemm_set_tile(tile)
         try:
             hm = ops.gemm_heads(x, w, bias, hd)                                    # [3*H, B*N, hd]
