@@ -35,6 +35,19 @@ int psam_gemm_f16(const void* A, const void* W, const float* bias, void* out, co
  * head_major = 1: a head's Q / K / V rows are then contiguous hd-vectors. Same arithmetic as epilogue 0. */
 int psam_gemm_f16_heads(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int lda, int ldw,
                         int hd, void* stream);
+/* psam_gemm_f16 with a LayerNorm folded into the GEMMs either side of it (no LayerNorm pass, no cast pass):
+ *   epilogue 2 (x = resid + gamma*(a w^T + bias)) also writes out16 = half(x) [.., ld16] and stats: per row and 64-column
+ *              group (sum, sum of squares) of x, float [M][N/64][2] (either may be null);
+ *   epilogue 0 / 1 take A = half(x), W already multiplied by the LayerNorm weight, bias' = bias + W . ln_bias, and
+ *              ln_mr float [M][2] = (mean, rstd) from psam_ln_finalize, ln_s float [N] = row sums of the fp16 W':
+ *              out = act(rstd * (acc - mean * ln_s[n]) + bias'[n]).
+ * modeling/image_encoder.py:174-193 (norm1 -> attn.qkv, norm2 -> mlp.lin1); DINOv2 Block (norm1 / norm2). */
+int psam_gemm_f16_ln(const void* A, const void* W, const float* bias, void* out, const float* resid, const float* gamma,
+                     int M, int N, int K, int lda, int ldw, int ldo, int ldr, int resid_mod, int out_seg,
+                     int out_seg_stride, int out_seg_off, int epilogue, void* out16, int ld16, float* stats,
+                     const float* ln_mr, const float* ln_s, void* stream);
+/* stats [M][D/64][2] -> mr [M][2] = (mean, 1/sqrt(var + eps)), biased variance (nn.LayerNorm) */
+int psam_ln_finalize(const float* stats, int M, int D, float eps, float* mr, void* stream);
 
 
 /* Tile override for psam_gemm_f16: 0 auto (default; also env PSAM_GEMM_TILE), 1 = 128x128x64 double-buffered,

@@ -127,7 +127,7 @@ def check_dinov2_vs_transformers():
     from oracle import dinov2 as odino
     from protosam_amd.dinov2 import DinoVisionTransformer
     from protosam_amd.synth import synth_state_dict
-    print("DINOv2 restatement vs transformers.Dinov2Model (518x518: no pos-embed interpolation)")
+    print("DINOv2 restatement vs transformers.Dinov2Model (518x518: no pos-embed interpolation; 504 / 1022: interpolated)")
     depth = 2
     sd = synth_state_dict(DinoVisionTransformer("dinov2_vitb14", depth=depth), 7)
     cfg = Dinov2Config(hidden_size=768, num_hidden_layers=depth, num_attention_heads=12, mlp_ratio=4, image_size=518,
@@ -165,6 +165,34 @@ def check_dinov2_vs_transformers():
     out = odino.forward_features(x, sd, "dinov2_b14", depth=depth)
     close(out["x_norm_patchtokens"], ref[:, 1:], 2e-5, "x_norm_patchtokens")
     close(out["x_norm_clstoken"], ref[:, 0], 2e-5, "x_norm_clstoken")
+    # The sizes the configurations actually run at (grid_proto_fewshot.py:88-91 resizes to (S // 14) * 14: 504 for 512 inputs,
+    # 1022 for 1024) take the pos-embed interpolation path. transformers resamples with `size=`; the hub code the reference
+    # loads passes `scale_factor=(n + 0.1) / 37` (interpolate_offset 0.1), which the oracle restates. Two measurements:
+    #   (a) transformers' own interpolation vs the oracle: the difference IS the known size= / scale_factor= delta;
+    #   (b) transformers with the ORACLE'S interpolated pos-embed swapped in: everything else (patch embed, cls handling,
+    #       token order, blocks, final norm at these sequence lengths) must agree to rounding.
+    emb = hf.embeddings
+    orig_interp = emb.interpolate_pos_encoding
+    for S in (504, 1022):
+        xs = torch.randn((1, 3, S, S), generator=torch.Generator().manual_seed(S))
+        n = S // 14
+        with torch.no_grad():
+            o = odino.forward_features(xs, sd, "dinov2_b14", depth=depth)
+            ref_own = hf(pixel_values=xs, interpolate_pos_encoding=True).last_hidden_state if "interpolate_pos_encoding" in \
+                hf.forward.__code__.co_varnames else hf(pixel_values=xs).last_hidden_state
+            pe_oracle = odino.interpolate_pos_encoding(sd["pos_embed"], n, n, False, 0.1)
+            emb.interpolate_pos_encoding = lambda embeddings, height, width: pe_oracle
+            try:
+                ref_swapped = hf(pixel_values=xs).last_hidden_state
+            finally:
+                emb.interpolate_pos_encoding = orig_interp
+            pe_hf = orig_interp(torch.zeros(1, 1 + n * n, 768), S, S)
+        d_pe = (pe_hf - pe_oracle).abs().max().item()
+        d_own = (o["x_norm_patchtokens"] - ref_own[:, 1:]).abs().max().item()
+        print(f"  [info] {S}x{S} ({n}x{n} patches): pos-embed size= vs scale_factor=(n+0.1)/37: max |delta| {d_pe:.3e} on the "
+              f"table (std 0.5), {d_own:.3e} on x_norm_patchtokens after {depth} blocks")
+        close(o["x_norm_patchtokens"], ref_swapped[:, 1:], 3e-5, f"{S}x{S}: x_norm_patchtokens with the oracle's pos-embed swapped in")
+        close(o["x_norm_clstoken"], ref_swapped[:, 0], 3e-5, f"{S}x{S}: x_norm_clstoken with the oracle's pos-embed swapped in")
 
 
 def _small_encoder_kwargs():

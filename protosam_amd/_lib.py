@@ -19,6 +19,8 @@ c_void_p, c_int, c_float, c_longlong = ctypes.c_void_p, ctypes.c_int, ctypes.c_f
 SIGNATURES = {
     "psam_gemm_f16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p],
     "psam_gemm_f16_heads": [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p],
+    "psam_gemm_f16_ln": [c_void_p] * 6 + [c_int] * 12 + [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "psam_ln_finalize": [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p],
     "psam_gemm_set_tile": [c_int],
     "psam_layernorm": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                        c_int, c_int, c_void_p],

@@ -92,3 +92,30 @@ extern "C" int psam_layernorm(const float* x, const float* w, const float* b, vo
                        ldy, eps, zero_tail_rows);
   return psam_launch_status();
 }
+
+
+// Folded LayerNorm (psam_gemm_f16_ln): per-row partial (sum, sum of squares) over 64-column groups, written by the epilogue of
+// the residual-stream GEMM, -> (mean, rstd) per row for the consuming GEMM's epilogue. Deterministic (fixed summation order,
+// no atomics); biased variance as nn.LayerNorm, E[x^2] - mean^2 in fp32 (|mean| << std on a ViT residual stream; clamped at 0).
+__global__ void ln_finalize_kernel(const float* __restrict__ stats, int M, int parts, float inv_d, float eps,
+                                   float* __restrict__ mr) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const float2* s = reinterpret_cast<const float2*>(stats) + (size_t)m * parts;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = 0; i < parts; ++i) {
+    const float2 v = s[i];
+    s1 += v.x;
+    s2 += v.y;
+  }
+  const float mean = s1 * inv_d;
+  const float var = fmaxf(s2 * inv_d - mean * mean, 0.f);
+  reinterpret_cast<float2*>(mr)[m] = make_float2(mean, 1.0f / sqrtf(var + eps));
+}
+
+extern "C" int psam_ln_finalize(const float* stats, int M, int D, float eps, float* mr, void* stream) {
+  if (M <= 0 || D <= 0 || (D % 64) != 0) return PSAM_ERR_ARG;
+  hipLaunchKernelGGL(ln_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, M, D / 64,
+                     1.0f / (float)D, eps, mr);
+  return psam_launch_status();
+}

@@ -15,6 +15,7 @@ epilogue] -> final LN (fp32). GEMM/attention operands are fp16 with fp32 accumul
 and all LayerNorm statistics are fp32. The nn.Module tree below only holds parameters.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -96,6 +97,7 @@ class DinoVisionTransformer(nn.Module):
         self._packed = None
         self._pos_cache = {}
         self._ws = {}
+        self.fold_ln = os.environ.get("PSAM_FOLD_LN", "1") != "0"
 
     # -- weight packing (fp16 GEMM operands); rebuilt whenever parameters change -----------------------------
     def _apply(self, fn, *a, **k):
@@ -129,6 +131,12 @@ class DinoVisionTransformer(nn.Module):
                 n1w=blk.norm1.weight.detach().float().contiguous(), n1b=blk.norm1.bias.detach().float().contiguous(),
                 n2w=blk.norm2.weight.detach().float().contiguous(), n2b=blk.norm2.bias.detach().float().contiguous(),
                 g1=blk.ls1.gamma.detach().float().contiguous(), g2=blk.ls2.gamma.detach().float().contiguous()))
+            # LayerNorm folded into the consuming GEMM (ops.fold_layernorm)
+            d = pk["blocks"][-1]
+            d["qkv_wf"], d["qkv_s"], d["qkv_t"] = ops.fold_layernorm(blk.attn.qkv.weight, blk.attn.qkv.bias, blk.norm1.weight,
+                                                                    blk.norm1.bias)
+            d["fc1_wf"], d["fc1_s"], d["fc1_t"] = ops.fold_layernorm(blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.norm2.weight,
+                                                                    blk.norm2.bias)
         pk["nw"] = self.norm.weight.detach().float().contiguous()
         pk["nb"] = self.norm.bias.detach().float().contiguous()
         self._packed = pk
@@ -171,6 +179,8 @@ class DinoVisionTransformer(nn.Module):
             self._ws[key] = dict(
                 x=torch.empty((B, N, D), dtype=torch.float32, device=dev),
                 ln=torch.empty((M, D), dtype=torch.float16, device=dev),
+                stats=torch.empty((M, D // 64, 2), dtype=torch.float32, device=dev),
+                mr=torch.empty((M, 2), dtype=torch.float32, device=dev),
                 qkv=torch.empty((M, 3 * D), dtype=torch.float16, device=dev),
                 att=torch.empty((M, D), dtype=torch.float16, device=dev),
                 hid=torch.empty((M, 4 * D), dtype=torch.float16, device=dev),
@@ -198,17 +208,32 @@ class DinoVisionTransformer(nn.Module):
         for r in range(1 + R):
             ops.broadcast_rows(prefix[r], x, B, N * D, r * D)
         x2 = x.view(B * N, D)
-        for bp in pk["blocks"]:
-            ops.layernorm(x2, bp["n1w"], bp["n1b"], LN_EPS, out=ws["ln"])
-            if ops.QKV_HEAD_MAJOR:
-                ops.gemm_heads(ws["ln"], bp["qkv_w"], bp["qkv_b"], hd, out=ws["qkv"])   # [3,H,B*N,hd]
+        # `fold_ln`: as in the SAM encoder (image_encoder.py), the residual-stream GEMMs emit half(x) + row partial sums and the
+        # consuming GEMM applies (mean, rstd) in its epilogue. The first norm1 stays a pass of its own: the cls / register rows
+        # come from `broadcast_rows`, not from a GEMM epilogue.
+        fold = self.fold_ln and not ops.QKV_HEAD_MAJOR and D % 64 == 0
+        M = B * N
+        x16, stats, mr = ws["ln"], ws["stats"], ws["mr"]
+        fk = dict(out16=x16, stats=stats) if fold else {}
+        for bi, bp in enumerate(pk["blocks"]):
+            if fold and bi > 0:
+                ops.ln_finalize(stats, M, D, LN_EPS, mr=mr)
+                ops.gemm(x16, bp["qkv_wf"], bp["qkv_t"], out=ws["qkv"], epilogue=ops.EPI_F16, ln_mr=mr, ln_s=bp["qkv_s"])
             else:
-                ops.gemm(ws["ln"], bp["qkv_w"], bp["qkv_b"], out=ws["qkv"], epilogue=ops.EPI_F16)
+                ops.layernorm(x2, bp["n1w"], bp["n1b"], LN_EPS, out=ws["ln"])
+                if ops.QKV_HEAD_MAJOR:
+                    ops.gemm_heads(ws["ln"], bp["qkv_w"], bp["qkv_b"], hd, out=ws["qkv"])   # [3,H,B*N,hd]
+                else:
+                    ops.gemm(ws["ln"], bp["qkv_w"], bp["qkv_b"], out=ws["qkv"], epilogue=ops.EPI_F16)
             ops.attention(ws["qkv"], B, N, H, hd, hd ** -0.5, out=ws["att"], head_major=ops.QKV_HEAD_MAJOR)
-            ops.gemm(ws["att"], bp["proj_w"], bp["proj_b"], out=x2, epilogue=ops.EPI_F32, resid=x2, gamma=bp["g1"])
-            ops.layernorm(x2, bp["n2w"], bp["n2b"], LN_EPS, out=ws["ln"])
-            ops.gemm(ws["ln"], bp["fc1_w"], bp["fc1_b"], out=ws["hid"], epilogue=ops.EPI_GELU_F16)
-            ops.gemm(ws["hid"], bp["fc2_w"], bp["fc2_b"], out=x2, epilogue=ops.EPI_F32, resid=x2, gamma=bp["g2"])
+            ops.gemm(ws["att"], bp["proj_w"], bp["proj_b"], out=x2, epilogue=ops.EPI_F32, resid=x2, gamma=bp["g1"], **fk)
+            if fold:
+                ops.ln_finalize(stats, M, D, LN_EPS, mr=mr)
+                ops.gemm(x16, bp["fc1_wf"], bp["fc1_t"], out=ws["hid"], epilogue=ops.EPI_GELU_F16, ln_mr=mr, ln_s=bp["fc1_s"])
+            else:
+                ops.layernorm(x2, bp["n2w"], bp["n2b"], LN_EPS, out=ws["ln"])
+                ops.gemm(ws["ln"], bp["fc1_w"], bp["fc1_b"], out=ws["hid"], epilogue=ops.EPI_GELU_F16)
+            ops.gemm(ws["hid"], bp["fc2_w"], bp["fc2_b"], out=x2, epilogue=ops.EPI_F32, resid=x2, gamma=bp["g2"], **fk)
         ops.layernorm(x2, pk["nw"], pk["nb"], LN_EPS, out=ws["out"].view(B * N, D), out_dtype=torch.float32)
         return ws["out"]
 

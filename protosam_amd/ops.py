@@ -80,8 +80,11 @@ def _req(t, dtype, name):
 
 
 def gemm(a, w, bias=None, out=None, epilogue=EPI_F16, resid=None, gamma=None, resid_mod=0, out_seg=0,
-         out_seg_stride=0, out_seg_off=0, M=None):
-    """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias). a/w fp16 (K contiguous); out fp16 or fp32 by epilogue."""
+         out_seg_stride=0, out_seg_off=0, M=None, out16=None, stats=None, ln_mr=None, ln_s=None):
+    """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias). a/w fp16 (K contiguous); out fp16 or fp32 by epilogue.
+    Folded LayerNorm (psam_gemm_f16_ln): with EPI_F32, `out16` (fp16 [rows, N]) receives half(out) and `stats` (fp32
+    [rows, N/64, 2]) per-row partial (sum, sum of squares); with EPI_F16 / EPI_GELU_F16, `ln_mr` (fp32 [rows, 2] from
+    `ln_finalize`) and `ln_s` (fp32 [N]) apply out = act(rstd * (acc - mean * ln_s) + bias)."""
     _req(a, torch.float16, "a"); _req(w, torch.float16, "w")
     _req(bias, torch.float32, "bias"); _req(gamma, torch.float32, "gamma")
     _req(resid, torch.float16 if epilogue == EPI_RELU_F16 else torch.float32, "resid")   # epilogue 3 adds a half map
@@ -100,14 +103,46 @@ def gemm(a, w, bias=None, out=None, epilogue=EPI_F16, resid=None, gamma=None, re
     if resid is not None:
         r2 = resid.reshape(-1, resid.shape[-1]) if resid.dim() != 2 else resid
         ldr = r2.stride(0)
+    fold = out16 is not None or stats is not None or ln_mr is not None
+    if fold:
+        _req(out16, torch.float16, "out16"); _req(stats, torch.float32, "stats")
+        _req(ln_mr, torch.float32, "ln_mr"); _req(ln_s, torch.float32, "ln_s")
     t0 = GEMM_TIMER.start() if GEMM_TIMER is not None else None
-    st = _lib.lib().psam_gemm_f16(_ptr(a2), _ptr(w), _ptr(bias), _ptr(out2), _ptr(resid), _ptr(gamma), M, N, K,
-                                 a2.stride(0), w.stride(0), out2.stride(0), ldr, resid_mod, out_seg,
-                                 out_seg_stride, out_seg_off, epilogue, _stream())
+    if fold:
+        st = _lib.lib().psam_gemm_f16_ln(_ptr(a2), _ptr(w), _ptr(bias), _ptr(out2), _ptr(resid), _ptr(gamma), M, N, K,
+                                        a2.stride(0), w.stride(0), out2.stride(0), ldr, resid_mod, out_seg,
+                                        out_seg_stride, out_seg_off, epilogue, _ptr(out16),
+                                        0 if out16 is None else out16.stride(-2), _ptr(stats), _ptr(ln_mr), _ptr(ln_s),
+                                        _stream())
+    else:
+        st = _lib.lib().psam_gemm_f16(_ptr(a2), _ptr(w), _ptr(bias), _ptr(out2), _ptr(resid), _ptr(gamma), M, N, K,
+                                     a2.stride(0), w.stride(0), out2.stride(0), ldr, resid_mod, out_seg,
+                                     out_seg_stride, out_seg_off, epilogue, _stream())
     if t0 is not None:
         GEMM_TIMER.stop(t0, 2.0 * M * N * K)
-    _lib.check(st, "psam_gemm_f16")
+    _lib.check(st, "psam_gemm_f16_ln" if fold else "psam_gemm_f16")
     return out
+
+
+def ln_finalize(stats, M, D, eps, mr=None):
+    """stats fp32 [rows, D/64, 2] (partial sums from a folded-LayerNorm producer GEMM) -> mr fp32 [rows, 2] = (mean, rstd)."""
+    _req(stats, torch.float32, "stats")
+    if mr is None:
+        mr = torch.empty((M, 2), dtype=torch.float32, device=stats.device)
+    _req(mr, torch.float32, "mr")
+    st = _lib.lib().psam_ln_finalize(_ptr(stats), M, D, float(eps), _ptr(mr), _stream())
+    _lib.check(st, "psam_ln_finalize")
+    return mr
+
+
+def fold_layernorm(weight, bias, ln_weight, ln_bias):
+    """One-time weight transform for a Linear that consumes LayerNorm(x): -> (W' fp16 = half(W * ln_weight), ln_s fp32 [N] =
+    row sums of the ROUNDED W', bias' fp32 = bias + W . ln_bias), so that  Linear(LN(x)) = rstd * (x W'^T - mean * ln_s) + bias'."""
+    W = weight.detach().float()
+    Wp = (W * ln_weight.detach().float()[None, :]).half().contiguous()
+    s = Wp.float().sum(1).contiguous()
+    b = bias.detach().float() if bias is not None else torch.zeros(W.shape[0], dtype=torch.float32, device=W.device)
+    return Wp, s, (b + W @ ln_bias.detach().float()).contiguous()
 
 
 def gemm_heads(a, w, bias, hd, out=None, M=None):

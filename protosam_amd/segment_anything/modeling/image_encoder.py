@@ -7,6 +7,8 @@ index math, or global with a 64-key tile = one key row) -> proj GEMM (+residual)
 lin2 GEMM (+residual). Neck: 1x1 conv = GEMM, LayerNorm2d = row LN (token-major), 3x3 conv = im2col + GEMM, LN.
 The 64x64x256 embedding is kept token-major; `forward` returns the reference's NCHW shape as a permuted view.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -50,6 +52,18 @@ class Block(nn.Module):
         self.window_size = window_size
 
 
+def _rel_table(rel_pos, K):
+    """`get_rel_pos` (image_encoder.py:303-334) for a square K x K attention region: a table whose length is not 2K - 1 (a
+    checkpoint trained at another resolution) is resampled linearly to 2K - 1 rows, once, when the weights are packed; with
+    q_size == k_size the gather index is qy - ky + K - 1, which is how the kernels address the packed table."""
+    L = 2 * K - 1
+    r = rel_pos.detach().float()
+    if r.shape[0] == L:
+        return r
+    r = torch.nn.functional.interpolate(r.reshape(1, r.shape[0], -1).permute(0, 2, 1), size=L, mode="linear")
+    return r.reshape(-1, L).permute(1, 0).contiguous()
+
+
 class ImageEncoderViT(nn.Module):
     def __init__(self, img_size=1024, patch_size=16, in_chans=3, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.0,
                  out_chans=256, qkv_bias=True, norm_layer=nn.LayerNorm, act_layer=nn.GELU, use_abs_pos=True,
@@ -77,6 +91,7 @@ class ImageEncoderViT(nn.Module):
                                   LayerNorm2d(out_chans))
         self._packed = None
         self._ws = {}
+        self.fold_ln = os.environ.get("PSAM_FOLD_LN", "1") != "0"
 
     def _apply(self, fn, *a, **k):
         self._packed, self._ws = None, {}
@@ -100,12 +115,16 @@ class ImageEncoderViT(nn.Module):
                 ws=blk.window_size, n1w=f32(blk.norm1.weight), n1b=f32(blk.norm1.bias), n2w=f32(blk.norm2.weight),
                 n2b=f32(blk.norm2.bias), qkv_w=f16(a.qkv.weight), qkv_b=f32(a.qkv.bias), pad_row=f16(a.qkv.bias),
                 proj_w=f16(a.proj.weight), proj_b=f32(a.proj.bias),
-                rpack=ops.pack_rel_tables(a.rel_pos_h, a.rel_pos_w, blk.window_size > 0, D // self.num_heads),
+                rpack=ops.pack_rel_tables(_rel_table(a.rel_pos_h, blk.window_size or self.grid),
+                                          _rel_table(a.rel_pos_w, blk.window_size or self.grid), blk.window_size > 0,
+                                          D // self.num_heads),
                 l1w=f16(blk.mlp.lin1.weight), l1b=f32(blk.mlp.lin1.bias), l2w=f16(blk.mlp.lin2.weight),
                 l2b=f32(blk.mlp.lin2.bias)))
-            K = blk.window_size if blk.window_size > 0 else self.grid
-            if a.rel_pos_h.shape[0] != 2 * K - 1:
-                raise NotImplementedError("rel-pos table length != 2K-1 needs get_rel_pos' linear resize")
+            # LayerNorm folded into the consuming GEMM (ops.fold_layernorm): W' = half(W * ln_w), row sums of W', bias + W . ln_b
+            d = pk["blocks"][-1]
+            d["qkv_wf"], d["qkv_s"], d["qkv_t"] = ops.fold_layernorm(a.qkv.weight, a.qkv.bias, blk.norm1.weight, blk.norm1.bias)
+            d["l1wf"], d["l1s"], d["l1t"] = ops.fold_layernorm(blk.mlp.lin1.weight, blk.mlp.lin1.bias, blk.norm2.weight,
+                                                               blk.norm2.bias)
         pk["neck0"] = f16(self.neck[0].weight.reshape(oc, D))
         pk["neck1w"], pk["neck1b"] = f32(self.neck[1].weight), f32(self.neck[1].bias)
         pk["neck2"] = f16(self.neck[2].weight.permute(0, 2, 3, 1).reshape(oc, 9 * oc))  # [out, (ky,kx,cin)]
@@ -125,6 +144,7 @@ class ImageEncoderViT(nn.Module):
             M = B * N
             e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)  # noqa: E731
             self._ws[B] = dict(x=e((M, D), torch.float32), ln=e((M, D), torch.float16), qkv=e((M, 3 * D), torch.float16),
+                               stats=e((M, D // 64, 2), torch.float32), mr=e((M, 2), torch.float32),
                                att=e((M, D), torch.float16), hid=e((M, 4 * D), torch.float16),
                                relh=e((B, H, N, 64), torch.float32), relw=e((B, H, N, 64), torch.float32),
                                relq=torch.zeros((B, H, N, 2, 32), dtype=torch.float16, device=dev),
@@ -134,18 +154,30 @@ class ImageEncoderViT(nn.Module):
         return self._ws[B]
 
     def encode_patches(self, patches, B):
-        """patches fp16 [B*4096, 3*16*16] (im2col of the normalised image) -> token-major embedding fp32 [B,4096,out]."""
+        """patches fp16 [B*4096, 3*16*16] (im2col of the normalised image) -> token-major embedding fp32 [B,4096,out].
+        `fold_ln` (default): the blocks' LayerNorms never run as passes of their own - the GEMM that updates the residual
+        stream also emits half(x) and per-row partial sums, `ln_finalize` turns them into (mean, rstd), and the consuming
+        GEMM (qkv / lin1, weights pre-multiplied by the LayerNorm weight) applies them in its epilogue. Same arithmetic up to
+        rounding (tools/emulate_ln_fusion.py: embedding error 6.4e-4 mean vs 7.0e-4 for the separate LayerNorm pass)."""
         pk = self._pack()
         ws = self._workspace(B)
         D, H, N, g = self.embed_dim, self.num_heads, self.grid * self.grid, self.grid
         hd = D // H
         x = ws["x"]
-        ops.gemm(patches, pk["patch_w"], pk["patch_b"], out=x, epilogue=ops.EPI_F32, resid=pk["pos"], resid_mod=N)
+        fold = self.fold_ln and not ops.QKV_HEAD_MAJOR and D % 64 == 0
+        M = B * N
+        x16, stats, mr = ws["ln"], ws["stats"], ws["mr"]
+        fk = dict(out16=x16, stats=stats) if fold else {}
+        ops.gemm(patches, pk["patch_w"], pk["patch_b"], out=x, epilogue=ops.EPI_F32, resid=pk["pos"], resid_mod=N, **fk)
         for bp in pk["blocks"]:
-            ops.layernorm(x, bp["n1w"], bp["n1b"], LN_EPS, out=ws["ln"])
-            if ops.QKV_HEAD_MAJOR:
+            if fold:
+                ops.ln_finalize(stats, M, D, LN_EPS, mr=mr)
+                ops.gemm(x16, bp["qkv_wf"], bp["qkv_t"], out=ws["qkv"], epilogue=ops.EPI_F16, ln_mr=mr, ln_s=bp["qkv_s"])
+            elif ops.QKV_HEAD_MAJOR:
+                ops.layernorm(x, bp["n1w"], bp["n1b"], LN_EPS, out=ws["ln"])
                 ops.gemm_heads(ws["ln"], bp["qkv_w"], bp["qkv_b"], hd, out=ws["qkv"])   # [3,H,B*N,hd]
             else:
+                ops.layernorm(x, bp["n1w"], bp["n1b"], LN_EPS, out=ws["ln"])
                 ops.gemm(ws["ln"], bp["qkv_w"], bp["qkv_b"], out=ws["qkv"], epilogue=ops.EPI_F16)
             if bp["ws"] > 0:
                 if ops.FUSE_WINDOW_RELPOS:   # the query-side rel-pos terms are computed inside the attention kernel
@@ -161,13 +193,19 @@ class ImageEncoderViT(nn.Module):
                            rel_w=ws["relw"], head_major=ops.QKV_HEAD_MAJOR)
                 ops.attention(ws["qkv"], B, N, H, hd, hd ** -0.5, out=ws["att"], mode=1, rel_h=ws["relh"],
                               rel_w=ws["relw"], gh=g, gw=g, head_major=ops.QKV_HEAD_MAJOR)
-            ops.gemm(ws["att"], bp["proj_w"], bp["proj_b"], out=x, epilogue=ops.EPI_F32, resid=x)
-            ops.layernorm(x, bp["n2w"], bp["n2b"], LN_EPS, out=ws["ln"])
-            ops.gemm(ws["ln"], bp["l1w"], bp["l1b"], out=ws["hid"], epilogue=ops.EPI_GELU_F16)
-            ops.gemm(ws["hid"], bp["l2w"], bp["l2b"], out=x, epilogue=ops.EPI_F32, resid=x)
-        # neck (image_encoder.py:90-106): the residual stream is cast once to fp16 for the 1x1-conv GEMM
+            ops.gemm(ws["att"], bp["proj_w"], bp["proj_b"], out=x, epilogue=ops.EPI_F32, resid=x, **fk)
+            if fold:
+                ops.ln_finalize(stats, M, D, LN_EPS, mr=mr)
+                ops.gemm(x16, bp["l1wf"], bp["l1t"], out=ws["hid"], epilogue=ops.EPI_GELU_F16, ln_mr=mr, ln_s=bp["l1s"])
+            else:
+                ops.layernorm(x, bp["n2w"], bp["n2b"], LN_EPS, out=ws["ln"])
+                ops.gemm(ws["ln"], bp["l1w"], bp["l1b"], out=ws["hid"], epilogue=ops.EPI_GELU_F16)
+            ops.gemm(ws["hid"], bp["l2w"], bp["l2b"], out=x, epilogue=ops.EPI_F32, resid=x, **fk)
+        # neck (image_encoder.py:90-106): the residual stream goes through the 1x1-conv GEMM as fp16 (with `fold_ln` the last
+        # lin2 epilogue already wrote that copy)
         xh = ws["ln"]
-        ops.cast_f16(x, xh)
+        if not fold:
+            ops.cast_f16(x, xh)
         ops.gemm(xh, pk["neck0"], None, out=ws["n0"], epilogue=ops.EPI_F32)
         ops.layernorm(ws["n0"], pk["neck1w"], pk["neck1b"], LN_EPS, out=ws["n1"])
         ops.im2col3x3(ws["n1"], B, g, g, self.out_chans, out=ws["col"])

@@ -313,3 +313,51 @@ def test_attention_softmax_variants_agree(dev, mode, N, H, hd, B):
         assert torch.isfinite(o).all()
         torch.testing.assert_close(o, ref, rtol=2e-3, atol=2e-3)
     assert (outs[0] - outs[1]).abs().max().item() < 2e-3
+
+
+@pytest.mark.parametrize("tile", [1, 11, 14])
+@pytest.mark.parametrize("M,D,N2,act", [(4096, 1280, 3840, 0), (1297 * 3, 768, 3072, 1), (777, 256, 256, 0)])
+def test_gemm_folded_layernorm(dev, tile, M, D, N2, act):
+    """psam_gemm_f16_ln: x = resid + gamma * (a w^T + b) emitting half(x) + per-row partial sums, psam_ln_finalize, then the
+    consuming GEMM on half(x) with LayerNorm-folded weights  ==  Linear(LayerNorm(x)) (GELU) to fp16-operand accuracy; also
+    against the separate LayerNorm-pass path, and the statistics themselves against torch."""
+    from protosam_amd import ops
+    K1 = 256
+    a = _rand((M, K1), dev, 1.0, 51).half()
+    w1 = _rand((D, K1), dev, 0.06, 52).half()
+    b1 = _rand((D,), dev, 0.3, 53)
+    gamma = (_rand((D,), dev, 0.2, 54) + 1.0).contiguous()
+    resid = (_rand((M, D), dev, 1.0, 55) + 0.7).contiguous()          # a common-mode offset the LayerNorm removes
+    ln_w = (_rand((D,), dev, 0.1, 56) + 1.0).contiguous()
+    ln_b = _rand((D,), dev, 0.1, 57)
+    w2 = _rand((N2, D), dev, 0.03, 58)
+    b2 = _rand((N2,), dev, 0.2, 59)
+    eps = 1e-6
+    x_ref = resid + gamma * (a.float() @ w1.float().t() + b1)
+    y_ref = torch.nn.functional.linear(torch.nn.functional.layer_norm(x_ref, (D,), ln_w, ln_b, eps), w2, b2)
+    if act:
+        y_ref = torch.nn.functional.gelu(y_ref)
+    ops.gemm_set_tile(tile)
+    try:
+        x = resid.clone()
+        x16 = torch.empty((M, D), dtype=torch.float16, device=dev)
+        stats = torch.full((M, D // 64, 2), float("nan"), device=dev)
+        ops.gemm(a, w1, b1, out=x, epilogue=ops.EPI_F32, resid=x, gamma=gamma, out16=x16, stats=stats)
+        torch.testing.assert_close(x, x_ref, rtol=1e-4, atol=3e-4)
+        assert torch.equal(x16, x.half())
+        torch.testing.assert_close(stats[..., 0].sum(1), x.sum(1), rtol=1e-4, atol=1e-2)
+        torch.testing.assert_close(stats[..., 1].sum(1), (x * x).sum(1), rtol=1e-4, atol=1e-2)
+        mr = ops.ln_finalize(stats, M, D, eps)
+        torch.testing.assert_close(mr[:, 0], x.mean(1), rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(mr[:, 1], torch.rsqrt(x.var(1, unbiased=False) + eps), rtol=1e-4, atol=1e-5)
+        wf, s_, t_ = ops.fold_layernorm(w2, b2, ln_w, ln_b)
+        e = ops.EPI_GELU_F16 if act else ops.EPI_F16
+        y = ops.gemm(x16, wf, t_, epilogue=e, ln_mr=mr, ln_s=s_).float()
+        # the separate-pass path through the same tile
+        y_sep = ops.gemm(ops.layernorm(x, ln_w, ln_b, eps), w2.half(), b2, epilogue=e).float()
+    finally:
+        ops.gemm_set_tile(0)
+    err, err_sep = (y - y_ref).abs().max().item(), (y_sep - y_ref).abs().max().item()
+    print(f"tile {tile} M={M} D={D}: folded max err {err:.2e}, separate LayerNorm pass {err_sep:.2e}")
+    torch.testing.assert_close(y, y_ref, rtol=3e-3, atol=3e-3)
+    assert err < 2.0 * err_sep + 1e-3

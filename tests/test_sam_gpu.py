@@ -168,3 +168,27 @@ def test_predictor_arbitrary_image_size(dev, hw):
     print(f"{hw}: input {pred.input_size}, max |dprob(low_res)| {perr:.2e}, iou err {np.abs(iou - iou_ref.numpy()).max():.2e}, "
           f"min Dice {d:.5f}")
     assert perr < 5e-3 and np.abs(iou - iou_ref.numpy()).max() < 5e-3 and d > 0.99
+
+
+def test_image_encoder_rel_pos_table_resize(dev):
+    """`get_rel_pos` (image_encoder.py:303-334): a rel-pos table whose length is not 2K - 1 is linearly resized. Block 0
+    (windowed, K = 14) gets 63-row tables, block 2 (global, K = 64) 41-row ones; the oracle takes the reference's resize path."""
+    from oracle import sam_image_encoder as oenc
+    from protosam_amd.synth import synth_tensor
+    sam, sd = _sam(dev, "vit_b", 3)
+    enc = sam.image_encoder
+    hd = enc.embed_dim // enc.num_heads
+    for bi, L in ((0, 63), (2, 41)):
+        for nm in ("rel_pos_h", "rel_pos_w"):
+            t = synth_tensor(f"resized.{bi}.{nm}", (L, hd), 99)
+            sd[f"image_encoder.blocks.{bi}.attn.{nm}"] = t
+            setattr(enc.blocks[bi].attn, nm, torch.nn.Parameter(t.to(dev)))
+    enc._packed = None
+    img = _image(3)
+    x = (img.float() - torch.tensor([123.675, 116.28, 103.53]).view(1, 3, 1, 1)) / torch.tensor(
+        [58.395, 57.12, 57.375]).view(1, 3, 1, 1)
+    ref = oenc.image_encoder(x, sd, model_type="vit_b", depth=3)
+    out = sam.image_encoder(sam.preprocess(img.to(dev)))
+    err = (out.cpu() - ref).abs()
+    print(f"resized rel-pos tables: max abs err {err.max():.3e} mean {err.mean():.3e}")
+    assert err.max() < 5e-2 and err.mean() < 3e-3
