@@ -1,0 +1,65 @@
+// Shared device helpers for the protosam_amd HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 half_t;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define PSAM_OK 0
+#define PSAM_ERR_ARG 1
+#define PSAM_ERR_LAUNCH 2
+
+#define WAVE 64
+
+static inline int psam_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? PSAM_OK : PSAM_ERR_LAUNCH;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// erf-form GELU (torch.nn.GELU() default). erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the fp16
+// rounding of every consumer) on the hardware exp2 / rcp: ~14 VALU ops instead of libm erff's ~40 with branches.
+__device__ __forceinline__ float fast_erf(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f);
+  const float y = fmaf(-poly * t, e, 1.0f);
+  return copysignf(y, x);
+}
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f));
+}
+
+// XCD-aware bijective block remap (8 XCDs; block b runs on XCD b % 8): gives each XCD a
+// contiguous chunk of the logical tile space so neighbouring tiles share an L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int nx = 8;
+  int xcd = bid % nx, idx = bid / nx;
+  int q = nwg / nx, r = nwg % nx;
+  int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}

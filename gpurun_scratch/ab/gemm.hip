@@ -43,34 +43,8 @@ struct GemmArgs {
   int wide16;    // fp16 output rows may be stored with 16-byte instructions (ldo % 8 == 0, 16-byte aligned base)
   int stagger;   // start-time spread of the first round of workgroups, in units of s_sleep(8) (tile 10)
   int dbg;       // ablation switches for tools/gemm_ablate.py (PSAM_GEMM_DBG; only the DBG instantiation reads it)
-  // ---- LayerNorm folded into the GEMMs either side of it (psam_gemm_f16_ln; tiles 1 / 11 / 14 only) ----
-  // producer (EPI_F32, the residual-stream update x = resid + gamma * (acc + bias)): besides x it writes
-  //   out16[m, n]                 = fp16(x)   - the NEXT GEMM's A operand (no LayerNorm pass, no cast pass)
-  //   stats[(m * parts + n/64)*2] = (sum, sum of squares) of x over the 64 columns [n/64*64, +64) of row m, parts = N / 64
-  // consumer (EPI_F16 / EPI_GELU_F16, W already multiplied by the LayerNorm weight): with (mean, rstd) = ln_mr[m] and
-  //   s[n] = sum_k W'[n,k]:   out = act( rstd * (acc - mean * s[n]) + bias'[n] ),  bias' = bias + W . ln_bias   (the caller's `bias`)
-  half_t* out16;
-  int ld16;
-  float* stats;
-  const float* ln_mr;
-  const float* ln_s;
 };
 
-
-// ---- device geometry, read once from the runtime (a full MI355X reports 256 CUs in 8 XCDs; a CPX / NPS partition fewer) ----
-// The XCD-region tile maps below are written for 8 XCDs (block b on XCD b % 8, observed placement, speed only): on any other
-// geometry the launchers fall back to the identity map, and the persistent grids / fill tests use the real CU count.
-static int g_num_cus = 0, g_num_xcds = 0;
-static void device_geometry() {
-  if (g_num_cus > 0) return;
-  int dev = 0, v = 0;
-  (void)hipGetDevice(&dev);
-  g_num_cus = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
-  g_num_xcds = (hipDeviceGetAttribute(&v, hipDeviceAttributeNumberOfXccs, dev) == hipSuccess && v > 0) ? v : 8;
-  (void)hipGetLastError();
-}
-static inline int num_cus() { device_geometry(); return g_num_cus; }
-static inline bool xcd_maps_apply() { device_geometry(); return g_num_xcds == 8 && g_num_cus % 8 == 0; }
 
 // ---- tile -> workgroup mapping ------------------------------------------------------------------------------------
 // Block b runs on XCD b % 8 (observed placement; used for speed only, never for correctness) and every XCD has a
@@ -138,9 +112,8 @@ static int pick_map_mode(int ntm, int ntn) {
   static int forced = -2;
   if (forced == -2) { const char* e = getenv("PSAM_GEMM_MAP"); forced = e ? atoi(e) : -1; }
   if (forced >= 0) return forced;
-  if (!xcd_maps_apply()) return 1;   // not the 8-XCD geometry the region maps are laid out for: identity
-  const int total = ntm * ntn, ncu = num_cus(), per_xcd = ncu / 8;
-  const int rounds_region = (tile_map_max_region(ntm, ntn) + per_xcd - 1) / per_xcd, rounds_even = (total + ncu - 1) / ncu;
+  const int total = ntm * ntn;
+  const int rounds_region = (tile_map_max_region(ntm, ntn) + 31) / 32, rounds_even = (total + 255) / 256;
   return rounds_region > rounds_even ? 2 : 0;
 }
 // grid size that covers every region of tile_map (host side)
@@ -230,7 +203,7 @@ __device__ __forceinline__ void slab_park(const f32x16 (&a00), const f32x16 (&a0
       }
 }
 
-template <int EPI, bool PRE = false, bool LNF = false>
+template <int EPI, bool PRE = false>
 __device__ __forceinline__ void slab_emit(const float* __restrict__ slab, int mbase, int nbase, int lane,
                                           const GemmArgs& p, const float4* pre = nullptr) {
   // same-wave LDS traffic is ordered; the compiler inserts the lgkmcnt wait for the reads below
@@ -244,12 +217,10 @@ __device__ __forceinline__ void slab_emit(const float* __restrict__ slab, int mb
     const int row = it * 4 + (lane >> 4);
     const int m = mbase + row;
     float4 v = *reinterpret_cast<const float4*>(&slab[row * 64 + ((c4 ^ (row & 15)) << 2)]);
-    if (m >= p.M && !(LNF && EPI == EPI_F32 && p.stats)) continue;
+    if (m >= p.M) continue;
     v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
     const size_t orow = p.out_seg ? (size_t)(m / p.out_seg) * p.out_seg_stride + p.out_seg_off + (m % p.out_seg) : (size_t)m;
-    if (m >= p.M) {
-      // (out-of-range row kept only for the wave-wide shuffles of the row statistics below)
-    } else if (EPI == EPI_F16) {
+    if (EPI == EPI_F16) {
       half4_t h = {(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
       if (p.head_hd) {  // packed qkv written head-major: plane (which*H + h) of [M, hd], 4 columns never straddle a head
         const int pl = n / p.head_hd;
@@ -278,28 +249,16 @@ __device__ __forceinline__ void slab_emit(const float* __restrict__ slab, int mb
         v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
       }
       *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + orow * p.ldo + n) = v;
-      if (LNF && p.out16) {   // folded LayerNorm, producer side (16 lanes hold this row's 64 columns)
-        half4_t h = {(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
-        *reinterpret_cast<half4_t*>(p.out16 + orow * p.ld16 + n) = h;
-      }
-    }
-    if (LNF && EPI == EPI_F32 && p.stats) {   // (every lane of the wave takes part in the shuffles: rows beyond M contribute nothing)
-      float s1 = m < p.M ? (v.x + v.y) + (v.z + v.w) : 0.f;
-      float s2 = m < p.M ? (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w) : 0.f;
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-      if (c4 == 0 && m < p.M)
-        *reinterpret_cast<float2*>(p.stats + (orow * (p.N >> 6) + (nbase >> 6)) * 2) = make_float2(s1, s2);
     }
   }
 }
 
-template <int EPI, bool PRE = false, bool LNF = false>
+template <int EPI, bool PRE = false>
 __device__ __forceinline__ void store_slab_staged(const f32x16 (&a00), const f32x16 (&a01), const f32x16 (&a10),
                                                   const f32x16 (&a11), float* __restrict__ slab, int mbase, int nbase,
                                                   int lane, const GemmArgs& p, const float4* pre = nullptr) {
   slab_park(a00, a01, a10, a11, slab, lane);
-  slab_emit<EPI, PRE, LNF>(slab, mbase, nbase, lane, p, pre);
+  slab_emit<EPI, PRE>(slab, mbase, nbase, lane, p, pre);
 }
 
 // fp16-output slabs (EPI_F16 / EPI_GELU_F16): bias / GELU are applied in fp32 in the accumulator layout and the slab is parked
@@ -308,41 +267,24 @@ __device__ __forceinline__ void store_slab_staged(const f32x16 (&a00), const f32
 // store instruction whatever its width: 256 dwordx2 stores per 256x256 tile took 5.6 us of a 45 us tile), so halving the
 // instruction count is what counts. 16-byte chunks XOR-swizzled by (row >> 1) & 7: the 8-byte parking writes and the
 // 16-byte reads are both conflict-free.
-template <int EPI, bool LNF = false>
+template <int EPI>
 __device__ __forceinline__ void slab_park16(const f32x16 (&a00), const f32x16 (&a01), const f32x16 (&a10),
                                             const f32x16 (&a11), half_t* __restrict__ slab, int nbase, int lane,
-                                            const GemmArgs& p, int mbase = 0) {
+                                            const GemmArgs& p) {
   const int lr = lane & 31, lg = lane >> 5;
   const f32x16* accs[2][2] = {{&a00, &a01}, {&a10, &a11}};
-  float2 mr[2] = {make_float2(0.f, 1.f), make_float2(0.f, 1.f)};   // folded LayerNorm: (mean, rstd) of this lane's two rows
-  if (LNF && p.ln_mr) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int m = mbase + i * 32 + lr;
-      m = m < p.M ? m : p.M - 1;
-      mr[i] = *reinterpret_cast<const float2*>(p.ln_mr + (size_t)m * 2);
-    }
-  }
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), sv = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
       if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + nbase + j * 32 + 8 * q + 4 * lg);
-      if (LNF && p.ln_mr) sv = *reinterpret_cast<const float4*>(p.ln_s + nbase + j * 32 + 8 * q + 4 * lg);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int row = i * 32 + lr;
         const int chunk = j * 4 + q;
         const f32x16& a = *accs[i][j];
-        float4 v;
-        if (LNF && p.ln_mr) {
-          const float mu = mr[i].x, rs = mr[i].y;
-          v = make_float4(fmaf(fmaf(-mu, sv.x, a[4 * q]), rs, bv.x), fmaf(fmaf(-mu, sv.y, a[4 * q + 1]), rs, bv.y),
-                          fmaf(fmaf(-mu, sv.z, a[4 * q + 2]), rs, bv.z), fmaf(fmaf(-mu, sv.w, a[4 * q + 3]), rs, bv.w));
-        } else {
-          v = make_float4(a[4 * q] + bv.x, a[4 * q + 1] + bv.y, a[4 * q + 2] + bv.z, a[4 * q + 3] + bv.w);
-        }
+        float4 v = make_float4(a[4 * q] + bv.x, a[4 * q + 1] + bv.y, a[4 * q + 2] + bv.z, a[4 * q + 3] + bv.w);
         if (EPI == EPI_GELU_F16) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
         half4_t h = {(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
         *reinterpret_cast<half4_t*>(&slab[row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3) + 4 * lg]) = h;
@@ -475,7 +417,7 @@ __device__ __forceinline__ void glds16(const half_t* g, half_t* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int EPI, bool LNF = false>
+template <int EPI>
 __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) half_t smem[2][2][BM * BK];  // [buf][A|W] 64 KiB
 
@@ -561,14 +503,14 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs p) {
   // closing __syncthreads() guarantees nobody still reads the k-tile buffers
   float* slab = reinterpret_cast<float*>(&smem[0][0][0]) + wv * 4096;
   if (EPI == EPI_F32 && has_res)
-    store_slab_staged<EPI, true, LNF>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], slab, m0 + wm * 64, n0 + wn * 64, lane, p,
-                                      rpre);
+    store_slab_staged<EPI, true>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], slab, m0 + wm * 64, n0 + wn * 64, lane, p,
+                                 rpre);
   else if ((EPI == EPI_F16 || EPI == EPI_GELU_F16) && p.wide16) {
     half_t* slab16 = reinterpret_cast<half_t*>(slab);
-    slab_park16<EPI, LNF>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], slab16, n0 + wn * 64, lane, p, m0 + wm * 64);
+    slab_park16<EPI>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], slab16, n0 + wn * 64, lane, p);
     slab_emit16(slab16, m0 + wm * 64, n0 + wn * 64, lane, p);
   } else
-    store_slab_staged<EPI, false, LNF>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], slab, m0 + wm * 64, n0 + wn * 64, lane, p);
+    store_slab_staged<EPI, false>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], slab, m0 + wm * 64, n0 + wn * 64, lane, p);
 }
 
 // =====================================================================================================
@@ -1599,10 +1541,8 @@ static void launch8k(const GemmArgs& p, hipStream_t s) {
 // five half-tile DMAs are issued BEFORE the epilogue of the finished tile and land while its stores drain, and there is no
 // workgroup turn-around. The epilogue therefore cannot park its slabs in the ring: each wave owns 4 KiB of the 32 KiB that
 // the 128 KiB ring leaves free and emits its 128x64 tile as four 32-row fp16 slabs (4 dwordx4 stores each).
-template <bool LN>
 __device__ __forceinline__ void slab_park16h(const f32x16 (&a0), const f32x16 (&a1), half_t* __restrict__ slab,
-                                             const float4 (&bv)[2][4], int lane, bool gelu, const float4 (&sv)[2][4],
-                                             float2 mr) {
+                                             const float4 (&bv)[2][4], int lane, bool gelu) {
   const int lr = lane & 31, lg = lane >> 5;
   const f32x16* accs[2] = {&a0, &a1};
 #pragma unroll
@@ -1611,14 +1551,7 @@ __device__ __forceinline__ void slab_park16h(const f32x16 (&a0), const f32x16 (&
     for (int q = 0; q < 4; ++q) {
       const f32x16& a = *accs[j];
       const float4 b = bv[j][q];
-      float4 v;
-      if (LN) {   // folded LayerNorm, consumer side: rstd * (acc - mean * s[n]) + bias'[n]
-        const float4 sn = sv[j][q];
-        v = make_float4(fmaf(fmaf(-mr.x, sn.x, a[4 * q]), mr.y, b.x), fmaf(fmaf(-mr.x, sn.y, a[4 * q + 1]), mr.y, b.y),
-                        fmaf(fmaf(-mr.x, sn.z, a[4 * q + 2]), mr.y, b.z), fmaf(fmaf(-mr.x, sn.w, a[4 * q + 3]), mr.y, b.w));
-      } else {
-        v = make_float4(a[4 * q] + b.x, a[4 * q + 1] + b.y, a[4 * q + 2] + b.z, a[4 * q + 3] + b.w);
-      }
+      float4 v = make_float4(a[4 * q] + b.x, a[4 * q + 1] + b.y, a[4 * q + 2] + b.z, a[4 * q + 3] + b.w);
       if (gelu) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
       half4_t h = {(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
       *reinterpret_cast<half4_t*>(&slab[lr * 64 + (((j * 4 + q) ^ ((lr >> 1) & 7)) << 3) + 4 * lg]) = h;
@@ -1649,7 +1582,7 @@ __device__ __forceinline__ void slab_emit16h(const half_t* __restrict__ slab, in
 }
 
 // Epilogue of one 128x64 wave tile of the persistent kernels, through the wave's private 4 KiB slab.
-template <int EPI, bool LNF = false>
+template <int EPI>
 __device__ __forceinline__ void persist_epilogue(const f32x16 (&acc)[2][2][2], half_t* __restrict__ slab, int mbase, int nbase,
                                                  int lane, const GemmArgs& p) {
   const int lr = lane & 31, lg = lane >> 5;
@@ -1675,8 +1608,6 @@ __device__ __forceinline__ void persist_epilogue(const f32x16 (&acc)[2][2][2], h
       gvv[j] = p.gamma ? *reinterpret_cast<const float4*>(p.gamma + nbase + j * 32 + c * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
     }
     float4 ra[4], rb[4];
-    float ps1[4] = {0.f, 0.f, 0.f, 0.f}, ps2[4] = {0.f, 0.f, 0.f, 0.f};   // folded LayerNorm: row sums over the wave's 64 columns
-    half4_t hx[2][4];                                                      // and half(x) of the current 32-row strip
     pre(0, ra);
 #pragma unroll
     for (int blk = 0; blk < 8; ++blk) {
@@ -1701,83 +1632,26 @@ __device__ __forceinline__ void persist_epilogue(const f32x16 (&acc)[2][2][2], h
         v.x = (v.x + bv.x) * gv.x + r[it].x; v.y = (v.y + bv.y) * gv.y + r[it].y;
         v.z = (v.z + bv.z) * gv.z + r[it].z; v.w = (v.w + bv.w) * gv.w + r[it].w;
         *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + orow * p.ldo + n) = v;
-        if (LNF && p.out16) hx[blk & 1][it] = half4_t{(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
-        if (LNF && p.stats) {
-          ps1[it] += (v.x + v.y) + (v.z + v.w);
-          ps2[it] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-        }
-      }
-      if (LNF && p.out16 && (blk & 1)) {
-        // half(x) of this 32-row x 64-column strip: through the (consumed) slab so that 8 lanes cover a row with 16 bytes each -
-        // 4 dwordx4 stores instead of 8 dwordx2 (the epilogue is store-ISSUE-bound)
-        half_t* slabh = reinterpret_cast<half_t*>(slabf);
-#pragma unroll
-        for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-          for (int it = 0; it < 4; ++it) {
-            const int row = it * 8 + r8;
-            *reinterpret_cast<half4_t*>(&slabh[row * 64 + (((jb * 4 + (c >> 1)) ^ ((row >> 1) & 7)) << 3) + (c & 1) * 4]) =
-                hx[jb][it];
-          }
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int row = it * 8 + r8;
-          const int m = mbase + (blk >> 1) * 32 + row;
-          const half8_t hv = *reinterpret_cast<const half8_t*>(&slabh[row * 64 + ((c ^ ((row >> 1) & 7)) << 3)]);
-          if (m >= p.M) continue;
-          const size_t orow = p.out_seg ? (size_t)(m / p.out_seg) * p.out_seg_stride + p.out_seg_off + (m % p.out_seg) : (size_t)m;
-          *reinterpret_cast<half8_t*>(p.out16 + orow * p.ld16 + nbase + c * 8) = hv;
-        }
-      }
-      if (LNF && p.stats && (blk & 1)) {   // both 32-column blocks of this 32-row strip are in: 8 lanes hold one row's 64 columns
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          float s1 = ps1[it], s2 = ps2[it];
-#pragma unroll
-          for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-          const int m = mbase + (blk >> 1) * 32 + it * 8 + r8;
-          const size_t orow = p.out_seg ? (size_t)(m / p.out_seg) * p.out_seg_stride + p.out_seg_off + (m % p.out_seg) : (size_t)m;
-          if (c == 0 && m < p.M)
-            *reinterpret_cast<float2*>(p.stats + (orow * (p.N >> 6) + (nbase >> 6)) * 2) = make_float2(s1, s2);
-          ps1[it] = 0.f; ps2[it] = 0.f;
-        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
   } else {  // epilogue of the finished tile from the wave's private slab
-    float4 bv[2][4], sv[2][4];
-    float2 mrv[4];
+    float4 bv[2][4];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < 4; ++q)
         bv[j][q] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nbase + j * 32 + 8 * q + 4 * lg)
                           : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (LNF) sv[j][q] = *reinterpret_cast<const float4*>(p.ln_s + nbase + j * 32 + 8 * q + 4 * lg);
-      }
-    if (LNF) {   // every request of the epilogue in flight at once (one exposed latency, as for the bias)
-#pragma unroll
-      for (int sidx = 0; sidx < 4; ++sidx) {
-        int m = mbase + sidx * 32 + lr;
-        m = m < p.M ? m : p.M - 1;
-        mrv[sidx] = *reinterpret_cast<const float2*>(p.ln_mr + (size_t)m * 2);
-      }
-    }
 #pragma unroll
     for (int sidx = 0; sidx < 4; ++sidx) {
-      if (LNF) {
-        slab_park16h<true>(acc[sidx >> 1][sidx & 1][0], acc[sidx >> 1][sidx & 1][1], slab, bv, lane, EPI == EPI_GELU_F16, sv,
-                           mrv[sidx]);
-      } else {
-        slab_park16h<false>(acc[sidx >> 1][sidx & 1][0], acc[sidx >> 1][sidx & 1][1], slab, bv, lane, EPI == EPI_GELU_F16, bv,
-                            make_float2(0.f, 1.f));
-      }
+      slab_park16h(acc[sidx >> 1][sidx & 1][0], acc[sidx >> 1][sidx & 1][1], slab, bv, lane, EPI == EPI_GELU_F16);
       slab_emit16h(slab, mbase + sidx * 32, nbase, lane, p);
     }
   }
 }
 
-template <int EPI, bool LNF = false>
+template <int EPI>
 __global__ __launch_bounds__(512) void gemm8kp_f16_kernel(GemmArgs p, int total) {
   extern __shared__ __attribute__((aligned(16))) half_t ring[];  // [buf 2][A0 A1 B0 B1][128][64] + 8 x 4 KiB slabs
   constexpr int HT = 128 * 64;
@@ -1918,7 +1792,7 @@ __global__ __launch_bounds__(512) void gemm8kp_f16_kernel(GemmArgs p, int total)
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    persist_epilogue<EPI, LNF>(acc, slab, m0 + wr * 128, n0 + wc * 64, lane, p);
+    persist_epilogue<EPI>(acc, slab, m0 + wr * 128, n0 + wc * 64, lane, p);
     if (!have) break;
     idx = nidx; tm = ntm_; tn = ntn_;
   }
@@ -1929,19 +1803,19 @@ __global__ __launch_bounds__(512) void gemm8kp_f16_kernel(GemmArgs p, int total)
 #undef PHASE_SYNC_OUT
 }
 
-template <int EPI, bool LNF = false>
+template <int EPI>
 static void launch8kp(const GemmArgs& p, hipStream_t s) {
   constexpr int LDS = 2 * 4 * 128 * 64 * 2 + 8 * 4096;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm8kp_f16_kernel<EPI, LNF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)gemm8kp_f16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr = true;
   }
   const int ntm = (p.M + 255) / 256, ntn = p.N / 256;
   GemmArgs q = p;
   q.map_mode = pick_map_mode(ntm, ntn);
   const int total = tile_map_grid(ntm, ntn, q.map_mode);
-  hipLaunchKernelGGL((gemm8kp_f16_kernel<EPI, LNF>), dim3(total < num_cus() ? total : num_cus()), dim3(512), LDS, s, q, total);
+  hipLaunchKernelGGL((gemm8kp_f16_kernel<EPI>), dim3(total < 256 ? total : 256), dim3(512), LDS, s, q, total);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1960,7 +1834,7 @@ static void launch8kp(const GemmArgs& p, hipStream_t s) {
 // the barrier is passed): after load A vmcnt(6) - only A0(t+1) and this part's four stay in flight, A1(t) is in; after load B
 // vmcnt(4). lgkmcnt(0) also sits BEFORE the barrier: the lagging wave row's reads of A0(t) retire before the leading row,
 // one interval later, refills that half-tile with A0(t+2).
-template <int EPI, bool LNF = false>
+template <int EPI>
 __global__ __launch_bounds__(512) void gemm8q_f16_kernel(GemmArgs p, int total) {
   extern __shared__ __attribute__((aligned(16))) half_t ring[];  // [buf 2][A0 A1 B0 B1][128][64] + 8 x 4 KiB slabs
   constexpr int HT = 128 * 64;
@@ -2090,7 +1964,7 @@ __global__ __launch_bounds__(512) void gemm8q_f16_kernel(GemmArgs p, int total) 
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    persist_epilogue<EPI, LNF>(acc, slab, m0 + wr * 128, n0 + wc * 64, lane, p);
+    persist_epilogue<EPI>(acc, slab, m0 + wr * 128, n0 + wc * 64, lane, p);
     if (!have) break;
     idx = nidx; tm = ntm_; tn = ntn_;
   }
@@ -2101,19 +1975,19 @@ __global__ __launch_bounds__(512) void gemm8q_f16_kernel(GemmArgs p, int total) 
 #undef Q_SYNC_OUT
 }
 
-template <int EPI, bool LNF = false>
+template <int EPI>
 static void launch8q(const GemmArgs& p, hipStream_t s) {
   constexpr int LDS = 2 * 4 * 128 * 64 * 2 + 8 * 4096;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm8q_f16_kernel<EPI, LNF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)gemm8q_f16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr = true;
   }
   const int ntm = (p.M + 255) / 256, ntn = p.N / 256;
   GemmArgs q = p;
   q.map_mode = pick_map_mode(ntm, ntn);
   const int total = tile_map_grid(ntm, ntn, q.map_mode);
-  hipLaunchKernelGGL((gemm8q_f16_kernel<EPI, LNF>), dim3(total < num_cus() ? total : num_cus()), dim3(512), LDS, s, q, total);
+  hipLaunchKernelGGL((gemm8q_f16_kernel<EPI>), dim3(total < 256 ? total : 256), dim3(512), LDS, s, q, total);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -2280,7 +2154,7 @@ static void launch4p(const GemmArgs& p, hipStream_t s) {
   const int total = tile_map_grid(ntm, ntn, q.map_mode);
   static const char* tr = getenv("PSAM_GEMM_TRACE");
   if (tr) { (void)hipMalloc((void**)&q.trace, 256 * 4 * sizeof(unsigned long long)); (void)hipMemsetAsync(q.trace, 0, 256 * 32, s); }
-  hipLaunchKernelGGL((gemm4p_f16_kernel<EPI>), dim3(total < num_cus() ? total : num_cus()), dim3(256), LDS, s, q, total);
+  hipLaunchKernelGGL((gemm4p_f16_kernel<EPI>), dim3(total < 256 ? total : 256), dim3(256), LDS, s, q, total);
   if (tr) {   // debugging aid: cycles and wall time inside the k-loops (s_memtime / s_memrealtime at 100 MHz)
     std::vector<unsigned long long> h(256 * 4);
     (void)hipStreamSynchronize(s);
@@ -2340,8 +2214,7 @@ static int pick_tile(int M, int N, int K, int epilogue) {
   // wins. 5 = plain 4-deep ring, 3 = its two-phase staggered variant, 6 = wave-specialised loaders (kept for A/B).
   if (N % 256 == 0) {
     const long t256 = (long)((M + 255) / 256) * (N / 256);
-    const long ncu = num_cus();
-    const long rounds = (t256 + ncu - 1) / ncu;
+    const long rounds = (t256 + 255) / 256;
     // the fp32 residual epilogue with a short K (proj: 20 K-tiles) is better served by two workgroups per CU unless the
     // 256-tiles fill their rounds completely (65536x1280x1280: 603 vs 525 TFLOP/s; 32768x1280x1280, 2.5 rounds: 653 vs 689)
     const bool short_f32 = epilogue == EPI_F32 && K < 2048;
@@ -2349,7 +2222,7 @@ static int pick_tile(int M, int N, int K, int epilogue) {
     // K >= 768: DINOv2-B's shapes at 16 slices (M = 20752) measured 5-45 % faster on the persistent 256-tile kernel than on the
     // 128-tile one (tools/gemm_tiles.py 1,11: qkv 790-820 vs 750, proj 730-760 vs 500-620, fc1 870 vs 740 TFLOP/s; fp32 epilogue
     // 557 vs 497); per-slice calls (M = 1297) fail the fill test and stay on the 128-tile kernel (350 vs 200)
-    if (K >= 768 && t256 * 100 >= rounds * ncu * (short_f32 ? 95 : 80)) {
+    if (K >= 768 && t256 * 100 >= rounds * 256 * (short_f32 ? 95 : 80)) {
       static int f32p = -1;
       if (f32p < 0) { const char* e = getenv("PSAM_GEMM_F32_PERSIST"); f32p = e ? atoi(e) : 1; }
       return epilogue == EPI_F32 && !f32p ? 10 : 11;
@@ -2358,18 +2231,10 @@ static int pick_tile(int M, int N, int K, int epilogue) {
   return 1;
 }
 
-struct LnFold {   // see GemmArgs: LayerNorm folded into the GEMMs either side of it
-  void* out16 = nullptr;
-  int ld16 = 0;
-  float* stats = nullptr;
-  const float* ln_mr = nullptr;
-  const float* ln_s = nullptr;
-};
-
 static int gemm_dispatch(const void* A, const void* W, const float* bias, void* out, const float* resid,
                          const float* gamma, int M, int N, int K, int lda, int ldw, int ldo, int ldr,
                          int resid_mod, int out_seg, int out_seg_stride, int out_seg_off, int epilogue, int head_hd,
-                         void* stream, const LnFold& ln = LnFold()) {
+                         void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || (N % BN) != 0 || (K % BK) != 0 || (lda % 8) != 0 || (ldw % 8) != 0 ||
       (ldo % 4) != 0 || (resid && (ldr % 4) != 0))
     return PSAM_ERR_ARG;
@@ -2392,19 +2257,11 @@ static int gemm_dispatch(const void* A, const void* W, const float* bias, void* 
   p.out_seg = out_seg;
   p.out_seg_stride = out_seg_stride;
   p.out_seg_off = out_seg_off;
-  { static int mm = -2; if (mm == -2) { const char* e = getenv("PSAM_GEMM_MAP"); mm = e ? atoi(e) : (xcd_maps_apply() ? 0 : 1); } p.map_mode = mm; }
+  { static int mm = -2; if (mm == -2) { const char* e = getenv("PSAM_GEMM_MAP"); mm = e ? atoi(e) : 0; } p.map_mode = mm; }
   { const char* e = getenv("PSAM_GEMM_DBG"); p.dbg = e ? atoi(e) : 0; }
   p.trace = nullptr;
   { static int st = -1; if (st < 0) { const char* e = getenv("PSAM_GEMM_STAGGER"); st = e ? atoi(e) : 0; } p.stagger = st; }
   p.head_hd = head_hd;
-  p.out16 = (half_t*)ln.out16;
-  p.ld16 = ln.ld16;
-  p.stats = ln.stats;
-  p.ln_mr = ln.ln_mr;
-  p.ln_s = ln.ln_s;
-  const bool ln_prod = ln.out16 || ln.stats, ln_cons = ln.ln_mr || ln.ln_s;
-  if (ln_prod && (epilogue != EPI_F32 || (ln.out16 && ((ln.ld16 % 8) != 0 || (reinterpret_cast<uintptr_t>(ln.out16) & 15) != 0)))) return PSAM_ERR_ARG;
-  if (ln_cons && (!(epilogue == EPI_F16 || epilogue == EPI_GELU_F16) || !ln.ln_mr || !ln.ln_s)) return PSAM_ERR_ARG;
   const int ntm = (M + BM - 1) / BM, ntn = N / BN;
   dim3 grid(tile_map_grid(ntm, ntn, p.map_mode)), block(256);
   hipStream_t s = (hipStream_t)stream;
@@ -2413,10 +2270,6 @@ static int gemm_dispatch(const void* A, const void* W, const float* bias, void* 
   // the slab epilogues store fp16 rows with 16-byte instructions when the layout allows (tiles 7 / 8 / 10 require it)
   p.wide16 = (ldo % 8) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (!head_hd || head_hd % 8 == 0);
   if ((tsel == 7 || tsel == 8 || tsel == 10 || tsel == 11 || tsel == 13 || tsel == 14) && epilogue != EPI_F32 && !p.wide16) tsel = 1;
-  if (ln_prod || ln_cons) {   // the folded-LayerNorm epilogues live in the 128x128 kernel and the persistent 256x256 ones
-    if (tsel != 11 && tsel != 14) tsel = 1;
-    if (ln_cons && !p.wide16) return PSAM_ERR_ARG;
-  }
   if ((tsel == 3 || tsel == 5) && N % 256 == 0) {
     if (tsel == 3) {
       if (epilogue == EPI_F16) launch256<EPI_F16, 256, 1>(p, s);
@@ -2434,27 +2287,6 @@ static int gemm_dispatch(const void* A, const void* W, const float* bias, void* 
     if (epilogue == EPI_F16) launch4p<EPI_F16>(p, s);
     else if (epilogue == EPI_GELU_F16) launch4p<EPI_GELU_F16>(p, s);
     else launch4p<EPI_F32>(p, s);
-    return psam_launch_status();
-  }
-  const bool lnf = ln_prod || ln_cons;
-  if (lnf && (tsel == 14 || tsel == 11) && N % 256 == 0) {   // separate instantiations: the plain kernels stay as they were
-    if (tsel == 14) {
-      if (epilogue == EPI_F16) launch8q<EPI_F16, true>(p, s);
-      else if (epilogue == EPI_GELU_F16) launch8q<EPI_GELU_F16, true>(p, s);
-      else launch8q<EPI_F32, true>(p, s);
-    } else {
-      if (epilogue == EPI_F16) launch8kp<EPI_F16, true>(p, s);
-      else if (epilogue == EPI_GELU_F16) launch8kp<EPI_GELU_F16, true>(p, s);
-      else launch8kp<EPI_F32, true>(p, s);
-    }
-    return psam_launch_status();
-  }
-  if (lnf) {
-    switch (epilogue) {
-      case EPI_F16: hipLaunchKernelGGL((gemm_f16_kernel<EPI_F16, true>), grid, block, 0, s, p); break;
-      case EPI_GELU_F16: hipLaunchKernelGGL((gemm_f16_kernel<EPI_GELU_F16, true>), grid, block, 0, s, p); break;
-      default: hipLaunchKernelGGL((gemm_f16_kernel<EPI_F32, true>), grid, block, 0, s, p); break;
-    }
     return psam_launch_status();
   }
   if (tsel == 14 && N % 256 == 0) {
@@ -2535,21 +2367,6 @@ extern "C" int psam_gemm_f16(const void* A, const void* W, const float* bias, vo
                              void* stream) {
   return gemm_dispatch(A, W, bias, out, resid, gamma, M, N, K, lda, ldw, ldo, ldr, resid_mod, out_seg, out_seg_stride,
                        out_seg_off, epilogue, 0, stream);
-}
-
-// psam_gemm_f16 with a LayerNorm folded into the GEMMs either side of it (see GemmArgs): the residual-stream GEMM (epilogue 2)
-// also emits fp16(x) and per-row partial sums, the consuming GEMM (epilogue 0 / 1) runs on fp16(x) with W pre-multiplied by
-// the LayerNorm weight and corrects by (mean, rstd) per row. No LayerNorm pass, no cast pass, same arithmetic up to rounding
-// (modeling/image_encoder.py:174-193: norm1 -> attn.qkv, norm2 -> mlp.lin1; DINOv2 Block likewise).
-extern "C" int psam_gemm_f16_ln(const void* A, const void* W, const float* bias, void* out, const float* resid,
-                                const float* gamma, int M, int N, int K, int lda, int ldw, int ldo, int ldr, int resid_mod,
-                                int out_seg, int out_seg_stride, int out_seg_off, int epilogue, void* out16, int ld16,
-                                float* stats, const float* ln_mr, const float* ln_s, void* stream) {
-  LnFold ln;
-  ln.out16 = out16; ln.ld16 = ld16; ln.stats = stats; ln.ln_mr = ln_mr; ln.ln_s = ln_s;
-  if (stats && (N % 64) != 0) return PSAM_ERR_ARG;
-  return gemm_dispatch(A, W, bias, out, resid, gamma, M, N, K, lda, ldw, ldo, ldr, resid_mod, out_seg, out_seg_stride,
-                       out_seg_off, epilogue, 0, stream, ln);
 }
 
 // The packed qkv projection with a HEAD-MAJOR result: out half [N / hd planes][M][hd] (plane = which*H + h), so that the

@@ -11,7 +11,7 @@ import os
 import torch  # noqa: F401  (must precede the CDLL below: loads PyTorch's libamdhip64)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libprotosam_hip.so")
+LIB_PATH = os.environ.get("PSAM_LIB_PATH") or os.path.join(_HERE, "libprotosam_hip.so")   # (override: A/B of library builds)
 
 c_void_p, c_int, c_float, c_longlong = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong
 

@@ -97,7 +97,12 @@ class DinoVisionTransformer(nn.Module):
         self._packed = None
         self._pos_cache = {}
         self._ws = {}
-        self.fold_ln = os.environ.get("PSAM_FOLD_LN", "1") != "0"
+        # measured on MI355X (bench.py, 16-slice steps, same box, interleaved): 122.2 slices/s folded vs 124.3 with the separate
+        # LayerNorm passes - the passes (7 ms per step) are cheaper than what the extra fp16 copy, row sums and row-scale loads
+        # add to the persistent GEMM's epilogues (+10 ms), which nothing overlaps (profiles/r02_fold*_kernel_trace.md). Off by
+        # default; PSAM_FOLD_LN=1 / `fold_ln = True` selects it (it also lowers the embedding error: sigmoid(low_res) 4.6e-4 vs
+        # 6.2e-4 on config 4).
+        self.fold_ln = os.environ.get("PSAM_FOLD_LN", "0") != "0"
 
     # -- weight packing (fp16 GEMM operands); rebuilt whenever parameters change -----------------------------
     def _apply(self, fn, *a, **k):

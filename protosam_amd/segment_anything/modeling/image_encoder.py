@@ -91,7 +91,12 @@ class ImageEncoderViT(nn.Module):
                                   LayerNorm2d(out_chans))
         self._packed = None
         self._ws = {}
-        self.fold_ln = os.environ.get("PSAM_FOLD_LN", "1") != "0"
+        # measured on MI355X (bench.py, 16-slice steps, same box, interleaved): 122.2 slices/s folded vs 124.3 with the separate
+        # LayerNorm passes - the passes (7 ms per step) are cheaper than what the extra fp16 copy, row sums and row-scale loads
+        # add to the persistent GEMM's epilogues (+10 ms), which nothing overlaps (profiles/r02_fold*_kernel_trace.md). Off by
+        # default; PSAM_FOLD_LN=1 / `fold_ln = True` selects it (it also lowers the embedding error: sigmoid(low_res) 4.6e-4 vs
+        # 6.2e-4 on config 4).
+        self.fold_ln = os.environ.get("PSAM_FOLD_LN", "0") != "0"
 
     def _apply(self, fn, *a, **k):
         self._packed, self._ws = None, {}
@@ -155,7 +160,7 @@ class ImageEncoderViT(nn.Module):
 
     def encode_patches(self, patches, B):
         """patches fp16 [B*4096, 3*16*16] (im2col of the normalised image) -> token-major embedding fp32 [B,4096,out].
-        `fold_ln` (default): the blocks' LayerNorms never run as passes of their own - the GEMM that updates the residual
+        `fold_ln` (optional, see __init__): the blocks' LayerNorms never run as passes of their own - the GEMM that updates the residual
         stream also emits half(x) and per-row partial sums, `ln_finalize` turns them into (mean, rstd), and the consuming
         GEMM (qkv / lin1, weights pre-multiplied by the LayerNorm weight) applies them in its epilogue. Same arithmetic up to
         rounding (tools/emulate_ln_fusion.py: embedding error 6.4e-4 mean vs 7.0e-4 for the separate LayerNorm pass)."""

@@ -192,3 +192,25 @@ def test_image_encoder_rel_pos_table_resize(dev):
     err = (out.cpu() - ref).abs()
     print(f"resized rel-pos tables: max abs err {err.max():.3e} mean {err.mean():.3e}")
     assert err.max() < 5e-2 and err.mean() < 3e-3
+
+
+def test_image_encoder_folded_layernorm_path(dev):
+    """`fold_ln = True` (LayerNorm folded into the GEMMs either side of it, psam_gemm_f16_ln) against the oracle and against
+    the default path with the separate LayerNorm passes."""
+    from oracle import sam_image_encoder as oenc
+    sam, sd = _sam(dev, "vit_b", 3)
+    img = _image(4)
+    x = (img.float() - torch.tensor([123.675, 116.28, 103.53]).view(1, 3, 1, 1)) / torch.tensor(
+        [58.395, 57.12, 57.375]).view(1, 3, 1, 1)
+    ref = oenc.image_encoder(x, sd, model_type="vit_b", depth=3)
+    xin = sam.preprocess(img.to(dev))
+    outs = {}
+    for fold in (False, True):
+        sam.image_encoder.fold_ln = fold
+        outs[fold] = sam.image_encoder(xin).cpu().clone()
+    sam.image_encoder.fold_ln = False
+    for fold, o in outs.items():
+        err = (o - ref).abs()
+        print(f"fold_ln={fold}: max abs err {err.max():.3e} mean {err.mean():.3e}")
+        assert err.max() < 5e-2 and err.mean() < 3e-3
+    assert (outs[True] - outs[False]).abs().max() < 5e-2
