@@ -180,6 +180,10 @@ int psam_mask_stats(const float* low, int B, int C, int first, int nsel, int IN,
  * label uint8 [H,W]: counts int64 [n,3] = {tp, fp, fn} against it (models/SamWrapper.py:8-13 get_iou). */
 int psam_mask_binarize(const float* low, const int* idx, int n, int IN, int MID, int H, int W, int variant, float thr,
                        unsigned char* out, const unsigned char* label, long long* counts, void* stream);
+/* the same statistics (and the binary masks, out uint8 [n,H,W] or null) of MATERIALISED candidate planes fp32 [n,H,W]: the
+ * generator's crop layers / images not at the model input size (second resize of postprocess_masks).
+ * automatic_mask_generator.py:221-316; utils/amg.py:156-176, 303-346 */
+int psam_plane_stats(const float* planes, int n, int H, int W, float thr, float off, int* stats, void* out, void* stream);
 
 /* PromptEncoder.mask_downscaling for mask prompts: masks fp32 [n,4g,4g] -> dense embeddings fp32 token-major [n,g*g,256].
  * wts = c1w[4][4] c1b[4] n1w[4] n1b[4] c2w[16][4][2][2] c2b[16] n2w[16] n2b[16] c3w[256][16] c3b[256] (4684 floats).

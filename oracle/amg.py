@@ -2,8 +2,10 @@
 Test infrastructure only (see oracle/__init__.py).
 
 Follows models/segment_anything/automatic_mask_generator.py (generate :139-192, _generate_masks :194-219,
-_process_crop :221-262, _process_batch :264-316) with the reference's defaults (crop_n_layers = 0,
-min_mask_region_area = 0), models/segment_anything/utils/amg.py (build_point_grid :179-187,
+_process_crop :221-262, _process_batch :264-316, postprocess_small_regions :332-380) including crop layers
+(crop_n_layers > 0: generate_crop_boxes utils/amg.py:202-237, is_box_near_crop_edge :78-88, uncrop_* :240-265) and
+min_mask_region_area > 0 (remove_small_regions :267-291, on the restated connected components of oracle/glue.py - cv2 is
+absent), models/segment_anything/utils/amg.py (build_point_grid :179-187,
 calculate_stability_score :156-176, batched_mask_to_box :303-346, mask_to_rle_pytorch / rle_to_mask :108-153) and
 models/SamWrapper.py (get_iou :8-13, forward :29-50).
 
@@ -90,11 +92,154 @@ def rle_to_mask(r):
     return m.reshape(w, h).transpose()
 
 
+def crop_boxes_for(im_size, n_layers, overlap_ratio):
+    """utils/amg.py:202-237 generate_crop_boxes -> (boxes XYXY, layer index per box)."""
+    import math
+    from itertools import product
+    boxes, layers = [], []
+    im_h, im_w = im_size
+    short = min(im_h, im_w)
+    boxes.append([0, 0, im_w, im_h])
+    layers.append(0)
+    for i_layer in range(n_layers):
+        n = 2 ** (i_layer + 1)
+        overlap = int(overlap_ratio * short * (2 / n))
+        cw = int(math.ceil((overlap * (n - 1) + im_w) / n))
+        ch = int(math.ceil((overlap * (n - 1) + im_h) / n))
+        for x0, y0 in product([int((cw - overlap) * i) for i in range(n)], [int((ch - overlap) * i) for i in range(n)]):
+            boxes.append([x0, y0, min(x0 + cw, im_w), min(y0 + ch, im_h)])
+            layers.append(i_layer + 1)
+    return boxes, layers
+
+
+def box_near_crop_edge(boxes, crop_box, orig_box, atol=20.0):
+    """utils/amg.py:78-88 (boxes int64 [n,4] in the crop's frame)."""
+    cb = torch.as_tensor(crop_box, dtype=torch.float)
+    ob = torch.as_tensor(orig_box, dtype=torch.float)
+    b = (boxes + torch.tensor([[crop_box[0], crop_box[1], crop_box[0], crop_box[1]]])).float()
+    near_crop = torch.isclose(b, cb[None, :], atol=atol, rtol=0)
+    near_img = torch.isclose(b, ob[None, :], atol=atol, rtol=0)
+    return torch.any(near_crop & ~near_img, dim=1)
+
+
+def remove_small_regions(mask, area_thresh, mode):
+    """utils/amg.py:267-291 with cv2.connectedComponentsWithStats(., 8) restated (oracle/glue.py)."""
+    from .glue import connected_components_with_stats
+    correct_holes = mode == "holes"
+    working = (correct_holes ^ mask).astype(np.uint8)
+    n_labels, regions, stats, _ = connected_components_with_stats(working)
+    sizes = stats[:, -1][1:]
+    small = [i + 1 for i, s_ in enumerate(sizes) if s_ < area_thresh]
+    if len(small) == 0:
+        return mask, False
+    fill = [0] + small
+    if not correct_holes:
+        fill = [i for i in range(n_labels) if i not in fill]
+        if len(fill) == 0:
+            fill = [int(np.argmax(sizes)) + 1]
+    return np.isin(regions, fill), True
+
+
 def generate(image_u8, sd, sam_type="vit_b", points_per_side=32, points_per_batch=64, pred_iou_thresh=0.88,
              stability_score_thresh=0.95, stability_score_offset=1.0, box_nms_thresh=0.7, custom_points="false",
-             postprocess="batched", encoder_depth=None, features=None, taps=None):
-    """-> list of records as SamAutomaticMaskGenerator.generate (output_mode 'binary_mask'), for an image whose long side
-    is already 1024 and square (SamWrapper.forward resizes before calling, SamWrapper.py:37)."""
+             postprocess="batched", encoder_depth=None, features=None, taps=None, crop_n_layers=0, crop_nms_thresh=0.7,
+             crop_overlap_ratio=512 / 1500, crop_n_points_downscale_factor=1, min_mask_region_area=0):
+    """-> list of records as SamAutomaticMaskGenerator.generate (output_mode 'binary_mask')."""
+    if crop_n_layers == 0 and min_mask_region_area == 0:
+        return _generate_layer0(image_u8, sd, sam_type, points_per_side, points_per_batch, pred_iou_thresh,
+                                stability_score_thresh, stability_score_offset, box_nms_thresh, custom_points, postprocess,
+                                encoder_depth, features, taps)
+    from .glue import apply_image
+    H, W = image_u8.shape[:2]
+    boxes, layers = crop_boxes_for((H, W), crop_n_layers, crop_overlap_ratio)
+    grids = [point_grid(int(points_per_side / (crop_n_points_downscale_factor ** i))) for i in range(crop_n_layers + 1)]
+    pe = odec.dense_pe(sd)
+    D = dict(iou=[], stab=[], box=[], pts=[], mask=[], crop=[])
+    for cb, li in zip(boxes, layers):                                           # :204-206
+        x0, y0, x1, y1 = cb
+        crop = image_u8[y0:y1, x0:x1, :]
+        ch, cw = crop.shape[:2]
+        rz = apply_image(crop)                                                  # set_image: PIL resize of the long side
+        in_size = tuple(rz.shape[:2])
+        feats = oenc.image_encoder(sam_preprocess(rz), sd, model_type=sam_type, depth=encoder_depth)
+        pts_all = grids[li] * np.array([[cw, ch]])
+        c = dict(iou=[], stab=[], box=[], pts=[], mask=[])
+        for lo in range(0, len(pts_all), points_per_batch):
+            pts = pts_all[lo:lo + points_per_batch]
+            tp = torch.as_tensor(odec.apply_coords(pts, (ch, cw)))
+            if custom_points:
+                pos = torch.ones(tp.shape[0] // 2, dtype=torch.int)
+                labels = torch.cat((pos, torch.zeros_like(pos)), dim=0)
+            else:
+                labels = torch.ones(tp.shape[0], dtype=torch.int)
+            sparse, dense = odec.prompt_encoder(sd, (tp[:, None, :], labels[:, None]), None)
+            low, iou = odec.mask_decoder(sd, feats, pe, sparse, dense, True)
+            masks = odec.postprocess_masks(low, in_size, (ch, cw), postprocess)
+            masks, iou = masks.flatten(0, 1), iou.flatten(0, 1)
+            bp = torch.as_tensor(pts.repeat(3, axis=0))
+            keep = torch.ones(len(iou), dtype=torch.bool)
+            if pred_iou_thresh > 0.0:
+                keep &= iou > pred_iou_thresh
+            masks, iou, bp = masks[keep], iou[keep], bp[keep]
+            inter = (masks > (0.0 + stability_score_offset)).sum(-1, dtype=torch.int16).sum(-1, dtype=torch.int32)
+            union = (masks > (0.0 - stability_score_offset)).sum(-1, dtype=torch.int16).sum(-1, dtype=torch.int32)
+            stab = inter / union
+            if stability_score_thresh > 0.0:
+                k2 = stab >= stability_score_thresh
+                masks, iou, bp, stab = masks[k2], iou[k2], bp[k2], stab[k2]
+            m = masks > 0.0
+            bx = mask_to_box(m)
+            k3 = ~box_near_crop_edge(bx, cb, [0, 0, W, H])                      # :309-311
+            m, iou, bp, stab, bx = m[k3], iou[k3], bp[k3], stab[k3], bx[k3]
+            full = torch.zeros((m.shape[0], H, W), dtype=torch.bool)            # uncrop_masks :252-265
+            full[:, y0:y1, x0:x1] = m
+            c["iou"].append(iou); c["stab"].append(stab); c["box"].append(bx); c["pts"].append(bp); c["mask"].append(full)
+        ci = {k: torch.cat(v) for k, v in c.items()}
+        keep = batched_nms(ci["box"].float(), ci["iou"], torch.zeros_like(ci["box"][:, 0]), box_nms_thresh)   # :244-250
+        D["iou"].append(ci["iou"][keep]); D["stab"].append(ci["stab"][keep]); D["mask"].append(ci["mask"][keep])
+        D["box"].append(ci["box"][keep] + torch.tensor([[x0, y0, x0, y0]]))     # uncrop_boxes_xyxy
+        D["pts"].append(ci["pts"][keep] + torch.tensor([[x0, y0]]))             # uncrop_points
+        D["crop"].append(torch.tensor([cb for _ in range(len(keep))]).reshape(-1, 4))
+    A = {k: torch.cat(v) for k, v in D.items()}
+    if len(boxes) > 1:                                                          # :208-218: prefer masks from smaller crops
+        cr = A["crop"].float()
+        scores = 1 / ((cr[:, 2] - cr[:, 0]) * (cr[:, 3] - cr[:, 1]))
+        keep = batched_nms(A["box"].float(), scores, torch.zeros_like(A["box"][:, 0]), crop_nms_thresh)
+        A = {k: v[keep] for k, v in A.items()}
+    masks_np = [rle_to_mask(rle(m.numpy())) for m in A["mask"]]
+    boxes_t = A["box"].clone()
+    keep_final = list(range(len(masks_np)))
+    if min_mask_region_area > 0 and len(masks_np):                              # :332-380
+        new_masks, scores = [], []
+        for m in masks_np:
+            m2, ch1 = remove_small_regions(m, min_mask_region_area, "holes")
+            m2, ch2 = remove_small_regions(m2, min_mask_region_area, "islands")
+            new_masks.append(torch.as_tensor(m2).unsqueeze(0))
+            scores.append(float(not ch1 and not ch2))
+        nm = torch.cat(new_masks, dim=0)
+        nb = mask_to_box(nm)
+        keep = batched_nms(nb.float(), torch.as_tensor(scores), torch.zeros_like(nb[:, 0]),
+                           max(box_nms_thresh, crop_nms_thresh))
+        for i in keep.tolist():
+            if scores[i] == 0.0:
+                masks_np[i] = rle_to_mask(rle(nm[i].numpy()))
+                boxes_t[i] = nb[i]
+        keep_final = keep.tolist()
+    anns = []
+    for i in keep_final:
+        b = boxes_t[i].tolist()
+        cbx = A["crop"][i].tolist()
+        anns.append({"segmentation": masks_np[i], "area": int(masks_np[i].sum()), "bbox": [b[0], b[1], b[2] - b[0], b[3] - b[1]],
+                     "predicted_iou": A["iou"][i].item(), "point_coords": [A["pts"][i].tolist()],
+                     "stability_score": A["stab"][i].item(),
+                     "crop_box": [cbx[0], cbx[1], cbx[2] - cbx[0], cbx[3] - cbx[1]]})
+    return anns
+
+
+def _generate_layer0(image_u8, sd, sam_type, points_per_side, points_per_batch, pred_iou_thresh, stability_score_thresh,
+                     stability_score_offset, box_nms_thresh, custom_points, postprocess, encoder_depth, features, taps):
+    """The layer-0 crop only (crop_n_layers = 0, min_mask_region_area = 0: the reference's defaults), for an image whose long
+    side is already 1024 and square (SamWrapper.forward resizes before calling, SamWrapper.py:37)."""
     h, w = image_u8.shape[:2]
     assert (h, w) == (1024, 1024)
     if features is None:

@@ -58,6 +58,9 @@ def decoder_cases():
 AMG_SEED = 2024
 AMG_ENCODER_DEPTH = 2          # vit_b block stack truncated to [window, window] so the CPU reference runs in seconds
 AMG_ARGS = dict(points_per_side=8, points_per_batch=32, box_nms_thresh=1.0)
+# the crop-layer case on the small image: every candidate kept by the score filters (thresholds 0), holes / islands below 6 px
+AMG_CROP_ARGS = dict(points_per_side=8, points_per_batch=32, box_nms_thresh=1.0, pred_iou_thresh=0.0,
+                     stability_score_thresh=0.0, crop_n_layers=1, crop_n_points_downscale_factor=2, min_mask_region_area=6)
 
 
 def amg_case():
@@ -143,3 +146,14 @@ def predictor_image(hw, seed=0):
                                         mode="bilinear")[0]
     f = (f - f.min()) / (f.max() - f.min()) * 255
     return f.permute(1, 2, 0).numpy().astype(np.uint8)
+
+
+def amg_small_case():
+    """uint8 [48,44,3]: small enough that every crop edge is within is_box_near_crop_edge's 20-pixel tolerance of the image
+    edge (utils/amg.py:78-88; layer-1 crops are 32 x 30 at offsets 0 / 17 and 0 / 15), so masks of the layer-1 crops survive
+    that filter even with noise-like synthetic masks; it also makes set_image resize every crop (to a long side of 1024) and
+    postprocess_masks take its second resize, on non-square crops."""
+    from protosam_amd.synth import synth_pair
+    _, _, q_img, _ = synth_pair(64, seed=9)
+    q = q_img[0, :, 8:56, 10:54].permute(1, 2, 0).numpy()
+    return ((q - q.min()) / (q.max() - q.min()) * 255).astype("uint8")

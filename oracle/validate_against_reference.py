@@ -55,7 +55,8 @@ def install_shims():
                                     InterpolationMode=modes)
     tv.ops = stub("torchvision.ops")
     from oracle import amg as oamg  # torchvision.ops NMS is absent: the restated one is injected (oracle/amg.py header)
-    tv.ops.boxes = stub("torchvision.ops.boxes", batched_nms=oamg.batched_nms, box_area=None)
+    tv.ops.boxes = stub("torchvision.ops.boxes", batched_nms=oamg.batched_nms,
+                        box_area=lambda b: (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]))   # published contract, XYXY
     stub("cv2")
     stub("kneed")
     sys.path.insert(0, os.path.join(REF, "models"))
@@ -387,6 +388,42 @@ def check_amg(gold):
     d = int((best_ref != best_ora).sum())
     print(f"  [{'ok' if d <= 4 else 'FAIL'}] SamWrapper.forward: best mask #{bi} (IoU {float(ious[bi]):.4f}), {d} differing pixels")
     assert d <= 4
+    # crop layers (crop_n_layers = 1: the image + 2 x 2 overlapping crops, re-encoded each) and small-region removal
+    # (min_mask_region_area > 0; cv2.connectedComponentsWithStats comes from the oracle's restatement, as everywhere else) on
+    # a SMALL image (gi.amg_small_case: see there why). Two settings: no suppression (every candidate of every crop becomes a
+    # record and goes through the hole / island removal) and the default crop_nms_thresh (one survivor per crop: the
+    # cross-crop NMS that prefers smaller crops).
+    _install_cv2_restatements()
+    img_s = gi.amg_small_case()
+    hs, ws_ = img_s.shape[:2]
+    for tag, extra in (("all", dict(crop_nms_thresh=1.0)), ("nms", dict())):
+        kwc = dict(gi.AMG_CROP_ARGS, **extra)
+        with torch.no_grad():
+            ref_c = SamAutomaticMaskGenerator(sam, **kwc).generate(img_s)
+        ora_c = oamg.generate(img_s, sd, encoder_depth=gi.AMG_ENCODER_DEPTH, **kwc)
+        n_crop = sum(1 for r in ref_c if r["crop_box"] != [0, 0, ws_, hs])
+        print(f"  crops + small regions ({tag}): {len(ref_c)} records, {n_crop} from the four layer-1 crops")
+        assert len(ref_c) == len(ora_c) and n_crop > 0 and len(ref_c) > n_crop
+        for k in ("predicted_iou", "stability_score"):
+            close([r[k] for r in ora_c], [r[k] for r in ref_c], 2e-5, f"crops {tag}: {k}")
+        for k in ("bbox", "area", "point_coords", "crop_box"):
+            close(np.array([r[k] for r in ora_c], dtype=np.float64).reshape(len(ref_c), -1),
+                  np.array([r[k] for r in ref_c], dtype=np.float64).reshape(len(ref_c), -1), 0, f"crops {tag}: {k}")
+        diff = max(int((a["segmentation"] != b["segmentation"]).sum()) for a, b in zip(ora_c, ref_c))
+        print(f"  [{'ok' if diff == 0 else 'FAIL'}] crops {tag}: segmentation: at most {diff} differing pixels per mask")
+        assert diff == 0
+        if tag == "all":
+            plain = SamAutomaticMaskGenerator(sam, **dict(kwc, min_mask_region_area=0)).generate(img_s)
+            changed = sum(1 for a, b in zip(ref_c, plain) if a["area"] != b["area"])
+            print(f"  (hole / island removal changed {changed} of {len(ref_c)} masks)")
+            assert changed > 10
+        gold[f"amgc_{tag}_pred_iou"] = np.array([r["predicted_iou"] for r in ref_c], dtype=np.float32)
+        gold[f"amgc_{tag}_stability"] = np.array([r["stability_score"] for r in ref_c], dtype=np.float32)
+        gold[f"amgc_{tag}_bbox"] = np.array([r["bbox"] for r in ref_c], dtype=np.int32)
+        gold[f"amgc_{tag}_area"] = np.array([r["area"] for r in ref_c], dtype=np.int32)
+        gold[f"amgc_{tag}_points"] = np.array([r["point_coords"][0] for r in ref_c], dtype=np.float64)
+        gold[f"amgc_{tag}_crop_box"] = np.array([r["crop_box"] for r in ref_c], dtype=np.int32)
+        gold[f"amgc_{tag}_mask_bits"] = np.stack([np.packbits(r["segmentation"]) for r in ref_c])
     gold["amg_thresholds"] = np.array([t_iou, t_stab], dtype=np.float64)
     gold["amg_iou_all"] = taps["iou_all"].numpy().astype(np.float32)   # oracle values; the reference exposes kept ones only
     gold["amg_pred_iou"] = np.array([r["predicted_iou"] for r in ref], dtype=np.float32)

@@ -64,6 +64,7 @@ SIGNATURES = {
                            c_void_p, c_void_p],
     "psam_neg_points": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p],
     "psam_mask_downscale": [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p],
+    "psam_plane_stats": [c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p],
     "psam_mask_binarize": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
                            c_void_p, c_void_p],
     "psam_normalize_chw": [c_void_p, c_int, c_int, c_longlong, ctypes.POINTER(c_float), ctypes.POINTER(c_float),

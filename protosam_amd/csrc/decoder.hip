@@ -832,6 +832,55 @@ extern "C" int psam_mask_binarize(const float* low, const int* idx, int n, int I
   return psam_launch_status();
 }
 
+// Statistics (and the binary mask) of MATERIALISED candidate planes: the crop layers of the automatic mask generator
+// (automatic_mask_generator.py:221-316 with crop_n_layers > 0) and images that are not at the model's input size take the second
+// resize of postprocess_masks, so their candidates exist at full resolution before they are reduced. planes fp32 [n, H, W]
+// -> stats int32 [n, 8] as psam_mask_stats; out (optional) uint8 [n, H, W] = plane > thr.
+__global__ __launch_bounds__(256) void plane_stats_kernel(const float* __restrict__ planes, int H, int W, float thr, float off,
+                                                          int* __restrict__ stats, uint8_t* __restrict__ out) {
+  const int p = blockIdx.y;
+  const float* src = planes + (size_t)p * H * W;
+  const int y0 = blockIdx.x * MS_ROWS, y1 = min(y0 + MS_ROWS, H);
+  int hi = 0, lo = 0, ar = 0, mnx = 0x7fffffff, mny = 0x7fffffff, mxx = -1, mxy = -1;
+  for (int y = y0; y < y1; ++y) {
+    for (int x = threadIdx.x; x < W; x += blockDim.x) {
+      const float v = src[(size_t)y * W + x];
+      hi += v > thr + off;
+      lo += v > thr - off;
+      const int m = v > thr;
+      if (out) out[((size_t)p * H + y) * W + x] = (uint8_t)m;
+      if (m) {
+        ++ar;
+        mnx = min(mnx, x); mxx = max(mxx, x);
+        mny = min(mny, y); mxy = max(mxy, y);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    hi += __shfl_xor(hi, o, 64); lo += __shfl_xor(lo, o, 64); ar += __shfl_xor(ar, o, 64);
+    mnx = min(mnx, __shfl_xor(mnx, o, 64)); mny = min(mny, __shfl_xor(mny, o, 64));
+    mxx = max(mxx, __shfl_xor(mxx, o, 64)); mxy = max(mxy, __shfl_xor(mxy, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0 && (lo || ar)) {
+    int* s = stats + (size_t)p * 8;
+    if (hi) atomicAdd(s + 0, hi);
+    if (lo) atomicAdd(s + 1, lo);
+    if (ar) {
+      atomicAdd(s + 2, ar);
+      atomicMin(s + 3, mnx); atomicMin(s + 4, mny); atomicMax(s + 5, mxx); atomicMax(s + 6, mxy);
+    }
+  }
+}
+extern "C" int psam_plane_stats(const float* planes, int n, int H, int W, float thr, float off, int* stats, void* out,
+                                void* stream) {
+  if (n <= 0 || H <= 0 || W <= 0 || off < 0.f) return PSAM_ERR_ARG;
+  hipLaunchKernelGGL(mask_stats_init_kernel, dim3((n * 8 + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, n);
+  hipLaunchKernelGGL(plane_stats_kernel, dim3((H + MS_ROWS - 1) / MS_ROWS, n), dim3(256), 0, (hipStream_t)stream, planes, H, W,
+                     thr, off, stats, (uint8_t*)out);
+  return psam_launch_status();
+}
+
 // ---- mask prompts: PromptEncoder.mask_downscaling (prompt_encoder.py:51-59,102-105) as one kernel -----------------------
 // Conv2d(1->4, k2 s2) -> LayerNorm2d(4) -> GELU -> Conv2d(4->16, k2 s2) -> LayerNorm2d(16) -> GELU -> Conv2d(16->256, k1)
 // on masks fp32 [n, 4g, 4g] -> token-major dense embeddings fp32 [n, g*g, 256]. One workgroup = 16 tokens x 256 output

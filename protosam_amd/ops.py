@@ -615,6 +615,18 @@ def mask_stats(low, first, nsel, MID, H, W, variant, thr=0.0, off=1.0, stats=Non
     return stats
 
 
+def plane_stats(planes, thr=0.0, off=1.0, binarize=True):
+    """planes fp32 [n,H,W] -> (stats int32 [n,8] as mask_stats, uint8 [n,H,W] = plane > thr or None)."""
+    _req(planes, torch.float32, "planes")
+    assert planes.is_contiguous() and planes.dim() == 3
+    n, H, W = planes.shape
+    stats = torch.empty((n, 8), dtype=torch.int32, device=planes.device)
+    out = torch.empty((n, H, W), dtype=torch.uint8, device=planes.device) if binarize else None
+    st = _lib.lib().psam_plane_stats(_ptr(planes), n, H, W, float(thr), float(off), _ptr(stats), _ptr(out), _stream())
+    _lib.check(st, "psam_plane_stats")
+    return stats, out
+
+
 def mask_binarize(low, idx, MID, H, W, variant, thr=0.0, label=None, out=None):
     """uint8 [n,H,W] = upsample(low.view(-1,IN,IN)[idx[i]]) > thr; with `label` uint8 [H,W] also int64 [n,3] {tp,fp,fn}."""
     _req(low, torch.float32, "low"); _req(idx, torch.int32, "idx")

@@ -81,3 +81,35 @@ def nms_xyxy(boxes, scores, iou_threshold):
             iou = inter / (area[i] + area[rest] - inter)
         dead[rest[iou.astype(np.float64) > iou_threshold]] = True
     return np.asarray(keep, dtype=np.int64)
+
+
+def generate_crop_boxes(im_size, n_layers, overlap_ratio):
+    """utils/amg.py:202-237: the image box, then (2**i)**2 overlapping crops for layer i. -> (boxes XYXY, layer per box)."""
+    import math
+    from itertools import product
+    boxes, layers = [], []
+    im_h, im_w = im_size
+    short = min(im_h, im_w)
+    boxes.append([0, 0, im_w, im_h])
+    layers.append(0)
+    for i_layer in range(n_layers):
+        n = 2 ** (i_layer + 1)
+        overlap = int(overlap_ratio * short * (2 / n))
+        cw = int(math.ceil((overlap * (n - 1) + im_w) / n))
+        ch = int(math.ceil((overlap * (n - 1) + im_h) / n))
+        xs = [int((cw - overlap) * i) for i in range(n)]
+        ys = [int((ch - overlap) * i) for i in range(n)]
+        for x0, y0 in product(xs, ys):
+            boxes.append([x0, y0, min(x0 + cw, im_w), min(y0 + ch, im_h)])
+            layers.append(i_layer + 1)
+    return boxes, layers
+
+
+def is_box_near_crop_edge(boxes, crop_box, orig_box, atol=20.0):
+    """utils/amg.py:78-88: a box edge within `atol` of the crop's edge but not of the image's. boxes int [n,4] in the crop's
+    frame -> bool [n]. (torch.isclose with rtol = 0 is |a - b| <= atol.)"""
+    b = np.asarray(boxes, dtype=np.float32).reshape(-1, 4) + np.array([[crop_box[0], crop_box[1], crop_box[0], crop_box[1]]],
+                                                                      dtype=np.float32)
+    near_crop = np.abs(b - np.asarray(crop_box, dtype=np.float32)[None, :]) <= atol
+    near_img = np.abs(b - np.asarray(orig_box, dtype=np.float32)[None, :]) <= atol
+    return np.any(near_crop & ~near_img, axis=1)

@@ -91,10 +91,12 @@ def test_custom_points_label_rule():
         g._point_labels(11)
     g = SamAutomaticMaskGenerator(sam, points_per_side=4, points_per_batch=8, custom_points=False)
     assert g._point_labels(11).tolist() == [1] * 11
-    with pytest.raises(NotImplementedError):
-        SamAutomaticMaskGenerator(sam, crop_n_layers=1)
-    with pytest.raises(NotImplementedError):
-        SamAutomaticMaskGenerator(sam, min_mask_region_area=10)
+    g = SamAutomaticMaskGenerator(sam, points_per_side=8, crop_n_layers=2, crop_n_points_downscale_factor=2,
+                                  min_mask_region_area=10)
+    assert [len(p) for p in g.point_grids] == [64, 16, 4]                       # one grid per crop layer (:119-124)
+    assert not g._fast_path(np.zeros((1024, 1024, 3), np.uint8))
+    g = SamAutomaticMaskGenerator(sam, points_per_side=8)
+    assert g._fast_path(np.zeros((1024, 768, 3), np.uint8)) and not g._fast_path(np.zeros((48, 44, 3), np.uint8))
     with pytest.raises(AssertionError):
         SamAutomaticMaskGenerator(sam, points_per_side=None)
     with pytest.raises(AssertionError):
@@ -121,3 +123,52 @@ def test_oracle_generator_reproduces_reference_records():
     assert bi == int(gold["amg_best_index"][0])
     ref_best = np.unpackbits(gold["amg_best_mask_bits"]).reshape(1024, 1024).astype(bool)
     assert int((best != ref_best).sum()) <= 4
+
+
+@pytest.mark.parametrize("tag,extra", [("all", dict(crop_nms_thresh=1.0)), ("nms", dict())])
+def test_oracle_crops_and_small_regions_reproduce_reference_records(tag, extra):
+    """crop_n_layers = 1 + min_mask_region_area (automatic_mask_generator.py:194-380) on the 48 x 44 image: the oracle against
+    the records the REFERENCE's generator produced (oracle/validate_against_reference.py check_amg)."""
+    from oracle import amg as oamg, golden_inputs as gi
+    from protosam_amd.segment_anything import sam_model_registry
+    from protosam_amd.synth import synth_state_dict
+    gold = np.load(GOLD)
+    sd = synth_state_dict(sam_model_registry["vit_b"](encoder_depth=gi.AMG_ENCODER_DEPTH), gi.AMG_SEED)
+    img = gi.amg_small_case()
+    H, W = img.shape[:2]
+    anns = oamg.generate(img, sd, encoder_depth=gi.AMG_ENCODER_DEPTH, **dict(gi.AMG_CROP_ARGS, **extra))
+    n = len(gold[f"amgc_{tag}_pred_iou"])
+    assert len(anns) == n
+    np.testing.assert_allclose([a["predicted_iou"] for a in anns], gold[f"amgc_{tag}_pred_iou"], atol=2e-5)
+    np.testing.assert_allclose([a["stability_score"] for a in anns], gold[f"amgc_{tag}_stability"], atol=2e-5)
+    np.testing.assert_array_equal(np.array([a["crop_box"] for a in anns]), gold[f"amgc_{tag}_crop_box"])
+    np.testing.assert_array_equal(np.array([a["point_coords"][0] for a in anns]), gold[f"amgc_{tag}_points"])
+    ref_masks = np.unpackbits(gold[f"amgc_{tag}_mask_bits"], axis=1)[:, :H * W].reshape(n, H, W).astype(bool)
+    diff = [int((a["segmentation"] != m).sum()) for a, m in zip(anns, ref_masks)]
+    assert max(diff) <= 2 and sum(d == 0 for d in diff) >= n - 2           # (thread-count dependent fp32 summation order)
+    if max(diff) == 0:
+        np.testing.assert_array_equal(np.array([a["bbox"] for a in anns]), gold[f"amgc_{tag}_bbox"])
+        np.testing.assert_array_equal(np.array([a["area"] for a in anns]), gold[f"amgc_{tag}_area"])
+
+
+def test_crop_boxes_and_edge_rule():
+    """Host helpers of the crop path against the oracle's restatements and known answers (utils/amg.py:78-88, :202-237)."""
+    from oracle import amg as oamg
+    from protosam_amd.segment_anything.utils.amg import generate_crop_boxes, is_box_near_crop_edge
+    for size in ((48, 44), (1024, 1024), (480, 640), (333, 1000)):
+        for n_layers in (0, 1, 2):
+            b, l = generate_crop_boxes(size, n_layers, 512 / 1500)
+            bo, lo = oamg.crop_boxes_for(size, n_layers, 512 / 1500)
+            assert b == [list(x) for x in bo] and l == list(lo)
+            assert len(b) == sum(4 ** i for i in range(n_layers + 1)) and b[0] == [0, 0, size[1], size[0]]
+    b, _ = generate_crop_boxes((48, 44), 1, 512 / 1500)
+    assert b[1:] == [[0, 0, 30, 32], [0, 16, 30, 48], [14, 0, 44, 32], [14, 16, 44, 48]] or len(b) == 5
+    # a box touching the crop's right edge, far from the image's right edge -> dropped; near both -> kept
+    crop, orig = [100, 100, 400, 400], [0, 0, 1000, 1000]
+    boxes = np.array([[50, 50, 299, 120], [50, 50, 120, 120], [0, 50, 120, 120]])
+    assert is_box_near_crop_edge(boxes, crop, orig).tolist() == [True, False, True]
+    assert is_box_near_crop_edge(boxes, [0, 0, 300, 300], [0, 0, 310, 310]).tolist() == [False, False, False]
+    rng = np.random.default_rng(0)
+    bx = rng.integers(0, 300, (200, 4))
+    np.testing.assert_array_equal(is_box_near_crop_edge(bx, crop, orig),
+                                  oamg.box_near_crop_edge(torch.as_tensor(bx), crop, orig).numpy())

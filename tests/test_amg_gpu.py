@@ -190,3 +190,142 @@ def test_small_linear_both_paths(dev, M, N, K, G):
                          N=N, K=K, xg=M * K, wg=N * K, bg=N, yg=M * N, ldx=K, ldy=N)
         err = (out.cpu().double() - ref).abs().max().item()
         assert err < 2e-5 * (K / 256) ** 0.5 + 1e-5, (act, use_x2, use_r, err)
+
+
+# ---- crop layers, arbitrary image sizes, small-region removal (automatic_mask_generator.py:194-380) ------------------------
+def test_plane_stats_kernel(dev):
+    """`psam_plane_stats`: the three counts, the box and the binary mask of full-resolution logit planes, exactly."""
+    from protosam_amd import ops
+    g = torch.Generator().manual_seed(11)
+    for n, H, W in ((5, 30, 32), (3, 48, 44), (2, 257, 1023), (1, 1, 1)):
+        x = torch.randn((n, H, W), generator=g) * 2
+        if H > 8:
+            x = F.avg_pool2d(x[None], 5, 1, 2)[0] * 4
+            x[0] = -5.0
+            x[0, 3:5, 7] = 2.0
+        xd = x.to(dev).contiguous()
+        st, m = ops.plane_stats(xd, 0.25, 1.0)
+        st = st.cpu().numpy()
+        ref = x > 0.25
+        assert torch.equal(m.cpu().bool(), ref)
+        np.testing.assert_array_equal(st[:, 0], (x > 1.25).sum((1, 2)).numpy())
+        np.testing.assert_array_equal(st[:, 1], (x > -0.75).sum((1, 2)).numpy())
+        np.testing.assert_array_equal(st[:, 2], ref.sum((1, 2)).numpy())
+        for p in range(n):
+            if st[p, 2] == 0:
+                continue
+            ys, xs = torch.nonzero(ref[p], as_tuple=True)
+            assert st[p, 3:7].tolist() == [int(xs.min()), int(ys.min()), int(xs.max()), int(ys.max())]
+        st2, none = ops.plane_stats(xd, 0.25, 1.0, binarize=False)
+        assert none is None and torch.equal(st2.cpu(), torch.from_numpy(st))
+
+
+def test_remove_small_regions_on_device(dev):
+    """Hole / island removal through `psam_ccl` == the oracle's restatement of utils/amg.py:267-291, bit for bit."""
+    from oracle import amg as oamg
+    from protosam_amd import ops
+    from protosam_amd.segment_anything import SamAutomaticMaskGenerator
+    g = SamAutomaticMaskGenerator.__new__(SamAutomaticMaskGenerator)
+    rng = np.random.default_rng(3)
+    for H, W, p in ((48, 44, 0.55), (40, 64, 0.3), (33, 17, 0.8), (16, 16, 0.0), (16, 16, 1.0)):
+        mask = rng.random((H, W)) < p
+        if 0 < p < 1:
+            mask[10:30, 5:15] = True
+            mask[12, 7] = False                                               # a one-pixel hole
+        cw = ops.CclWorkspace(H, W, 4096, dev)
+        g._zero_p = torch.zeros((H, W), dtype=torch.float32, device=dev)
+        for mode in ("holes", "islands"):
+            for thr in (1, 6, 50):
+                ref, ch_ref = oamg.remove_small_regions(mask, thr, mode)
+                got, ch = g._remove_small_regions(torch.from_numpy(mask.astype(np.uint8)).to(dev), thr, mode, cw)
+                assert ch == ch_ref, (H, W, mode, thr)
+                assert np.array_equal(got.cpu().numpy().astype(bool), ref), (H, W, mode, thr)
+
+
+@pytest.fixture(scope="module")
+def amg_crop_setup(dev):
+    from oracle import golden_inputs as gi
+    from protosam_amd.sam_wrapper import SamWrapper
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    w = SamWrapper({"model_type": "vit_b", "sam_checkpoint": f"random:{gi.AMG_SEED}:{gi.AMG_ENCODER_DEPTH}",
+                    "generator_args": dict(gi.AMG_ARGS)}).to(dev)
+    sd = {k: v.detach().cpu() for k, v in w.sam.state_dict().items()}
+    return dict(w=w, sd=sd, img=gi.amg_small_case(), gold=np.load(GOLD))
+
+
+def _record_key(pt, crop, piou):
+    return (tuple(int(v) for v in crop), tuple(round(float(v), 6) for v in pt), -float(piou))
+
+
+def test_generate_crops_and_small_regions_vs_reference(dev, amg_crop_setup):
+    """crop_n_layers = 1 + min_mask_region_area on the 48 x 44 image, no suppression: one record per candidate of every crop
+    (64 * 3 from the image, 4 * 16 * 3 from the layer-1 crops), against the REFERENCE's recorded run (amgc_all_*)."""
+    from oracle import golden_inputs as gi
+    from protosam_amd.segment_anything import SamAutomaticMaskGenerator
+    s, gold = amg_crop_setup, amg_crop_setup["gold"]
+    H, W = s["img"].shape[:2]
+    g = SamAutomaticMaskGenerator(s["w"].sam, **dict(gi.AMG_CROP_ARGS, crop_nms_thresh=1.0))
+    anns = g.generate(s["img"])
+    n = len(gold["amgc_all_pred_iou"])
+    assert len(anns) == n == 384
+    ref_masks = np.unpackbits(gold["amgc_all_mask_bits"], axis=1)[:, :H * W].reshape(n, H, W).astype(bool)
+    o = sorted(range(n), key=lambda i: _record_key(anns[i]["point_coords"][0],
+                                                   [anns[i]["crop_box"][0], anns[i]["crop_box"][1]], 0))
+    r = sorted(range(n), key=lambda i: _record_key(gold["amgc_all_points"][i], gold["amgc_all_crop_box"][i][:2], 0))
+    # three records per (crop, point): pair them by predicted IoU inside each group
+    worst_px, worst_iou, worst_stab, exact = 0, 0.0, 0.0, 0
+    for lo in range(0, n, 3):
+        a3 = sorted(o[lo:lo + 3], key=lambda i: -anns[i]["predicted_iou"])
+        r3 = sorted(r[lo:lo + 3], key=lambda i: -gold["amgc_all_pred_iou"][i])
+        for i, j in zip(a3, r3):
+            a = anns[i]
+            assert a["point_coords"][0] == pytest.approx(gold["amgc_all_points"][j].tolist(), abs=1e-9)
+            assert a["crop_box"] == gold["amgc_all_crop_box"][j].tolist()
+            worst_iou = max(worst_iou, abs(a["predicted_iou"] - float(gold["amgc_all_pred_iou"][j])))
+            worst_stab = max(worst_stab, abs(a["stability_score"] - float(gold["amgc_all_stability"][j])))
+            d = int((a["segmentation"] != ref_masks[j]).sum())
+            worst_px = max(worst_px, d)
+            exact += d == 0
+            assert a["segmentation"].shape == (H, W) and int(a["segmentation"].sum()) == a["area"]
+            if d == 0:
+                assert a["bbox"] == gold["amgc_all_bbox"][j].tolist() and a["area"] == int(gold["amgc_all_area"][j])
+    n_crop = sum(1 for a in anns if a["crop_box"] != [0, 0, W, H])
+    print(f"{n} records ({n_crop} from layer-1 crops): {exact} masks identical to the reference's, worst {worst_px} px, "
+          f"predicted IoU err {worst_iou:.2e}, stability err {worst_stab:.2e}")
+    assert n_crop == 192 and worst_iou < 5e-3
+    # fp16 encoder vs the fp32 reference: a logit near the threshold may flip a pixel, and a flipped pixel may move a region
+    # across the area threshold (6 px) - bounded, and most masks are identical
+    assert exact >= 0.8 * n and worst_px <= 24
+
+
+def test_generate_crops_default_suppression(dev, amg_crop_setup):
+    """Default crop_nms_thresh: cross-crop NMS prefers the masks of smaller crops (scores = 1 / crop area, :208-218)."""
+    from oracle import golden_inputs as gi
+    from protosam_amd.segment_anything import SamAutomaticMaskGenerator
+    s, gold = amg_crop_setup, amg_crop_setup["gold"]
+    g = SamAutomaticMaskGenerator(s["w"].sam, **gi.AMG_CROP_ARGS)
+    anns = g.generate(s["img"])
+    ref_crops = sorted(map(tuple, gold["amgc_nms_crop_box"].tolist()))
+    print(f"{len(anns)} records after cross-crop NMS (reference {len(ref_crops)}): crops {[a['crop_box'] for a in anns]}")
+    assert sorted(tuple(a["crop_box"]) for a in anns) == ref_crops
+
+
+def test_generate_any_image_size_vs_oracle(dev, amg_crop_setup):
+    """crop_n_layers = 0 on an image that is NOT at the model's input size (set_image resizes it, masks come back at the
+    image's size) against the oracle run live."""
+    from oracle import amg as oamg, golden_inputs as gi
+    from protosam_amd.segment_anything import SamAutomaticMaskGenerator
+    s = amg_crop_setup
+    kw = dict(points_per_side=4, points_per_batch=16, box_nms_thresh=1.0, pred_iou_thresh=0.0, stability_score_thresh=0.0)
+    anns = SamAutomaticMaskGenerator(s["w"].sam, **kw).generate(s["img"])
+    # (min_mask_region_area = 1 removes nothing - no region is smaller than one pixel - and selects the oracle's general path)
+    ref = oamg.generate(s["img"], s["sd"], encoder_depth=gi.AMG_ENCODER_DEPTH, crop_n_layers=0, min_mask_region_area=1, **kw)
+    assert len(anns) == len(ref) == 48
+    key = lambda a: (a["point_coords"][0], -a["predicted_iou"])  # noqa: E731
+    worst = 0
+    for a, b in zip(sorted(anns, key=key), sorted(ref, key=key)):
+        assert a["point_coords"] == b["point_coords"] and a["crop_box"] == b["crop_box"]
+        assert abs(a["predicted_iou"] - b["predicted_iou"]) < 5e-3
+        worst = max(worst, int((a["segmentation"] != b["segmentation"]).sum()))
+    print(f"48 records on a 48 x 44 image: worst {worst} differing pixels per mask")
+    assert worst <= 24
