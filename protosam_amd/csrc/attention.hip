@@ -608,9 +608,662 @@ __global__ __launch_bounds__(NW * 64, (MODE == 2 ? 4 : 2)) void attn_kernel(Attn
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Window attention, second form (`wattn_kernel`, the default for mode 2 when the caller passes `rpack`): same arithmetic as
+// attn_kernel<HD, 2, 7>, restructured around what bounded that kernel (VALU issue and the staging round trip; the matrix pipe
+// was 7 % busy):
+//   * K and V of the window go global -> LDS by DMA (`global_load_lds_dwordx4`) as plain row-major [208][80] images: no
+//     staging registers, no LDS store instructions, no transposing writes. The V^T fragments of O^T += V^T P^T come from the
+//     row-major image through `ds_read_b64_tr_b16` (two per 16 x 32 fragment). Rows are 160 bytes for both head sizes (hd = 64
+//     leaves two 16-byte slots per row unused): with the LDS row ORDER chosen on the DMA's source side (below), every
+//     `ds_read_b128` K-fragment read and every transposing V read is bank-conflict-free by the model of MI355X_MICROARCH.md;
+//   * key k = 32c + 8a + 4t + b of chunk c sits in LDS row 32c + 16t + 4a + b of the K image (row li of MFMA key tile 2c + t
+//     is LDS row 16(2c + t) + li: the fragment rows of one read are consecutive) and in row 32c + 16(a>>1) + 8t + 4(a&1) + b
+//     of the V image (the eight rows two neighbouring 16-lane groups transpose-read are consecutive);
+//   * the one-hot key-side operands of the folded rel-pos bias are a constant of the window geometry: read from a table the
+//     host appends to `rpack` (one 16-byte load per key tile) instead of being rebuilt from compares per tile (a third of the
+//     old loop's VALU instructions);
+//   * softmax: max over the raw scores, then p = exp2(fma(s, scale*log2e, -m)); both query tiles in one straight-line block;
+//   * the V DMA is issued after the rel-pos prologue (whose scratch aliases the V image) and lands under the first chunk's
+//     scores + softmax; two barriers per workgroup in all.
+// rpack layout (ops.pack_rel_tables(windowed=True)): [2][2][32][HDP] tables | [13][64][8] one-hot fragments | 128 zeros.
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+template <int HD>
+__global__ __launch_bounds__(448, 4) void wattn_kernel(AttnArgs p) {
+  constexpr int NW = 7, NT = NW * 64;
+  constexpr int HDP = (HD + 31) / 32 * 32;
+  constexpr int KS = HDP / 32;
+  constexpr int DT = HD / 16;
+  constexpr int CH = HD / 8;          // 16-byte chunks of a head vector
+  constexpr int RC = 10;              // 16-byte slots per LDS row
+  constexpr int RLD = RC * 8;         // LDS row stride (halfs)
+  constexpr int WS = 14, NKEY = WS * WS;
+  constexpr int KROWS = 208;          // 13 MFMA key tiles
+  constexpr int NINS = (KROWS * RC + 63) / 64;   // DMA wave-instructions per image (33)
+  const float LOG2E = 1.4426950408889634f;
+  const float RESCALE_THR = 8.0f;
+
+  __shared__ __attribute__((aligned(16))) half_t Ks[KROWS * RLD + 64];   // + the third k-step's over-read of the last row
+  __shared__ __attribute__((aligned(16))) half_t Vs[KROWS * RLD];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int li = lane & 15, g = lane >> 4;
+  int h, b, win;
+  {
+    const int per = p.H, nshare = p.B * p.nwin;
+    const int gq = blockIdx.x / (8 * per), r = blockIdx.x % (8 * per);
+    const int grp = gq * 8 + (r & 7);
+    if (grp >= nshare) return;
+    h = r >> 3;
+    b = grp / p.nwin;
+    win = grp % p.nwin;
+  }
+  const int wy = win / p.nwx, wx = win % p.nwx;
+  const int N = p.N, H = p.H;
+  const size_t rs = (size_t)p.ts;
+  const half_t* qkv_b = p.qkv + (size_t)b * N * rs;
+  const half_t* oh_tab = p.rpack + 2 * 2 * 32 * HDP;
+  const half_t* zero_row = oh_tab + 13 * 64 * 8;
+  auto win_token = [&](int j) -> int {
+    const int y = wy * WS + j / WS, x = wx * WS + j % WS;
+    return (y < p.gh && x < p.gw) ? y * p.gw + x : -1;
+  };
+  // source of one 16-byte slot of the K (which = 1) or V (which = 2) image
+  auto dma_image = [&](int which, half_t* img) {
+#pragma unroll
+    for (int i = 0; i < (NINS + NW - 1) / NW; ++i) {
+      const int j = wv + i * NW;                    // wave-uniform
+      if (j < NINS) {
+        const int S = j * 64 + lane;
+        const int R = S / RC, c = S - R * RC;
+        const int rho = R & 31, C = R >> 5;
+        int key;
+        if (which == 1) key = C * 32 + ((rho >> 2) & 3) * 8 + (rho >> 4) * 4 + (rho & 3);
+        else key = C * 32 + ((rho >> 4) * 2 + ((rho >> 2) & 1)) * 8 + ((rho >> 3) & 1) * 4 + (rho & 3);
+        const half_t* src = zero_row;
+        if (key < NKEY) {
+          const int tok = win_token(key);
+          src = tok >= 0 ? qkv_b + (size_t)tok * rs + (size_t)which * p.ws_ + (size_t)h * p.hs
+                         : p.pad_row + ((size_t)which * H + h) * HD;
+        }
+        if (R < KROWS && c < CH)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + c * 8),
+                                           (__attribute__((address_space(3))) void*)(img + j * 512), 16, 0, 0);
+      }
+    }
+  };
+  if (!(p.dbg & 1)) dma_image(1, Ks);
+
+  // ---- query fragments ---------------------------------------------------------------------------------
+  const int qrow_blk = wv * 32;
+  int qtok[2];
+  bool qvalid[2];
+  half8_t qf[2][KS];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int q = qrow_blk + qt * 16 + li;
+    const int tok = q < NKEY ? win_token(q) : -1;
+    qvalid[qt] = tok >= 0;
+    qtok[qt] = tok >= 0 ? tok : 0;
+    const half_t* qp = qkv_b + (size_t)qtok[qt] * rs + (size_t)h * p.hs;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int c0 = s * 32 + g * 8;
+      if (c0 < HD && !(p.dbg & 64)) {
+        qf[qt][s] = *reinterpret_cast<const half8_t*>(qp + c0);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[qt][s][e] = (half_t)0.f;
+      }
+    }
+  }
+
+  // ---- rel-pos query terms (add_decomposed_rel_pos, image_encoder.py:337-372), as in attn_kernel; scratch = the V image -----
+  half8_t qaug[2][2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qaug[qt][0][e] = qaug[qt][1][e] = (half_t)0.f;
+  if (!(p.dbg & 2)) {
+    float* ts = reinterpret_cast<float*>(Vs) + wv * 1024;   // [tab 2][r 32][q 16] fp32 = 4 KiB per wave
+    const float inv_scale = 1.0f / p.scale;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+      for (int tab = 0; tab < 2; ++tab)
+#pragma unroll
+        for (int tile = 0; tile < 2; ++tile) {
+          f32x4 D = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int part = 0; part < 2; ++part)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+              const half8_t rf = *reinterpret_cast<const half8_t*>(
+                  p.rpack + ((size_t)((tab * 2 + part) * 32 + tile * 16 + li)) * HDP + s * 32 + g * 8);
+              D = __builtin_amdgcn_mfma_f32_16x16x32_f16(rf, qf[qt][s], D, 0, 0, 0);
+            }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) ts[(tab * 32 + tile * 16 + g * 4 + i) * 16 + li] = D[i];
+        }
+      const int q = qrow_blk + qt * 16 + li;
+      const int qy = (q * 4682) >> 16, qx = q - 14 * qy;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int j = g * 8 + e;
+        float v = 0.f;
+        if (j < 28) {
+          const int tab = j >= 14;
+          const int r = (tab ? qx : qy) + 13 - (tab ? j - 14 : j);
+          v = ts[(tab * 32 + r) * 16 + li] * inv_scale;
+        }
+        const half_t hi = (half_t)v;
+        qaug[qt][0][e] = hi;
+        qaug[qt][1][e] = (half_t)(v - (float)hi);
+      }
+    }
+  }
+  // K has landed (loads return in order and the query / table loads above were consumed); every wave is done with the scratch
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (!(p.dbg & 1)) dma_image(2, Vs);
+
+  f32x4 ot[DT][2];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) ot[d][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float sl2 = p.scale * LOG2E;
+  float mrun[2] = {-INFINITY, -INFINITY};
+  float lrun[2] = {0.f, 0.f};
+
+  auto chunk = [&](auto ntt_c, int c, bool first) {
+    constexpr int NTT = decltype(ntt_c)::value;
+    half8_t oh[NTT];
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+      if (!(p.dbg & 32)) oh[tt] = *reinterpret_cast<const half8_t*>(oh_tab + ((size_t)((c * 2 + tt) * 64 + lane)) * 8);
+      else oh[tt] = qaug[0][1];
+    }
+    f32x4 st[NTT][2];
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) st[tt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const half8_t kf = *reinterpret_cast<const half8_t*>(&Ks[(c * 32 + tt * 16 + li) * RLD + (s * 4 + g) * 8]);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+          st[tt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qt][s], st[tt][qt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        st[tt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(oh[tt], qaug[qt][0], st[tt][qt], 0, 0, 0);
+        st[tt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(oh[tt], qaug[qt][1], st[tt][qt], 0, 0, 0);
+      }
+    }
+    if (NTT == 1 && g != 0) {     // the last key tile holds keys 192..207: only 192..195 (lane group 0) exist
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) st[0][qt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    }
+    float mx[2];
+    if (!(p.dbg & 8)) {
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      float m = fmaxf(fmaxf(st[0][qt][0], st[0][qt][1]), fmaxf(st[0][qt][2], st[0][qt][3]));
+      if constexpr (NTT == 2)
+        m = fmaxf(m, fmaxf(fmaxf(st[1][qt][0], st[1][qt][1]), fmaxf(st[1][qt][2], st[1][qt][3])));
+      mx[qt] = m;
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      mx[qt] = fmaxf(mx[qt], __shfl_xor(mx[qt], 16, 64));
+      mx[qt] = fmaxf(mx[qt], __shfl_xor(mx[qt], 32, 64));
+      mx[qt] *= sl2;
+    }
+    if (!__all(mx[0] <= mrun[0] + RESCALE_THR && mx[1] <= mrun[1] + RESCALE_THR)) {
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        const float mnew = fmaxf(mrun[qt], mx[qt]);
+        const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
+        mrun[qt] = mnew;
+        lrun[qt] *= alpha;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ot[d][qt][r] *= alpha;
+      }
+    }
+    }
+    half8_t pf[2];
+    if (p.dbg & 8) {
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pf[qt][e] = (half_t)st[0][qt][e & 3];
+    } else
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const float nm = -mrun[qt];
+      float pv[NTT][4];
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pv[tt][r] = __builtin_amdgcn_exp2f(fmaf(st[tt][qt][r], sl2, nm));
+          pf[qt][tt * 4 + r] = (half_t)pv[tt][r];
+        }
+      float ps = (pv[0][0] + pv[0][1]) + (pv[0][2] + pv[0][3]);
+      if constexpr (NTT == 2) ps += (pv[1][0] + pv[1][1]) + (pv[1][2] + pv[1][3]);
+      else {
+#pragma unroll
+        for (int e = 4; e < 8; ++e) pf[qt][e] = (half_t)0.f;
+      }
+      lrun[qt] += ps;
+    }
+    if (first) {   // the V image: every wave's DMA complete and visible
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    // O^T += V^T P^T: the 16 (d) x 32 (keys) fragment = two transposing reads of [4 keys][16 d] blocks per 16-lane group
+    const int vrow = c * 32 + (NTT == 2 ? (g >> 1) * 16 : 0) + (g & 1) * 4 + (li >> 2);
+    const half_t* vb = &Vs[vrow * RLD + (li & 3) * 4];
+    if (!(p.dbg & 16))
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      const fp16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(vb + d * 16));
+      fp16x4_t v1 = {0, 0, 0, 0};
+      if constexpr (NTT == 2)
+        v1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(vb + d * 16 + 8 * RLD));
+      half8_t vf;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        vf[e] = (half_t)v0[e];
+        vf[4 + e] = (half_t)v1[e];
+      }
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) ot[d][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qt], ot[d][qt], 0, 0, 0);
+    }
+  };
+
+  if (!(p.dbg & 4)) {
+    chunk(std::integral_constant<int, 2>{}, 0, true);
+#pragma unroll 1
+    for (int c = 1; c < 6; ++c) chunk(std::integral_constant<int, 2>{}, c, false);
+    chunk(std::integral_constant<int, 1>{}, 6, false);
+  }
+
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    float l = lrun[qt];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    if (qvalid[qt]) {
+      half_t* op = p.out + ((size_t)b * N + qtok[qt]) * ((size_t)H * HD) + (size_t)h * HD;
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        half4_t o = {(half_t)(ot[d][qt][0] * inv), (half_t)(ot[d][qt][1] * inv), (half_t)(ot[d][qt][2] * inv),
+                     (half_t)(ot[d][qt][3] * inv)};
+        *reinterpret_cast<half4_t*>(op + d * 16 + g * 4) = o;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Window attention, persistent pipelined form (`wattn_p_kernel`; PSAM_WATTN=2, the default when the caller passes `rpack`).
+// The ablation of wattn_kernel (tools/attn_win_ablate.py, 16 slices: launch + stores 56 us, query loads 47, rel-pos prologue
+// ~100, K/V DMA ~60, key chunks ~120, SUM ~ the 344-400 us measured) showed that nothing overlaps: every workgroup of the grid
+// runs the same phase at the same time, so the chip alternates between a load burst and a compute burst. Here ONE workgroup
+// per CU walks a contiguous list of (window, head) items and overlaps them explicitly:
+//   * 14 waves; wave w owns ONE 16-row query tile (13 tiles cover the 196 queries; wave 13 only helps with the DMA);
+//   * K is double-buffered: the K image and the query fragments of item i+1 are requested at the top of item i; V is
+//     single-buffered: V(i+1) is requested at the end of item i (once every wave is done with V(i)) and lands under the rel-pos
+//     prologue and the first chunk's scores of item i+1; counted vmcnt waits (loads complete in order);
+//   * the rel-pos tables and the one-hot fragments live in LDS for the lifetime of the workgroup (the per-item loads of the
+//     24 KiB table from L2 were most of the old prologue's time);
+//   * two barriers per item.
+// LDS: K 2 x 33 280 + V 33 280 + tables 20 480 + one-hot 13 312 + 14 x 2 KiB prologue scratch = 162 304 bytes.
+#ifndef PSAM_WATTN_NTT
+#define PSAM_WATTN_NTT 2   // 64-key chunks (4) spill 26 VGPRs at the 128-register budget: 419 vs 349 us
+#endif
+template <int HD>
+__global__ __launch_bounds__(896, 4) void wattn_p_kernel(AttnArgs p, int nitems) {
+  constexpr int NW = 14, NT = NW * 64;
+  constexpr int HDP = (HD + 31) / 32 * 32;
+  constexpr int KS = HDP / 32;
+  constexpr int DT = HD / 16;
+  constexpr int CH = HD / 8;
+  constexpr int RC = 10, RLD = RC * 8;
+  constexpr int WS = 14, NKEY = WS * WS;
+  constexpr int KROWS = 208;
+  constexpr int IMG = KROWS * RLD;                   // halfs per image
+  constexpr int NINS = (KROWS * RC + 63) / 64;       // 33 DMA wave-instructions per image
+  constexpr int NDMA = (NINS + NW - 1) / NW;         // at most 3 per wave
+  const float LOG2E = 1.4426950408889634f;
+  const float RESCALE_THR = 8.0f;
+
+  __shared__ __attribute__((aligned(16))) half_t Kb[2 * IMG];
+  __shared__ __attribute__((aligned(16))) half_t Vs[IMG];
+  __shared__ __attribute__((aligned(16))) half_t Tab[2 * 2 * 32 * RLD];
+  __shared__ __attribute__((aligned(16))) half_t Oht[13 * 64 * 8];
+  __shared__ __attribute__((aligned(16))) float Scr[NW * 512];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int li = lane & 15, g = lane >> 4;
+  const int N = p.N, H = p.H;
+  const size_t rs = (size_t)p.ts;
+  const half_t* zero_row = p.rpack + 2 * 2 * 32 * HDP + 13 * 64 * 8;
+
+  // items of this workgroup: the (window, head) pairs whose window index is congruent to this XCD, window-major, a contiguous
+  // share per workgroup (consecutive items are heads of one window: neighbouring 160-byte slices of the same token rows)
+  const int ngrp = p.B * p.nwin;
+  const int x = blockIdx.x & 7, sx = blockIdx.x >> 3;
+  const int nwg_x = ((int)gridDim.x + 7 - x) >> 3;                 // workgroups on this XCD
+  const int cnt_x = ((ngrp + 7 - x) >> 3) * H;                     // items of this XCD
+  const int it0 = (int)((long long)sx * cnt_x / nwg_x), it1 = (int)((long long)(sx + 1) * cnt_x / nwg_x);
+  if (it0 >= it1) return;
+
+  // Everything that depends only on the lane is computed once: per DMA piece the key's position inside the window, its 16-byte
+  // chunk and whether the slot exists (packed: kx | ky << 4 | chunk << 8 | zero-row << 12 | active << 13); per item only the
+  // window origin, two compares and one multiply-add per piece remain (the integer divisions of the index math were most of
+  // the per-item instruction count, and a third of them on the one scalar unit the 14 waves share).
+  int geo[2][NDMA];
+#pragma unroll
+  for (int w2 = 0; w2 < 2; ++w2)
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+      const int S = (wv + i * NW) * 64 + lane;
+      const int R = S / RC, c = S - R * RC;
+      const int rho = R & 31, C = R >> 5;
+      int key;
+      if (w2 == 0) key = C * 32 + ((rho >> 2) & 3) * 8 + (rho >> 4) * 4 + (rho & 3);
+      else key = C * 32 + ((rho >> 4) * 2 + ((rho >> 2) & 1)) * 8 + ((rho >> 3) & 1) * 4 + (rho & 3);
+      const int kk = key < NKEY ? key : 0;
+      const int ky = kk / WS, kx = kk - ky * WS;
+      geo[w2][i] = kx | (ky << 4) | (c << 8) | ((key >= NKEY ? 1 : 0) << 12) | ((R < KROWS && c < CH) ? (1 << 13) : 0);
+    }
+  const int ndma_w = (wv + 2 * NW < NINS) ? 3 : 2;   // DMA instructions this wave issues per image (33 = 5 x 3 + 9 x 2)
+  const int qidx = wv * 16 + li;                     // this lane's query (window-local; >= 196: none)
+  const int qy = (qidx * 4682) >> 16, qx = qidx - 14 * qy;
+
+  struct Item { int b, h, wy14, wx14, grpq; };
+  auto item_at = [&](int it) -> Item {               // with divisions: once per workgroup
+    const int grpq = it / H, grp = grpq * 8 + x;
+    const int win = grp % p.nwin;
+    return Item{grp / p.nwin, it - grpq * H, (win / p.nwx) * WS, (win % p.nwx) * WS, grpq};
+  };
+  auto item_next = [&](const Item& im) -> Item {     // consecutive items: the next head, or head 0 of this XCD's next window
+    Item n = im;
+    if (++n.h == H) {
+      n.h = 0;
+      ++n.grpq;
+      const int grp = n.grpq * 8 + x;
+      const int win = grp % p.nwin;
+      n.b = grp / p.nwin;
+      n.wy14 = (win / p.nwx) * WS;
+      n.wx14 = (win % p.nwx) * WS;
+    }
+    return n;
+  };
+  auto dma_image = [&](const Item& im, int which, half_t* img) {
+    const half_t* base = p.qkv + (size_t)im.b * N * rs + (size_t)which * p.ws_ + (size_t)im.h * p.hs;   // wave-uniform
+    const half_t* padw = p.pad_row + ((size_t)which * H + im.h) * HD;
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+      if (wv + i * NW < NINS) {
+        const int gq = geo[which - 1][i];
+        const int y = im.wy14 + ((gq >> 4) & 15), xx = im.wx14 + (gq & 15);
+        const half_t* src = (y < p.gh && xx < p.gw) ? base + (size_t)(unsigned)((y * p.gw + xx) * (int)rs) : padw;
+        src = (gq & (1 << 12)) ? zero_row : src;
+        src += ((gq >> 8) & 15) * 8;
+        if (gq & (1 << 13))
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)(img + (wv + i * NW) * 512), 16, 0, 0);
+      }
+    }
+  };
+  auto load_q = [&](const Item& im, half8_t (&q)[KS], int& qtok, bool& qvalid) {
+    const int y = im.wy14 + qy, xx = im.wx14 + qx;
+    qvalid = qidx < NKEY && y < p.gh && xx < p.gw;
+    qtok = qvalid ? y * p.gw + xx : 0;
+    const half_t* qp = p.qkv + ((size_t)im.b * N + qtok) * rs + (size_t)im.h * p.hs;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int c0 = s * 32 + g * 8;
+      if (c0 < HD) {
+        q[s] = *reinterpret_cast<const half8_t*>(qp + c0);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q[s][e] = (half_t)0.f;
+      }
+    }
+  };
+
+  // ---- once per workgroup: tables into LDS, first item's K / Q / V ---------------------------------------------------
+  Item cur = item_at(it0);
+  dma_image(cur, 1, Kb);
+  half8_t qf[KS];
+  int qtok;
+  bool qvalid;
+  load_q(cur, qf, qtok, qvalid);
+  for (int idx = t; idx < 2 * 2 * 32 * RC; idx += NT) {            // [tab][part][32 rows][80]: the tables without their k padding
+    const int row = idx / RC, c = idx - row * RC;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (c < CH) v = *reinterpret_cast<const uint4*>(p.rpack + (size_t)row * HDP + c * 8);
+    *reinterpret_cast<uint4*>(&Tab[row * RLD + c * 8]) = v;
+  }
+  for (int idx = t; idx < 13 * 64; idx += NT)
+    *reinterpret_cast<uint4*>(&Oht[idx * 8]) = *reinterpret_cast<const uint4*>(p.rpack + 2 * 2 * 32 * HDP + (size_t)idx * 8);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  dma_image(cur, 2, Vs);
+
+  const float sl2 = p.scale * LOG2E;
+  const float inv_scale = 1.0f / p.scale;
+  float* ts = Scr + wv * 512;                                      // [32 r][16 q] fp32, one table at a time
+
+#pragma unroll 1
+  for (int it = it0; it < it1; ++it) {
+    const half_t* Ks = Kb + ((it - it0) & 1) * IMG;
+    // requests for the next item: K image into the other buffer, query fragments into registers
+    const bool has_next = it + 1 < it1;
+    Item nxt = cur;
+    half8_t qn[KS];
+    int qtok_n = 0;
+    bool qvalid_n = false;
+    if (has_next) {
+      nxt = item_next(cur);
+      dma_image(nxt, 1, Kb + (((it - it0) & 1) ^ 1) * IMG);
+      load_q(nxt, qn, qtok_n, qvalid_n);
+    } else {
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qn[s][e] = (half_t)0.f;
+    }
+
+    // ---- rel-pos query terms of this wave's query tile (image_encoder.py:337-372) ------------------------------------
+    half8_t qaug[2];
+    {
+      float vals[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) vals[e] = 0.f;
+#pragma unroll
+      for (int tab = 0; tab < 2; ++tab) {
+#pragma unroll
+        for (int tile = 0; tile < 2; ++tile) {
+          f32x4 D = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int part = 0; part < 2; ++part)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+              const half8_t rf = *reinterpret_cast<const half8_t*>(
+                  &Tab[((tab * 2 + part) * 32 + tile * 16 + li) * RLD + (s * 4 + g) * 8]);
+              D = __builtin_amdgcn_mfma_f32_16x16x32_f16(rf, qf[s], D, 0, 0, 0);
+            }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) ts[(tile * 16 + g * 4 + i) * 16 + li] = D[i];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int j = g * 8 + e;                       // k-slot: 0..13 rel_h, 14..27 rel_w, 28..31 unused
+          const bool mine = tab == 0 ? (j < 14) : (j >= 14 && j < 28);
+          const int r = ((tab ? qx : qy) + 13 - (tab ? j - 14 : j)) & 31;   // every lane reads (no divergent waits); others discard
+          const float v = ts[r * 16 + li] * inv_scale;
+          vals[e] = mine ? v : vals[e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const half_t hi = (half_t)vals[e];
+        qaug[0][e] = hi;
+        qaug[1][e] = (half_t)(vals[e] - (float)hi);
+      }
+    }
+
+    f32x4 ot[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) ot[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float mrun = -INFINITY, lrun = 0.f;
+
+    // NTT key tiles of 16 (T0 = first tile): 64-key chunks amortise the per-chunk reductions / rescale decision over twice the
+    // scores of a 32-key chunk and give the wave four independent MFMA chains
+    auto chunk = [&](auto ntt_c, int T0, bool first) {
+      constexpr int NTT = decltype(ntt_c)::value;
+      constexpr int NS2 = (NTT + 1) / 2;
+      f32x4 st[NTT];
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt) {
+        st[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const half8_t kf = *reinterpret_cast<const half8_t*>(&Ks[((T0 + tt) * 16 + li) * RLD + (s * 4 + g) * 8]);
+          st[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[s], st[tt], 0, 0, 0);
+        }
+        const half8_t oh = *reinterpret_cast<const half8_t*>(&Oht[((T0 + tt) * 64 + lane) * 8]);
+        st[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(oh, qaug[0], st[tt], 0, 0, 0);
+        st[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(oh, qaug[1], st[tt], 0, 0, 0);
+      }
+      if (NTT == 1 && g != 0) st[0] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};   // keys 196..207 do not exist
+      float mt[NTT];
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt) mt[tt] = fmaxf(fmaxf(st[tt][0], st[tt][1]), fmaxf(st[tt][2], st[tt][3]));
+      float mx = mt[0];
+      if constexpr (NTT == 2) mx = fmaxf(mt[0], mt[1]);
+      if constexpr (NTT == 4) mx = fmaxf(fmaxf(mt[0], mt[1]), fmaxf(mt[2], mt[3]));
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx *= sl2;
+      if (!__all(mx <= mrun + RESCALE_THR)) {
+        const float mnew = fmaxf(mrun, mx);
+        const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+        mrun = mnew;
+        lrun *= alpha;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ot[d][r] *= alpha;
+      }
+      half8_t pf[NS2];
+      {
+        const float nm = -mrun;
+        float psum[NTT];
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) {
+          float pv[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            pv[r] = __builtin_amdgcn_exp2f(fmaf(st[tt][r], sl2, nm));
+            pf[tt >> 1][(tt & 1) * 4 + r] = (half_t)pv[r];
+          }
+          psum[tt] = (pv[0] + pv[1]) + (pv[2] + pv[3]);
+        }
+        float ps = psum[0];
+        if constexpr (NTT == 2) ps = psum[0] + psum[1];
+        if constexpr (NTT == 4) ps = (psum[0] + psum[1]) + (psum[2] + psum[3]);
+        if constexpr (NTT == 1) {
+#pragma unroll
+          for (int e = 4; e < 8; ++e) pf[0][e] = (half_t)0.f;
+        }
+        lrun += ps;
+      }
+      if (first) {
+        // V(it) complete in every wave: the only newer requests of this wave are the next item's K pieces and query loads
+        if (has_next) {
+          if (ndma_w == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 + KS) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + KS) : "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < NS2; ++s2) {
+        const int vrow = (T0 / 2 + s2) * 32 + (NTT >= 2 ? (g >> 1) * 16 : 0) + (g & 1) * 4 + (li >> 2);
+        const half_t* vb = &Vs[vrow * RLD + (li & 3) * 4];
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+          const fp16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(vb + d * 16));
+          fp16x4_t v1 = {0, 0, 0, 0};
+          if constexpr (NTT >= 2)
+            v1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(vb + d * 16 + 8 * RLD));
+          half8_t vf;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            vf[e] = (half_t)v0[e];
+            vf[4 + e] = (half_t)v1[e];
+          }
+          ot[d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[s2], ot[d], 0, 0, 0);
+        }
+      }
+    };
+    if (PSAM_WATTN_NTT == 4) {
+      chunk(std::integral_constant<int, 4>{}, 0, true);
+      chunk(std::integral_constant<int, 4>{}, 4, false);
+      chunk(std::integral_constant<int, 4>{}, 8, false);
+    } else {
+      chunk(std::integral_constant<int, 2>{}, 0, true);
+#pragma unroll 1
+      for (int c = 1; c < 6; ++c) chunk(std::integral_constant<int, 2>{}, c * 2, false);
+    }
+    chunk(std::integral_constant<int, 1>{}, 12, false);
+
+    {
+      float l = lrun;
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+      const float inv = 1.0f / l;
+      if (qvalid) {
+        half_t* op = p.out + ((size_t)cur.b * N + qtok) * ((size_t)H * HD) + (size_t)cur.h * HD;
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+          half4_t o = {(half_t)(ot[d][0] * inv), (half_t)(ot[d][1] * inv), (half_t)(ot[d][2] * inv), (half_t)(ot[d][3] * inv)};
+          *reinterpret_cast<half4_t*>(op + d * 16 + g * 4) = o;
+        }
+      }
+    }
+    // next item's K image and query fragments have landed (they had the whole item); every wave is done with K(it) and V(it)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (has_next) dma_image(nxt, 2, Vs);
+    cur = nxt;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) qf[s] = qn[s];
+    qtok = qtok_n;
+    qvalid = qvalid_n;
+  }
+}
+
 static int g_attn_v2 = -1;
-extern "C" int psam_attention_set_variant(int v) {   // 0: serial softmax chains (round 1), 1: V2 (default); A/B and tests
-  g_attn_v2 = v ? 1 : 0;
+static int g_wattn = -1;   // 1: wattn_kernel for mode 2 (needs rpack with the appended tables), 0: attn_kernel<HD, 2, 7>
+extern "C" int psam_attention_set_variant(int v) {   // bit 0: V2 softmax in the global kernels (0 = round 1's serial chains); bit 1: wattn_kernel
+  g_attn_v2 = (v & 1) ? 1 : 0;                        // for the windows. Default 5; A/B and tests
+  g_wattn = (v >> 1) & 3;                             // bits 1-2: 0 attn_kernel<HD, 2, 7>, 1 wattn_kernel, 2 wattn_p_kernel
   return PSAM_OK;
 }
 
@@ -620,6 +1273,18 @@ static int launch_attn(AttnArgs p, int mode, hipStream_t s) {
     constexpr int NW = 7;
     p.nqb = 1;
     const int groups8 = (p.B * p.nwin + 7) / 8;
+    if (g_wattn < 0) { const char* e = getenv("PSAM_WATTN"); g_wattn = e ? atoi(e) : 2; }
+    if (g_wattn == 2 && p.rpack != nullptr) {
+      int cus, xcds;
+      psam_device_geometry(&cus, &xcds);
+      const int nitems = p.B * p.nwin * p.H;
+      hipLaunchKernelGGL((wattn_p_kernel<HD>), dim3(nitems < cus ? nitems : cus), dim3(14 * 64), 0, s, p, nitems);
+      return psam_launch_status();
+    }
+    if (g_wattn == 1 && p.rpack != nullptr) {
+      hipLaunchKernelGGL((wattn_kernel<HD>), dim3(groups8 * 8 * p.H), dim3(NW * 64), 0, s, p);
+      return psam_launch_status();
+    }
     // the window kernel sits at its 128-VGPR budget (two workgroups per CU): V2's extra live state spills there, so it keeps V1
     hipLaunchKernelGGL((attn_kernel<HD, 2, NW, false, false>), dim3(groups8 * 8 * p.H), dim3(NW * 64), 0, s, p);
   } else {

@@ -21,6 +21,20 @@ static inline int psam_launch_status() {
   return e == hipSuccess ? PSAM_OK : PSAM_ERR_LAUNCH;
 }
 
+// CU / XCD counts of the current device, read once per translation unit (persistent grids, XCD-aware maps)
+static inline void psam_device_geometry(int* cus, int* xcds) {
+  static int g_cus = 0, g_xcds = 0;
+  if (g_cus == 0) {
+    int dev = 0, v = 0;
+    (void)hipGetDevice(&dev);
+    g_cus = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    g_xcds = (hipDeviceGetAttribute(&v, hipDeviceAttributeNumberOfXccs, dev) == hipSuccess && v > 0) ? v : 8;
+    (void)hipGetLastError();
+  }
+  *cus = g_cus;
+  *xcds = g_xcds;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

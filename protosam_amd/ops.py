@@ -275,7 +275,8 @@ def attention(qkv, B, N, H, hd, scale, out=None, mode=0, rel_h=None, rel_w=None,
 
 
 def attention_set_variant(v):
-    """1 = V2 softmax (default), 0 = round-1 serial form; for A/B and the equivalence test."""
+    """bit 0: V2 softmax in the global kernels (0 = round-1 serial form); bits 1-2: window kernel of the fused rel-pos path
+    (0 attn_kernel, 1 wattn_kernel, 2 the persistent wattn_p_kernel). Default 5; for A/B and the equivalence tests."""
     _lib.check(_lib.lib().psam_attention_set_variant(int(v)), "psam_attention_set_variant")
 
 
@@ -291,7 +292,30 @@ def pack_rel_tables(rel_pos_h, rel_pos_w, windowed, hd):
         lo = (R - hi.float()).half()
         out[t, 0, :R.shape[0], :hd] = hi
         out[t, 1, :R.shape[0], :hd] = lo
-    return out.contiguous()
+    if not windowed:
+        return out.contiguous()
+    # window form: the tables, then the constants of the 14 x 14 window geometry the window-attention kernel reads (csrc/attention.hip
+    # wattn_kernel): the one-hot key-side fragments of the folded bias, [13 key tiles][64 lanes][8 k-slots], and a zero row
+    return torch.cat([out.reshape(-1), _window_onehot_table().to(out.device), out.new_zeros(128)]).contiguous()
+
+
+_ONEHOT = None
+
+
+def _window_onehot_table(ws=14):
+    """fp16 [13*64*8]: lane (li, g) of key tile T holds k-slots 8g..8g+7 of its key's row: 1 at slot kh and at slot 14 + kw, where
+    key = 32 (T >> 1) + 8 (li >> 2) + 4 (T & 1) + (li & 3) (the MFMA row -> key map of the kernels), zero rows for keys >= 196."""
+    global _ONEHOT
+    if _ONEHOT is None:
+        T = torch.arange(13).view(13, 1, 1)
+        lane = torch.arange(64).view(1, 64, 1)
+        e = torch.arange(8).view(1, 1, 8)
+        li, g = lane & 15, lane >> 4
+        key = (T >> 1) * 32 + (li >> 2) * 8 + (T & 1) * 4 + (li & 3)
+        slot = g * 8 + e
+        hot = ((slot == key // ws) | (slot == ws + key % ws)) & (key < ws * ws)
+        _ONEHOT = hot.to(torch.float16).reshape(-1)
+    return _ONEHOT
 
 
 def relpos(qkv, rpack, B, N, H, hd, gw, K, windowed, scale, rel_h=None, rel_w=None, relq=None, head_major=False):

@@ -196,20 +196,39 @@ def test_attention_global_relpos(dev, H, hd):
     torch.testing.assert_close(out.float(), ref, rtol=2e-3, atol=2e-3)
 
 
-@pytest.mark.parametrize("H,hd", [(2, 64), (2, 80)])
-def test_attention_window_relpos(dev, H, hd):
-    """14x14 windows over a 64x64 map, zero-padded tokens carry the qkv bias (image_encoder.py:267-271)."""
+@pytest.mark.parametrize("B,g,H,hd", [(2, 64, 2, 64), (2, 64, 2, 80), (3, 32, 3, 80), (1, 20, 1, 64), (5, 30, 16, 80)])
+def test_attention_window_relpos(dev, B, g, H, hd):
+    """14x14 windows over a g x g map, zero-padded tokens carry the qkv bias (image_encoder.py:267-271): the two-kernel path
+    (psam_relpos -> relq) and the three window kernels of the fused path (attn_kernel, wattn_kernel, the persistent
+    wattn_p_kernel) against the reference arithmetic. Shapes: the 64 x 64 map of a 1024 input; 32 x 32 (nine windows, three of
+    them ragged on two sides); a map smaller than two windows; item counts below / not a multiple of the XCD and CU counts."""
     from oracle.sam_image_encoder import decomposed_rel_pos_terms, window_partition, window_unpartition
     from protosam_amd import ops
-    B, g, ws = 2, 64, 14
+    ws = 14
     N, C = g * g, H * hd
-    qkv = _rand((B, N, 3, H, hd), dev, 1.0, 21).half()
+    qkv = _rand((B, N, 3, H, hd), dev, 1.0, 21)
+    # rows whose maximum jumps late in the key order (the lazy-rescale branch, guide rule 26): the LAST key of window 0 (the
+    # 16-key tail tile) aligned with query 0, and a key in the middle of the window aligned with query 17
+    last = min(13, g - 1) * g + min(13, g - 1)
+    qkv[0, last, 1, 0] = qkv[0, 0, 0, 0] * 25.0
+    qkv[0, 5 * g + 6, 1, 0] = qkv[0, g + 3, 0, 0] * 40.0
+    qkv = qkv.half()
     pad = _rand((3, H, hd), dev, 1.0, 22).half()
     Rh = _rand((2 * ws - 1, hd), dev, 0.3, 23)
     Rw = _rand((2 * ws - 1, hd), dev, 0.3, 24)
     scale = hd ** -0.5
-    relq = ops.relpos(qkv, ops.pack_rel_tables(Rh, Rw, True, hd), B, N, H, hd, g, ws, True, scale)
-    out = ops.attention(qkv, B, N, H, hd, scale, mode=2, relq=relq, pad_row=pad, gh=g, gw=g, ws=ws)
+    rp = ops.pack_rel_tables(Rh, Rw, True, hd)
+    outs = {}
+    if N % 64 == 0:                                   # psam_relpos works on 64-token blocks
+        relq = ops.relpos(qkv, rp, B, N, H, hd, g, ws, True, scale)
+        outs["relq"] = ops.attention(qkv, B, N, H, hd, scale, mode=2, relq=relq, pad_row=pad, gh=g, gw=g, ws=ws)
+    try:
+        for v in (1, 3, 5):
+            ops.attention_set_variant(v)
+            o = torch.full((B, N, C), float("nan"), device=dev, dtype=torch.float16)
+            outs[f"variant{v}"] = ops.attention(qkv, B, N, H, hd, scale, out=o, mode=2, rpack=rp, pad_row=pad, gh=g, gw=g, ws=ws)
+    finally:
+        ops.attention_set_variant(5)
 
     # reference on CPU: pad the qkv map with the pad row, partition, attend per window, unpartition
     m = qkv.float().cpu().view(B, g, g, 3 * C) - pad.float().cpu().view(1, 1, 1, 3 * C)
@@ -223,7 +242,10 @@ def test_attention_window_relpos(dev, H, hd):
     att = (att.view(-1, ws, ws, ws, ws) + rh[..., :, None] + rw[..., None, :]).view(-1, ws * ws, ws * ws)
     o = (att.softmax(-1) @ v).view(nW, H, ws, ws, hd).permute(0, 2, 3, 1, 4).reshape(nW, ws, ws, C)
     ref = window_unpartition(o, ws, pad_hw, (g, g)).reshape(B, N, C)
-    torch.testing.assert_close(out.float().cpu(), ref, rtol=2e-3, atol=2e-3)
+    for name, out in outs.items():
+        err = (out.float().cpu() - ref).abs().max().item()
+        assert torch.isfinite(out.float()).all(), name
+        torch.testing.assert_close(out.float().cpu(), ref, rtol=2e-3, atol=2e-3, msg=f"{name}: max err {err:.2e}")
 
 
 def test_head_major_qkv_layout(dev):
@@ -307,7 +329,7 @@ def test_attention_softmax_variants_agree(dev, mode, N, H, hd, B):
         try:
             outs.append(ops.attention(qkv, B, N, H, hd, scale, **kw).float())
         finally:
-            ops.attention_set_variant(1)
+            ops.attention_set_variant(5)
     ref = _ref_attn_global(qkv, B, N, H, hd, scale, rel=rel)
     for o in outs:
         assert torch.isfinite(o).all()

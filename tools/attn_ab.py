@@ -68,4 +68,4 @@ for name, mk in (("global+relpos hd80 N4096", case_global_rel), ("global hd64 N1
     for v in variants:
         med, mn = statistics.median(res[v]), min(res[v])
         print(f"{name} B={B} variant {v}: median {med:.0f} us  min {mn:.0f} us  {flops / med / 1e6:.0f} TFLOP/s")
-ops.attention_set_variant(1)
+ops.attention_set_variant(5)
