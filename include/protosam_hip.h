@@ -12,6 +12,7 @@
  */
 #ifndef PROTOSAM_HIP_H
 #define PROTOSAM_HIP_H
+#include <stddef.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -54,6 +55,11 @@ int psam_ln_finalize(const float* stats, int M, int D, float eps, float* mr, voi
  * 2 = 256x128x32 / 3 = 256x256x32 (two staggered wave groups) and 5 = 256x256x32 (plain) with a 4-deep direct-to-LDS
  * DMA ring. */
 int psam_gemm_set_tile(int tile);
+/* Device scratch for the split-K form of psam_gemm_f16 (fp32 partial sums, [ksplit][M][N]): used only when registered and
+ * large enough; EPI 2 on few 256x256 tiles with K >= 2048 then runs `ksplit` workgroups per tile + one reduce pass
+ * (deterministic). 16-byte aligned; the caller keeps it alive and must not share it between concurrently running streams.
+ * ptr = NULL unregisters (no split-K). Env PSAM_GEMM_SPLITK=0 disables the path. */
+int psam_gemm_set_workspace(void* ptr, size_t bytes);
 
 /* Row LayerNorm, fp32 in; out_dtype 0: half out (+ optional fp32 copy y2), 1: fp32 out. Appends `zero_tail_rows`
  * all-zero rows. torch.nn.LayerNorm of image_encoder.py:174-193, transformer.py:133-144 and LayerNorm2d

@@ -13,7 +13,7 @@ import torch  # noqa: F401  (must precede the CDLL below: loads PyTorch's libamd
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PSAM_LIB_PATH") or os.path.join(_HERE, "libprotosam_hip.so")   # (override: A/B of library builds)
 
-c_void_p, c_int, c_float, c_longlong = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong
+c_void_p, c_int, c_float, c_longlong, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong, ctypes.c_size_t
 
 # name -> argtypes; every entry point returns int (0 = ok). Kept in the same order as the header.
 SIGNATURES = {
@@ -22,6 +22,7 @@ SIGNATURES = {
     "psam_gemm_f16_ln": [c_void_p] * 6 + [c_int] * 12 + [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "psam_ln_finalize": [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p],
     "psam_gemm_set_tile": [c_int],
+    "psam_gemm_set_workspace": [c_void_p, c_size_t],
     "psam_layernorm": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                        c_int, c_int, c_void_p],
     "psam_attention_f16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

@@ -54,6 +54,10 @@ struct GemmArgs {
   float* stats;
   const float* ln_mr;
   const float* ln_s;
+  // ---- split-K (tile 11, EPI_F32): `ksplit` workgroups share one 256x256 tile, each over a contiguous range of K-tiles, and
+  // store their raw partial sums to plane `range` of `ks_ws` (fp32 [ksplit][M][N]); splitk_reduce_kernel finishes the epilogue
+  int ksplit;
+  float* ks_ws;
 };
 
 
@@ -1649,9 +1653,9 @@ __device__ __forceinline__ void slab_emit16h(const half_t* __restrict__ slab, in
 }
 
 // Epilogue of one 128x64 wave tile of the persistent kernels, through the wave's private 4 KiB slab.
-template <int EPI, bool LNF = false>
+template <int EPI, bool LNF = false, bool SPLITK = false>
 __device__ __forceinline__ void persist_epilogue(const f32x16 (&acc)[2][2][2], half_t* __restrict__ slab, int mbase, int nbase,
-                                                 int lane, const GemmArgs& p) {
+                                                 int lane, const GemmArgs& p, int krange = 0) {
   const int lr = lane & 31, lg = lane >> 5;
   if constexpr (EPI == EPI_F32) {
     // x (+)= gamma * (acc + bias) in fp32: eight 32x32 blocks through the 4 KiB slab, 8 lanes per 128-byte row; the
@@ -1665,13 +1669,13 @@ __device__ __forceinline__ void persist_epilogue(const f32x16 (&acc)[2][2][2], h
         int m = mb + it * 8 + r8;
         m = m < p.M ? m : p.M - 1;
         const size_t rrow = p.resid_mod ? (size_t)(m % p.resid_mod) : (size_t)m;
-        r[it] = p.resid ? *reinterpret_cast<const float4*>(p.resid + rrow * p.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        r[it] = (p.resid && !SPLITK) ? *reinterpret_cast<const float4*>(p.resid + rrow * p.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     };
     float4 bvv[2], gvv[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      bvv[j] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nbase + j * 32 + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      bvv[j] = (p.bias && !SPLITK) ? *reinterpret_cast<const float4*>(p.bias + nbase + j * 32 + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
       gvv[j] = p.gamma ? *reinterpret_cast<const float4*>(p.gamma + nbase + j * 32 + c * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
     }
     float4 ra[4], rb[4];
@@ -1698,9 +1702,15 @@ __device__ __forceinline__ void persist_epilogue(const f32x16 (&acc)[2][2][2], h
         float4 v = *reinterpret_cast<const float4*>(&slabf[row * 32 + ((c ^ ((row >> 1) & 7)) << 2)]);
         if (m >= p.M) continue;
         const size_t orow = p.out_seg ? (size_t)(m / p.out_seg) * p.out_seg_stride + p.out_seg_off + (m % p.out_seg) : (size_t)m;
-        v.x = (v.x + bv.x) * gv.x + r[it].x; v.y = (v.y + bv.y) * gv.y + r[it].y;
-        v.z = (v.z + bv.z) * gv.z + r[it].z; v.w = (v.w + bv.w) * gv.w + r[it].w;
-        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + orow * p.ldo + n) = v;
+        if constexpr (!SPLITK) {
+          v.x = (v.x + bv.x) * gv.x + r[it].x; v.y = (v.y + bv.y) * gv.y + r[it].y;
+          v.z = (v.z + bv.z) * gv.z + r[it].z; v.w = (v.w + bv.w) * gv.w + r[it].w;
+        }
+        if constexpr (SPLITK) {   // raw partial sums of this K range (bias, gamma and the residual are the reduce kernel's)
+          *reinterpret_cast<float4*>(p.ks_ws + ((size_t)krange * p.M + m) * p.N + n) = v;
+        } else {
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + orow * p.ldo + n) = v;
+        }
         if (LNF && p.out16) hx[blk & 1][it] = half4_t{(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
         if (LNF && p.stats) {
           ps1[it] += (v.x + v.y) + (v.z + v.w);
@@ -1777,7 +1787,7 @@ __device__ __forceinline__ void persist_epilogue(const f32x16 (&acc)[2][2][2], h
   }
 }
 
-template <int EPI, bool LNF = false>
+template <int EPI, bool LNF = false, bool SPLITK = false>
 __global__ __launch_bounds__(512) void gemm8kp_f16_kernel(GemmArgs p, int total) {
   extern __shared__ __attribute__((aligned(16))) half_t ring[];  // [buf 2][A0 A1 B0 B1][128][64] + 8 x 4 KiB slabs
   constexpr int HT = 128 * 64;
@@ -1792,9 +1802,12 @@ __global__ __launch_bounds__(512) void gemm8kp_f16_kernel(GemmArgs p, int total)
   const unsigned bh = 32u * (unsigned)p.ldw;
   const int arow0 = wr * 64 + lr, brow0 = wc * 32 + lr;
 
+  // SPLITK: work item = (tile, K range): item j is range j % ksplit of tile j / ksplit; `total` counts items
+  const int KSP = SPLITK ? p.ksplit : 1;
   int idx = blockIdx.x, tm = 0, tn = 0;
-  while (idx < total && !tile_map(idx, ntm, ntn, p.map_mode, tm, tn)) idx += gridDim.x;
+  while (idx < total && !tile_map(idx / KSP, ntm, ntn, p.map_mode, tm, tn)) idx += gridDim.x;
   if (idx >= total) return;
+  int k_lo = SPLITK ? (idx % KSP) * nk / KSP : 0, k_hi = SPLITK ? (idx % KSP + 1) * nk / KSP : nk;
 
   unsigned aoff[2][2], boff[2];
   auto offsets = [&](int m0, int n0) {
@@ -1822,9 +1835,9 @@ __global__ __launch_bounds__(512) void gemm8kp_f16_kernel(GemmArgs p, int total)
       glds16(g, dst + j * 4096);
     }
   };
-  auto prologue = [&]() {
-    stage(0, 0); stage(2, 0); stage(3, 0); stage(1, 0);
-    if (nk > 1) stage(0, 1);
+  auto prologue = [&](int k0, int k1) {
+    stage(0, k0); stage(2, k0); stage(3, k0); stage(1, k0);
+    if (k1 - k0 > 1) stage(0, k0 + 1);
   };
 
   if (p.stagger > 0) {
@@ -1832,7 +1845,7 @@ __global__ __launch_bounds__(512) void gemm8kp_f16_kernel(GemmArgs p, int total)
     for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(8);
   }
   offsets(tm * 256, tn * 256);
-  prologue();
+  prologue(k_lo, k_hi);
 
   half8_t fa[2][2];      // [i][k within the half]
   half8_t fb[2][2][2];   // [k half][b][k within the half]
@@ -1874,15 +1887,15 @@ __global__ __launch_bounds__(512) void gemm8kp_f16_kernel(GemmArgs p, int total)
     // first tile: the counted wait of the 8-phase prologue. Later tiles: the previous tile's stores were issued AFTER this
     // tile's first DMAs, and a count says nothing about which of loads and stores are still in flight, so wait for all
     // (the DMAs landed during the epilogue; stores are acknowledged ~0.1 us after issue)
-    if (first) { if (nk > 1) wait_vmcnt<4>(); else wait_vmcnt<2>(); } else { wait_vmcnt<0>(); }
+    if (first) { if (k_hi - k_lo > 1) wait_vmcnt<4>(); else wait_vmcnt<2>(); } else { wait_vmcnt<0>(); }
     first = false;
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger the second wave row by one barrier
     asm volatile("" ::: "memory");
 
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = k_lo; kt < k_hi; ++kt) {
       const half_t* buf = ring + (kt & 1) * 4 * HT;
-      const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+      const bool more1 = kt + 1 < k_hi, more2 = kt + 2 < k_hi;
 #define LOAD_PHASE(RDS, ST) RDS __builtin_amdgcn_sched_barrier(0); ST
       LOAD_PHASE(RD_B(buf, 0) __builtin_amdgcn_sched_barrier(0); RD_A(buf, 0, 0), if (more1) stage(2, kt + 1);)
       if (more1) wait_vmcnt<6>(); else wait_vmcnt<0>();
@@ -1910,17 +1923,18 @@ __global__ __launch_bounds__(512) void gemm8kp_f16_kernel(GemmArgs p, int total)
 
     // next tile of this workgroup: request its first half-tiles now
     int nidx = idx + gridDim.x, ntm_ = 0, ntn_ = 0;
-    while (nidx < total && !tile_map(nidx, ntm, ntn, p.map_mode, ntm_, ntn_)) nidx += gridDim.x;
+    while (nidx < total && !tile_map(nidx / KSP, ntm, ntn, p.map_mode, ntm_, ntn_)) nidx += gridDim.x;
     const bool have = nidx < total;
-    if (have) {
+    const int nk_lo = SPLITK && have ? (nidx % KSP) * nk / KSP : 0, nk_hi = SPLITK && have ? (nidx % KSP + 1) * nk / KSP : nk;
+    if (have) {   // (every wave is past the ring here: whichever slots the next item's first K-tiles map to are free)
       offsets(ntm_ * 256, ntn_ * 256);
-      prologue();
+      prologue(nk_lo, nk_hi);
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    persist_epilogue<EPI, LNF>(acc, slab, m0 + wr * 128, n0 + wc * 64, lane, p);
+    persist_epilogue<EPI, LNF, SPLITK>(acc, slab, m0 + wr * 128, n0 + wc * 64, lane, p, SPLITK ? idx % KSP : 0);
     if (!have) break;
-    idx = nidx; tm = ntm_; tn = ntn_;
+    idx = nidx; tm = ntm_; tn = ntn_; k_lo = nk_lo; k_hi = nk_hi;
   }
 #undef RD_A
 #undef RD_B
@@ -1942,6 +1956,62 @@ static void launch8kp(const GemmArgs& p, hipStream_t s) {
   q.map_mode = pick_map_mode(ntm, ntn);
   const int total = tile_map_grid(ntm, ntn, q.map_mode);
   hipLaunchKernelGGL((gemm8kp_f16_kernel<EPI, LNF>), dim3(total < num_cus() ? total : num_cus()), dim3(512), LDS, s, q, total);
+}
+
+// Split-K form of tile 11 for the residual update of a FEW tiles with a LONG K (one slice through fc2: 4096x1280x5120 = 80
+// tiles of 256x256 for 256 CUs): `ksplit` workgroups per tile, each over nk / ksplit K-tiles, storing raw partial sums to a
+// caller-registered workspace (psam_gemm_set_workspace); splitk_reduce_kernel then applies out = resid + gamma * (sum + bias)
+// in a fixed order (deterministic; an fp32-atomic epilogue was measured 2.5x SLOWER than no split at all - device-scope float
+// atomics are resolved beyond the per-XCD L2s).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int ks, const float* __restrict__ bias,
+                                                            const float* __restrict__ gamma, const float* resid, int ldr,
+                                                            int resid_mod, float* out, int ldo, int M, int N) {
+  const int n4 = N >> 2;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)M * n4) return;
+  const int m = (int)(i / n4), n = (int)(i - (size_t)m * n4) * 4;
+  float4 v = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int r = 0; r < ks; ++r) {
+    const float4 q = *reinterpret_cast<const float4*>(ws + ((size_t)r * M + m) * N + n);
+    v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+  }
+  if (gamma) {
+    const float4 g = *reinterpret_cast<const float4*>(gamma + n);
+    v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w;
+  }
+  if (resid) {
+    const size_t rrow = resid_mod ? (size_t)(m % resid_mod) : (size_t)m;
+    const float4 r = *reinterpret_cast<const float4*>(resid + rrow * ldr + n);
+    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+  }
+  *reinterpret_cast<float4*>(out + (size_t)m * ldo + n) = v;
+}
+
+static float* g_ks_ws = nullptr;
+static size_t g_ks_ws_bytes = 0;
+extern "C" int psam_gemm_set_workspace(void* ptr, size_t bytes) {   // device scratch for the split-K partial sums (null: no split-K)
+  if (ptr && (reinterpret_cast<uintptr_t>(ptr) & 15)) return PSAM_ERR_ARG;
+  g_ks_ws = (float*)ptr;
+  g_ks_ws_bytes = ptr ? bytes : 0;
+  return PSAM_OK;
+}
+
+static void launch8kp_splitk(const GemmArgs& p, hipStream_t s) {
+  constexpr int LDS = 2 * 4 * 128 * 64 * 2 + 8 * 4096;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm8kp_f16_kernel<EPI_F32, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr = true;
+  }
+  const int ntm = (p.M + 255) / 256, ntn = p.N / 256;
+  GemmArgs q = p;
+  q.map_mode = 1;   // identity map: the items of one tile are neighbours
+  q.ks_ws = g_ks_ws;
+  const int total = ntm * ntn * q.ksplit;
+  hipLaunchKernelGGL((gemm8kp_f16_kernel<EPI_F32, false, true>), dim3(total < num_cus() ? total : num_cus()), dim3(512), LDS, s, q, total);
+  const size_t n4 = (size_t)p.M * (p.N / 4);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, g_ks_ws, q.ksplit, p.bias, p.gamma,
+                     p.resid, p.ldr, p.resid_mod, reinterpret_cast<float*>(p.out), p.ldo, p.M, p.N);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -2435,6 +2505,32 @@ static int gemm_dispatch(const void* A, const void* W, const float* bias, void* 
     else if (epilogue == EPI_GELU_F16) launch4p<EPI_GELU_F16>(p, s);
     else launch4p<EPI_F32>(p, s);
     return psam_launch_status();
+  }
+  p.ksplit = 1;
+  p.ks_ws = nullptr;
+  // split-K (see launch8kp_splitk): only where the automatic choice fell back to the 128x128 kernel because too few 256-tiles
+  // exist, every K range keeps >= 16 K-tiles (the partial stores + the reduce pass cost about as much as 12) and the
+  // registered workspace holds the partial sums
+  {
+    static int ks_on = -1;
+    if (ks_on < 0) { const char* e = getenv("PSAM_GEMM_SPLITK"); ks_on = e ? atoi(e) : 1; }
+    const bool auto_sel = g_tile_override <= 0;
+    if (ks_on && auto_sel && g_ks_ws && tsel == 1 && epilogue == EPI_F32 && !ln_prod && !ln_cons && !head_hd && N % 256 == 0 &&
+        out_seg == 0 && (ldo % 4) == 0) {
+      const int t256 = ((M + 255) / 256) * (N / 256), nkt = K / 64;
+      // measured (tools/gemm_splitk_bench.py, us split / 128-tile): 4096x1280x5120 (3 ranges of 26-27 K-tiles, 240 items) 80 / 108;
+      // 4096x1024x4096 (4 x 16, 256 items) 58 / 52; 4096x768x3072 (3 x 16, 144 items) 44 / 40; 1297x768x3072 (3 x 16, 54) 34 / 37:
+      // it pays only with >= 24 K-tiles per range and the CUs at least three quarters busy
+      int ks = num_cus() / t256;
+      if (ks > nkt / 24) ks = nkt / 24;
+      if (ks > 8) ks = 8;
+      while (ks >= 2 && (size_t)ks * M * N * sizeof(float) > g_ks_ws_bytes) --ks;
+      if (ks >= 2 && t256 * ks * 4 >= num_cus() * 3) {
+        p.ksplit = ks;
+        launch8kp_splitk(p, s);
+        return psam_launch_status();
+      }
+    }
   }
   const bool lnf = ln_prod || ln_cons;
   if (lnf && (tsel == 14 || tsel == 11) && N % 256 == 0) {   // separate instantiations: the plain kernels stay as they were

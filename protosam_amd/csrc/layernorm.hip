@@ -11,6 +11,7 @@
 //     (modeling/common.py:31-43; image_encoder.py:97,105)
 // HBM-bound: reads 4*D bytes, writes 2*D (fp16) or 4*D (fp32) per row.
 #include "common.h"
+#include <stdlib.h>
 
 #define LN_MAXV 8  // supports D <= 64 * 4 * 8 = 2048
 
@@ -18,8 +19,11 @@ template <typename OutT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, OutT* __restrict__ y,
                                                         float* __restrict__ y2, int M, int D, int ldx, int ldy,
-                                                        float eps, int zero_tail_rows) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                        float eps, int zero_tail_rows, int rev) {
+  // rev: walk the rows from the last to the first. The residual stream this kernel reads was written front to back by the GEMM
+  // before it and (at 16 slices: 335 MB) does not fit the 256 MB memory-side cache: reading it back to front meets the most
+  // recently written rows first, while they are still resident
+  const int row = (rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x) * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int nv = D >> 2;
   if (row >= M) {
@@ -84,12 +88,14 @@ extern "C" int psam_layernorm(const float* x, const float* w, const float* b, vo
   if (M <= 0 || D <= 0 || (D & 3) || D > 64 * 4 * LN_MAXV || (ldx & 3) || (ldy & 3)) return PSAM_ERR_ARG;
   dim3 grid((M + zero_tail_rows + 3) / 4), block(256);
   hipStream_t s = (hipStream_t)stream;
+  static int rev = -1;
+  if (rev < 0) { const char* e = getenv("PSAM_LN_REVERSE"); rev = e ? atoi(e) : 0; }
   if (out_dtype == 0)
     hipLaunchKernelGGL(layernorm_kernel<half_t>, grid, block, 0, s, x, w, b, (half_t*)y, y2, M, D, ldx, ldy, eps,
-                       zero_tail_rows);
+                       zero_tail_rows, rev);
   else
     hipLaunchKernelGGL(layernorm_kernel<float>, grid, block, 0, s, x, w, b, (float*)y, (float*)nullptr, M, D, ldx,
-                       ldy, eps, zero_tail_rows);
+                       ldy, eps, zero_tail_rows, rev);
   return psam_launch_status();
 }
 

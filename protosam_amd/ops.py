@@ -107,6 +107,8 @@ def gemm(a, w, bias=None, out=None, epilogue=EPI_F16, resid=None, gamma=None, re
     if fold:
         _req(out16, torch.float16, "out16"); _req(stats, torch.float32, "stats")
         _req(ln_mr, torch.float32, "ln_mr"); _req(ln_s, torch.float32, "ln_s")
+    if epilogue == EPI_F32 and _GEMM_WS is None:
+        _ensure_gemm_workspace(a.device)
     t0 = GEMM_TIMER.start() if GEMM_TIMER is not None else None
     if fold:
         st = _lib.lib().psam_gemm_f16_ln(_ptr(a2), _ptr(w), _ptr(bias), _ptr(out2), _ptr(resid), _ptr(gamma), M, N, K,
@@ -164,6 +166,20 @@ def gemm_heads(a, w, bias, hd, out=None, M=None):
         GEMM_TIMER.stop(t0, 2.0 * M * N * K)
     _lib.check(st, "psam_gemm_f16_heads")
     return out
+
+
+_GEMM_WS = None
+GEMM_WORKSPACE_MB = int(_os.environ.get("PSAM_GEMM_WORKSPACE_MB", "64"))
+
+
+def _ensure_gemm_workspace(device):
+    """Scratch for the split-K form of the fp32-residual GEMM (csrc/gemm.hip launch8kp_splitk): partial sums of one slice through
+    fc2 are 63 MB. Allocated once per process from torch's allocator and registered with the library; 0 MB = no split-K."""
+    global _GEMM_WS
+    if _GEMM_WS is None:
+        n = GEMM_WORKSPACE_MB << 20
+        _GEMM_WS = torch.empty(max(n, 16), dtype=torch.uint8, device=device)
+        _lib.check(_lib.lib().psam_gemm_set_workspace(_GEMM_WS.data_ptr() if n else 0, n), "psam_gemm_set_workspace")
 
 
 def gemm_set_tile(tile):

@@ -127,6 +127,46 @@ def test_gemm_inplace_residual(dev):
     torch.testing.assert_close(x, ref, rtol=1e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("M,N,K,ks", [(4096, 1280, 5120, 3), (4000, 1280, 5120, 3), (2048, 2048, 6144, 4), (8192, 256, 16384, 8),
+                                      (1297, 768, 3072, 1), (4096, 1280, 1280, 1)])
+def test_gemm_splitk_residual(dev, M, N, K, ks):
+    """The residual update of few 256-tiles over a long K (one slice through fc2) takes the split-K form of the persistent
+    kernel: several workgroups per tile write partial sums, a reduce pass applies bias, LayerScale and the residual in a fixed
+    order. Against a float64 product and against the single-pass 128x128 kernel (forced tile 1: no split).
+    `ks` = the split the dispatch rule picks for the shape (1: stays on the single-pass kernel)."""
+    from protosam_amd import ops
+    a = _rand((M, K), dev, 1.0, 1).half()
+    w = _rand((N, K), dev, 0.05, 2).half()
+    bias = _rand((N,), dev, 1.0, 4)
+    gamma = _rand((N,), dev, 1.0, 5)
+    x0 = _rand((M, N), dev, 1.0, 3)
+    ref = (x0.double() + gamma.double() * (a.double() @ w.double().t() + bias.double())).float()
+    x = x0.clone()
+    ops.gemm(a, w, bias, out=x, epilogue=ops.EPI_F32, resid=x, gamma=gamma)
+    y = x0.clone()
+    ops.gemm_set_tile(1)
+    try:
+        ops.gemm(a, w, bias, out=y, epilogue=ops.EPI_F32, resid=y, gamma=gamma)
+    finally:
+        ops.gemm_set_tile(0)
+    tol = 2e-4 * (K / 1280) ** 0.5
+    e_split, e_plain = (x - ref).abs().max().item(), (y - ref).abs().max().item()
+    print(f"{M}x{N}x{K}: max err vs float64: auto {e_split:.2e}, 128-tile {e_plain:.2e}; auto vs 128-tile {(x - y).abs().max().item():.2e}")
+    assert e_split < tol and e_plain < tol
+    # deterministic: a second run is bit-identical; so is the out-of-place form (resid != out) and a row-periodic residual
+    x2 = x0.clone()
+    ops.gemm(a, w, bias, out=x2, epilogue=ops.EPI_F32, resid=x2, gamma=gamma)
+    assert torch.equal(x2, x)
+    z = torch.empty_like(x0)
+    ops.gemm(a, w, bias, out=z, epilogue=ops.EPI_F32, resid=x0, gamma=gamma)
+    assert torch.equal(z, x)
+    per = 100
+    zp = torch.empty_like(x0)
+    ops.gemm(a, w, None, out=zp, epilogue=ops.EPI_F32, resid=x0[:per].contiguous(), resid_mod=per)
+    refp = (x0[:per].double().repeat((M + per - 1) // per, 1)[:M] + a.double() @ w.double().t()).float()
+    assert (zp - refp).abs().max().item() < tol
+
+
 @pytest.mark.parametrize("M,D", [(5, 256), (1297, 768), (4096, 1280), (33, 1024)])
 @pytest.mark.parametrize("eps", [1e-6, 1e-5])
 def test_layernorm(dev, M, D, eps):
