@@ -126,9 +126,10 @@ def main():
     out = torch.zeros((B, 512, 512), dtype=torch.uint8, device=dev)
     parts = [[z for z in range(args.slices) if part_assign(z, args.slices) == pt] for pt in range(3)]
 
-    def step(s, micro=None):
+    def step(s, micro=None, volume=None):
         zs = step_slices(s, parts, B, world, rank)
-        masks, st = run_slices(model, vol_d, sup_imgs, sup_masks, zs, dev, out=out, batch=micro or args.micro)
+        masks, st = run_slices(model, vol_d if volume is None else volume, sup_imgs, sup_masks, zs, dev, out=out,
+                               batch=micro or args.micro)
         full = gather_masks(masks, world)
         return zs, full, st
 
@@ -199,7 +200,7 @@ def main():
         "roofline": roofline,
     }
     if world == 1 and not args.no_extras:     # single-GPU legs (they would need the other ranks for the all-gather otherwise)
-        res.update(extras(args, model, step, ops, psmod, B, torch))
+        res.update(extras(args, model, step, ops, psmod, B, torch, dev))
     cpu = parity = None
     if world == 1 and not args.no_cpu_baseline:
         cpu, parity = cpu_baseline(model, alp_sd, vol, svol, slab, args, dev)
@@ -211,7 +212,7 @@ def main():
         dist.destroy_process_group()
 
 
-def extras(args, model, step, ops, psmod, B, torch):
+def extras(args, model, step, ops, psmod, B, torch, dev):
     """Single-rank legs after the headline measurement (rank 0 only, no collectives): the reference-shaped numbers, per-stage
     GPU time and the HBM-side roofline entries. Each leg is a couple of steps."""
     out = {}
@@ -254,6 +255,26 @@ def extras(args, model, step, ops, psmod, B, torch):
     dt = timed(1, micro=1)
     out["per_slice_forward"] = {"value": round(B / dt, 2), "unit": "slices/s",
                                 "note": "micro_batch 1: one ProtoSAM.forward call per slice, support cached"}
+    # (b2) a scan whose organ covers only part of the z range and comes with satellites: empty coarse masks (SAM skipped for
+    # the slice) and several prompt sets per slice inside the timed region; every step visits all three z-parts
+    from protosam_amd.synth import synth_volume
+    sparse = synth_volume(args.slices, 512, seed=0, kind="ct_sparse")[0].to(dev)
+    nsp = 3
+    for i in range(nsp):
+        step(s0 + i, volume=sparse)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    counts = []
+    for i in range(nsp):
+        counts += step(s0 + i, volume=sparse)[2]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    out["sparse_volume"] = {"value": round(nsp * B / dt, 2), "unit": "slices/s",
+                            "empty_slices": round(sum(1 for c in counts if c == 0) / max(len(counts), 1), 3),
+                            "mean_prompt_sets_per_nonempty_slice": round(sum(counts) / max(sum(1 for c in counts if c), 1), 2),
+                            "note": "headline configuration on a volume whose organ (with five satellite blobs) spans 44 % of "
+                                    "the slices and whose outer 28 % are air: empty coarse masks skip SAM, organ slices carry "
+                                    "4-6 prompt sets"}
     # (c) support re-encoded for every slice as the reference does (grid_proto_fewshot.py:181-184)
     alp = model.coarse_segmentation_model.model
     if alp.cache_support:

@@ -109,7 +109,20 @@ def synth_volume(n_slices=32, size=512, seed=0, kind="mri"):
         r = math.sqrt(max(1e-3, 1.0 - (2 * t - 1) ** 2 * 0.8))
         m = ellipse_mask(size, 0.5 + 0.03 * math.sin(6.0 * t), 0.48 + 0.04 * t, 0.16 * r, 0.21 * r)
         noise = rng.randn(size, size).astype(np.float32)
-        if kind == "ct":
+        if kind == "ct_sparse":
+            # a scan whose organ covers only the middle of the z range (the slices outside it have nothing to segment), with
+            # five small same-contrast satellites around it (a coarse mask of several components on every organ slice)
+            if abs(t - 0.5) > 0.22:
+                m = np.zeros_like(m)
+                if abs(t - 0.5) > 0.36:          # beyond the body: air only
+                    vol[z] = -300.0 + 20.0 * noise
+                    continue
+            else:
+                for j in range(5):
+                    a = 2.0 * math.pi * (j / 5.0 + 0.37 * t)
+                    m = np.maximum(m, ellipse_mask(size, 0.5 + 0.33 * math.sin(a), 0.5 + 0.33 * math.cos(a),
+                                                   0.022 + 0.004 * j, 0.026))
+        if kind in ("ct", "ct_sparse"):
             img = -300.0 + 400.0 * base + 350.0 * m + 20.0 * noise
         else:
             img = np.abs(0.6 * base + 1.5 * m + 0.05 * noise + 0.8)
