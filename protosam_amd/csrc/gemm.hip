@@ -2629,6 +2629,28 @@ extern "C" int psam_gemm_f16(const void* A, const void* W, const float* bias, vo
                              const float* gamma, int M, int N, int K, int lda, int ldw, int ldo, int ldr,
                              int resid_mod, int out_seg, int out_seg_stride, int out_seg_off, int epilogue,
                              void* stream) {
+  // Column split for a tile count just above one round of the persistent kernel (one slice through fc1: 4096x5120x1280 is
+  // 16 x 20 = 320 tiles of 256x256 for 256 CUs - two rounds for 1.25 rounds of work, or 2.5 rounds of the 128-tile kernel):
+  // the columns that fill the CUs exactly once go to the persistent kernel, the rest to whatever the picker chooses for
+  // them (every kernel accumulates an element's K-tiles in the same order, so the results do not depend on the split).
+  {
+    static int ns_on = -1;
+    if (ns_on < 0) { const char* e = getenv("PSAM_GEMM_NSPLIT"); ns_on = e ? atoi(e) : 1; }
+    const int ncu = num_cus();
+    const int ntm = (M + 255) / 256;
+    if (ns_on && g_tile_override <= 0 && (epilogue == EPI_F16 || epilogue == EPI_GELU_F16) && out_seg == 0 && N % 256 == 0 &&
+        K >= 768 && ntm > 0 && ntm <= ncu) {
+      const int ntn = N / 256, c1 = ncu / ntm;                       // whole tile columns in one full round
+      if (c1 >= 1 && c1 < ntn && ntm * c1 * 100 >= ncu * 95 && (ntn - c1) * 2 <= c1) {   // remainder at most half a round
+        const int n1 = c1 * 256;
+        const half_t* Wh = (const half_t*)W;
+        int st = gemm_dispatch(A, W, bias, out, resid, gamma, M, n1, K, lda, ldw, ldo, ldr, resid_mod, 0, 0, 0, epilogue, 0, stream);
+        if (st != PSAM_OK) return st;
+        return gemm_dispatch(A, Wh + (size_t)n1 * ldw, bias ? bias + n1 : nullptr, (half_t*)out + n1, resid, gamma ? gamma + n1 : nullptr,
+                             M, N - n1, K, lda, ldw, ldo, ldr, resid_mod, 0, 0, 0, epilogue, 0, stream);
+      }
+    }
+  }
   return gemm_dispatch(A, W, bias, out, resid, gamma, M, N, K, lda, ldw, ldo, ldr, resid_mod, out_seg, out_seg_stride,
                        out_seg_off, epilogue, 0, stream);
 }

@@ -33,3 +33,24 @@ for M, N, K in shapes:
     ops.gemm_set_tile(0)
     fl = 2.0 * M * N * K
     print(f"{M}x{N}x{K}: " + "  ".join(f"tile {t}: {us:.1f} us ({fl / us / 1e6:.0f} TF)" for t, us in res.items()))
+
+# fp16-output shapes of one slice (column split of a just-over-one-round tile count)
+for M, N, K, epi in ((4096, 5120, 1280, ops.EPI_GELU_F16), (4096, 3840, 1280, ops.EPI_F16), (4096, 4096, 1024, ops.EPI_GELU_F16),
+                     (4096, 3072, 768, ops.EPI_GELU_F16)):
+    a = torch.randn(M, K, device=dev).half()
+    w = (torch.randn(N, K, device=dev) * 0.05).half()
+    b = torch.randn(N, device=dev)
+    o = torch.empty(M, N, device=dev, dtype=torch.float16)
+    res = {}
+    for tile in (0, 1, 11):
+        ops.gemm_set_tile(tile)
+        res[tile] = timed(lambda: ops.gemm(a, w, b, out=o, epilogue=epi))
+    ops.gemm_set_tile(0)
+    ref = o.clone()
+    ops.gemm_set_tile(1)
+    ops.gemm(a, w, b, out=o, epilogue=epi)
+    ops.gemm_set_tile(0)
+    ops.gemm(a, w, b, out=ref, epilogue=epi)
+    fl = 2.0 * M * N * K
+    print(f"{M}x{N}x{K} epi {epi}: " + "  ".join(f"tile {t}: {us:.1f} us ({fl / us / 1e6:.0f} TF)" for t, us in res.items()),
+          "auto == tile 1:", bool(torch.equal(o, ref)))
