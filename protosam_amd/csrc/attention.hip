@@ -1259,10 +1259,272 @@ __global__ __launch_bounds__(896, 4) void wattn_p_kernel(AttnArgs p, int nitems)
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Global attention, DMA-fed form (`gattn_kernel`; PSAM_GATTN=1): attn_kernel<HD, 0 | 1, 4>'s arithmetic (V2 softmax) with the
+// K/V staging of the window kernels: each 64-key tile goes global -> LDS by `global_load_lds_dwordx4` as row-major [64][80]
+// images (K rows in MFMA-row order, V rows in the order the transposing reads want, see wattn_kernel), double-buffered, one
+// barrier per tile; V^T fragments through `ds_read_b64_tr_b16`. No staging registers (28 VGPRs), no LDS store instructions, no
+// transposing writes, no second barrier: the ablation of attn_kernel had the staging at 830 of 1798 us, un-overlapped with the
+// 1180 us of scores + softmax + PV.
+template <int HD, int MODE, bool FULL>
+__global__ __launch_bounds__(256, 2) void gattn_kernel(AttnArgs p) {
+  constexpr int NW = 4, NT = 256, QB = 128;
+  constexpr int HDP = (HD + 31) / 32 * 32;
+  constexpr int KS = HDP / 32;
+  constexpr int DT = HD / 16;
+  constexpr int CH = HD / 8;
+  constexpr int RC = 10, RLD = RC * 8;
+  constexpr int IMG = KT * RLD;                        // halfs per 64-row image
+  constexpr int NINS = (KT * RC) / 64;                 // 10 DMA wave-instructions per image
+  constexpr int NDMA = (NINS + NW - 1) / NW;           // at most 3 per wave
+  const float LOG2E = 1.4426950408889634f;
+  const float RESCALE_THR = 8.0f;
+
+  __shared__ __attribute__((aligned(16))) half_t Kb[2 * IMG];
+  __shared__ __attribute__((aligned(16))) half_t Vb[2 * IMG];
+  constexpr int RWLD = 64;
+  __shared__ __attribute__((aligned(16))) float relw_s[MODE == 1 ? QB * RWLD : 4];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int li = lane & 15, g = lane >> 4;
+  int h, b, qblk;
+  {
+    const int per = p.nqb, nshare = p.B * p.H;
+    const int gq = blockIdx.x / (8 * per), r = blockIdx.x % (8 * per);
+    const int grp = gq * 8 + (r & 7);
+    if (grp >= nshare) return;
+    qblk = r >> 3;
+    h = grp % p.H;
+    b = grp / p.H;
+  }
+  const int N = p.N, H = p.H;
+  const size_t rs = (size_t)p.ts;
+  const half_t* qkv_b = p.qkv + (size_t)b * N * rs;
+  const int ntiles = (N + KT - 1) / KT;
+
+  // per-lane constants of the DMA pieces: key offset inside the tile and 16-byte chunk, for the K and the V image
+  int dkey[2][NDMA], dchunk[NDMA];
+#pragma unroll
+  for (int i = 0; i < NDMA; ++i) {
+    const int S = (wv + i * NW) * 64 + lane;
+    const int R = S / RC, c = S - R * RC;
+    const int rho = R & 31, C = R >> 5;
+    dkey[0][i] = C * 32 + ((rho >> 2) & 3) * 8 + (rho >> 4) * 4 + (rho & 3);
+    dkey[1][i] = C * 32 + ((rho >> 4) * 2 + ((rho >> 2) & 1)) * 8 + ((rho >> 3) & 1) * 4 + (rho & 3);
+    dchunk[i] = c;
+  }
+  const half_t* kbase = qkv_b + (size_t)p.ws_ + (size_t)h * p.hs;        // which = 1
+  const half_t* vbase = qkv_b + 2 * (size_t)p.ws_ + (size_t)h * p.hs;    // which = 2
+  auto dma_tile = [&](int tile, int buf) {
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+      if (wv + i * NW < NINS) {
+        int kk = tile * KT + dkey[0][i], kv = tile * KT + dkey[1][i];
+        if (!FULL) { kk = kk < N ? kk : N - 1; kv = kv < N ? kv : N - 1; }   // masked keys: finite data, probabilities are 0
+        if (dchunk[i] < CH) {
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + (size_t)kk * rs + dchunk[i] * 8),
+                                           (__attribute__((address_space(3))) void*)(Kb + buf * IMG + (wv + i * NW) * 512), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + (size_t)kv * rs + dchunk[i] * 8),
+                                           (__attribute__((address_space(3))) void*)(Vb + buf * IMG + (wv + i * NW) * 512), 16, 0, 0);
+        }
+      }
+    }
+  };
+  dma_tile(0, 0);
+
+  // ---- query fragments ---------------------------------------------------------------------------------
+  const int qrow_blk = qblk * QB + wv * 32;
+  int qtok[2];
+  bool qvalid[2];
+  half8_t qf[2][KS];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int q = qrow_blk + qt * 16 + li;
+    qvalid[qt] = q < N;
+    qtok[qt] = q < N ? q : 0;
+    const half_t* qp = qkv_b + (size_t)qtok[qt] * rs + (size_t)h * p.hs;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int c0 = s * 32 + g * 8;
+      if (c0 < HD) {
+        qf[qt][s] = *reinterpret_cast<const half8_t*>(qp + c0);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[qt][s][e] = (half_t)0.f;
+      }
+    }
+  }
+  const float* relh_q[2] = {nullptr, nullptr};
+  if (MODE == 1) {
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) relh_q[qt] = p.rel_h + (((size_t)b * H + h) * N + qtok[qt]) * (size_t)p.gw;
+    for (int idx = t; idx < QB * 16; idx += NT) {
+      const int qr = idx >> 4, c4 = idx & 15;
+      int q = qblk * QB + qr;
+      q = q < N ? q : N - 1;
+      float4 v = *reinterpret_cast<const float4*>(p.rel_w + (((size_t)b * H + h) * N + q) * (size_t)p.gw + c4 * 4);
+      v.x *= LOG2E; v.y *= LOG2E; v.z *= LOG2E; v.w *= LOG2E;
+      *reinterpret_cast<float4*>(&relw_s[qr * RWLD + ((c4 ^ (qr & 15)) << 2)]) = v;
+    }
+  }
+
+  f32x4 ot[DT][2];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) ot[d][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float sl2 = p.scale * LOG2E;
+  float mrun[2] = {-INFINITY, -INFINITY};
+  f32x4 lt[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  half8_t ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (half_t)1.f;
+
+  // rel_h of (query, key row) is one scalar per 64-key tile: requested one tile ahead and BEFORE that tile's DMA pieces - loads
+  // complete in order, so a request issued after the DMA would wait for the whole next tile to land
+  float bh2n[2] = {0.f, 0.f};
+  if (MODE == 1) {
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) bh2n[qt] = relh_q[qt][0];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();   // tile 0 and the rel_w stage are in
+
+#pragma unroll 1
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int buf = tile & 1;
+    float bh2[2] = {bh2n[0] * LOG2E, bh2n[1] * LOG2E};
+    if (MODE == 1 && tile + 1 < ntiles) {
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) bh2n[qt] = relh_q[qt][tile + 1];
+    }
+    if (tile + 1 < ntiles) dma_tile(tile + 1, buf ^ 1);
+    const half_t* Ks = Kb + buf * IMG;
+    const half_t* Vs = Vb + buf * IMG;
+    const int kbase_i = tile * KT;
+    const bool last_partial = !FULL && (tile == ntiles - 1) && (N % KT != 0);
+    // S^T = K Q^T (four 16-key MFMA tiles)
+    f32x4 st[4][2];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) st[tt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        // (hd = 80: the third k-step's lane groups 2 / 3 face zero query columns; they re-read chunk 9 instead of running into
+        // the next row - finite data either way, but the row after the LAST one may be LDS nobody wrote)
+        const int kc = (s * 4 + 3 < CH) ? s * 4 + g : min(s * 4 + g, CH - 1);
+        const half8_t kf = *reinterpret_cast<const half8_t*>(&Ks[(tt * 16 + li) * RLD + kc * 8]);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) st[tt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qt][s], st[tt][qt], 0, 0, 0);
+      }
+    }
+    half8_t pf[2][2];
+    {
+      float mx[2];
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        float mt[4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          float4 rw4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (MODE == 1)
+            rw4 = *reinterpret_cast<const float4*>(
+                &relw_s[(wv * 32 + qt * 16 + li) * RWLD + ((((tt >> 1) * 8 + g * 2 + (tt & 1)) ^ li) << 2)]);
+          const float rwv[4] = {rw4.x, rw4.y, rw4.z, rw4.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float sv = MODE == 1 ? fmaf(st[tt][qt][r], sl2, rwv[r]) : st[tt][qt][r] * sl2;
+            if (!FULL && last_partial) {
+              const int kidx = kbase_i + (tt >> 1) * 32 + g * 8 + (tt & 1) * 4 + r;
+              if (kidx >= N) sv = -INFINITY;
+            }
+            st[tt][qt][r] = sv;
+          }
+          mt[tt] = fmaxf(fmaxf(st[tt][qt][0], st[tt][qt][1]), fmaxf(st[tt][qt][2], st[tt][qt][3]));
+        }
+        mx[qt] = fmaxf(fmaxf(mt[0], mt[1]), fmaxf(mt[2], mt[3]));
+      }
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        mx[qt] = fmaxf(mx[qt], __shfl_xor(mx[qt], 16, 64));
+        mx[qt] = fmaxf(mx[qt], __shfl_xor(mx[qt], 32, 64));
+        mx[qt] += bh2[qt];
+      }
+      if (!__all(mx[0] <= mrun[0] + RESCALE_THR && mx[1] <= mrun[1] + RESCALE_THR)) {
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          const float mnew = fmaxf(mrun[qt], mx[qt]);
+          const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
+          mrun[qt] = mnew;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lt[qt][r] *= alpha;
+#pragma unroll
+          for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ot[d][qt][r] *= alpha;
+        }
+      }
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        const float moff = mrun[qt] - bh2[qt];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            pf[qt][tt >> 1][(tt & 1) * 4 + r] = (half_t)__builtin_amdgcn_exp2f(st[tt][qt][r] - moff);
+      }
+    }
+    // O^T += V^T P^T; row sums on the matrix pipe
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) lt[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf[qt][s2], lt[qt], 0, 0, 0);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int vrow = s2 * 32 + (g >> 1) * 16 + (g & 1) * 4 + (li >> 2);
+      const half_t* vb = &Vs[vrow * RLD + (li & 3) * 4];
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        const fp16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(vb + d * 16));
+        const fp16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(vb + d * 16 + 8 * RLD));
+        half8_t vf;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          vf[e] = (half_t)v0[e];
+          vf[4 + e] = (half_t)v1[e];
+        }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) ot[d][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qt][s2], ot[d][qt], 0, 0, 0);
+      }
+    }
+    // the next tile has landed (it had this tile's compute time); every wave is done with this tile's buffers
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const float inv = 1.0f / lt[qt][0];
+    if (qvalid[qt]) {
+      half_t* op = p.out + ((size_t)b * N + qtok[qt]) * ((size_t)H * HD) + (size_t)h * HD;
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        half4_t o = {(half_t)(ot[d][qt][0] * inv), (half_t)(ot[d][qt][1] * inv), (half_t)(ot[d][qt][2] * inv),
+                     (half_t)(ot[d][qt][3] * inv)};
+        *reinterpret_cast<half4_t*>(op + d * 16 + g * 4) = o;
+      }
+    }
+  }
+}
+
 static int g_attn_v2 = -1;
+static int g_gattn = -1;   // 1: gattn_kernel for modes 0 / 1
 static int g_wattn = -1;   // 1: wattn_kernel for mode 2 (needs rpack with the appended tables), 0: attn_kernel<HD, 2, 7>
 extern "C" int psam_attention_set_variant(int v) {   // bit 0: V2 softmax in the global kernels (0 = round 1's serial chains); bit 1: wattn_kernel
   g_attn_v2 = (v & 1) ? 1 : 0;                        // for the windows. Default 5; A/B and tests
+  g_gattn = (v & 8) ? 0 : 1;                          // bit 3: 1 = the register-staged global kernel (attn_kernel), 0 = gattn_kernel
   g_wattn = (v >> 1) & 3;                             // bits 1-2: 0 attn_kernel<HD, 2, 7>, 1 wattn_kernel, 2 wattn_p_kernel
   return PSAM_OK;
 }
@@ -1293,6 +1555,17 @@ static int launch_attn(AttnArgs p, int mode, hipStream_t s) {
     const int groups8 = (p.B * p.H + 7) / 8;
     dim3 grid(groups8 * 8 * p.nqb), block(NW * 64);
     const bool full = (p.N % 64) == 0;
+    if (g_gattn < 0) { const char* e = getenv("PSAM_GATTN"); g_gattn = e ? atoi(e) : 1; }
+    if (g_gattn && V2) {
+      if (mode == 1) {
+        if (full) hipLaunchKernelGGL((gattn_kernel<HD, 1, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((gattn_kernel<HD, 1, false>), grid, block, 0, s, p);
+      } else {
+        if (full) hipLaunchKernelGGL((gattn_kernel<HD, 0, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((gattn_kernel<HD, 0, false>), grid, block, 0, s, p);
+      }
+      return psam_launch_status();
+    }
     if (mode == 1) {
       if (full) hipLaunchKernelGGL((attn_kernel<HD, 1, NW, true, V2>), grid, block, 0, s, p);
       else hipLaunchKernelGGL((attn_kernel<HD, 1, NW, false, V2>), grid, block, 0, s, p);

@@ -1653,9 +1653,13 @@ __device__ __forceinline__ void slab_emit16h(const half_t* __restrict__ slab, in
 }
 
 // Epilogue of one 128x64 wave tile of the persistent kernels, through the wave's private 4 KiB slab.
-template <int EPI, bool LNF = false, bool SPLITK = false>
+struct NoNext { __device__ __forceinline__ void operator()() const {} };
+// `issue_next` (tile 11): requests the next tile's first half-tiles. It is called AFTER the epilogue's own first global loads
+// (bias / LayerScale / first residual rows) have been issued: loads complete in order, so requested behind 80 KiB of DMA they
+// would hold the whole epilogue until those tiles have landed.
+template <int EPI, bool LNF = false, bool SPLITK = false, class NEXT = NoNext>
 __device__ __forceinline__ void persist_epilogue(const f32x16 (&acc)[2][2][2], half_t* __restrict__ slab, int mbase, int nbase,
-                                                 int lane, const GemmArgs& p, int krange = 0) {
+                                                 int lane, const GemmArgs& p, int krange = 0, NEXT issue_next = NEXT()) {
   const int lr = lane & 31, lg = lane >> 5;
   if constexpr (EPI == EPI_F32) {
     // x (+)= gamma * (acc + bias) in fp32: eight 32x32 blocks through the 4 KiB slab, 8 lanes per 128-byte row; the
@@ -1682,6 +1686,9 @@ __device__ __forceinline__ void persist_epilogue(const f32x16 (&acc)[2][2][2], h
     float ps1[4] = {0.f, 0.f, 0.f, 0.f}, ps2[4] = {0.f, 0.f, 0.f, 0.f};   // folded LayerNorm: row sums over the wave's 64 columns
     half4_t hx[2][4];                                                      // and half(x) of the current 32-row strip
     pre(0, ra);
+    __builtin_amdgcn_sched_barrier(0);
+    issue_next();
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int blk = 0; blk < 8; ++blk) {
       const f32x16& a = acc[blk >> 2][(blk >> 1) & 1][blk & 1];
@@ -1773,6 +1780,9 @@ __device__ __forceinline__ void persist_epilogue(const f32x16 (&acc)[2][2][2], h
         mrv[sidx] = *reinterpret_cast<const float2*>(p.ln_mr + (size_t)m * 2);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    issue_next();
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int sidx = 0; sidx < 4; ++sidx) {
       if (LNF) {
@@ -1926,13 +1936,24 @@ __global__ __launch_bounds__(512) void gemm8kp_f16_kernel(GemmArgs p, int total)
     while (nidx < total && !tile_map(nidx / KSP, ntm, ntn, p.map_mode, ntm_, ntn_)) nidx += gridDim.x;
     const bool have = nidx < total;
     const int nk_lo = SPLITK && have ? (nidx % KSP) * nk / KSP : 0, nk_hi = SPLITK && have ? (nidx % KSP + 1) * nk / KSP : nk;
-    if (have) {   // (every wave is past the ring here: whichever slots the next item's first K-tiles map to are free)
-      offsets(ntm_ * 256, ntn_ * 256);
-      prologue(nk_lo, nk_hi);
-    }
+    // (every wave is past the ring here: whichever slots the next item's first K-tiles map to are free)
+    auto issue_next = [&]() {
+      if (have) {
+        offsets(ntm_ * 256, ntn_ * 256);
+        prologue(nk_lo, nk_hi);
+      }
+    };
     __builtin_amdgcn_sched_barrier(0);
-
+#ifndef PSAM_EPI_EARLY_NEXT
+#define PSAM_EPI_EARLY_NEXT 1   // 0: the previous order (next tile's DMA before the epilogue's loads), for A/B builds
+#endif
+#if PSAM_EPI_EARLY_NEXT
+    persist_epilogue<EPI, LNF, SPLITK>(acc, slab, m0 + wr * 128, n0 + wc * 64, lane, p, SPLITK ? idx % KSP : 0, issue_next);
+#else
+    issue_next();
+    __builtin_amdgcn_sched_barrier(0);
     persist_epilogue<EPI, LNF, SPLITK>(acc, slab, m0 + wr * 128, n0 + wc * 64, lane, p, SPLITK ? idx % KSP : 0);
+#endif
     if (!have) break;
     idx = nidx; tm = ntm_; tn = ntn_; k_lo = nk_lo; k_hi = nk_hi;
   }

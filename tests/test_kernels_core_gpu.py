@@ -364,7 +364,7 @@ def test_attention_softmax_variants_agree(dev, mode, N, H, hd, B):
         kw = dict(mode=1, rel_h=rel_h, rel_w=rel_w, gh=g, gw=g)
         rel = (rel_h.view(B, H, N, g, 1) + rel_w.view(B, H, N, 1, g)).reshape(B, H, N, N)
     outs = []
-    for v in (0, 1):
+    for v in (0, 9, 1):   # round-1 serial softmax, V2 on the register-staged kernel, V2 on the DMA-fed kernel (gattn_kernel)
         ops.attention_set_variant(v)
         try:
             outs.append(ops.attention(qkv, B, N, H, hd, scale, **kw).float())
