@@ -1266,6 +1266,8 @@ __global__ __launch_bounds__(896, 4) void wattn_p_kernel(AttnArgs p, int nitems)
 // barrier per tile; V^T fragments through `ds_read_b64_tr_b16`. No staging registers (28 VGPRs), no LDS store instructions, no
 // transposing writes, no second barrier: the ablation of attn_kernel had the staging at 830 of 1798 us, un-overlapped with the
 // 1180 us of scores + softmax + PV.
+// (Tried on top: rel_w folded into the score MFMA as 64 one-hot k-slots - 16 more MFMAs per tile for one fma + one LDS read +
+// one subtract less per score, no rel_w stage in LDS: 2083 -> 2183 us, dropped.)
 template <int HD, int MODE, bool FULL>
 __global__ __launch_bounds__(256, 2) void gattn_kernel(AttnArgs p) {
   constexpr int NW = 4, NT = 256, QB = 128;
@@ -1435,7 +1437,8 @@ __global__ __launch_bounds__(256, 2) void gattn_kernel(AttnArgs p) {
           const float rwv[4] = {rw4.x, rw4.y, rw4.z, rw4.w};
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float sv = MODE == 1 ? fmaf(st[tt][qt][r], sl2, rwv[r]) : st[tt][qt][r] * sl2;
+            // MODE 0: the raw score stays (scale > 0: the max commutes with it; folded into the exp2 argument below)
+            float sv = MODE == 1 ? fmaf(st[tt][qt][r], sl2, rwv[r]) : st[tt][qt][r];
             if (!FULL && last_partial) {
               const int kidx = kbase_i + (tt >> 1) * 32 + g * 8 + (tt & 1) * 4 + r;
               if (kidx >= N) sv = -INFINITY;
@@ -1450,7 +1453,8 @@ __global__ __launch_bounds__(256, 2) void gattn_kernel(AttnArgs p) {
       for (int qt = 0; qt < 2; ++qt) {
         mx[qt] = fmaxf(mx[qt], __shfl_xor(mx[qt], 16, 64));
         mx[qt] = fmaxf(mx[qt], __shfl_xor(mx[qt], 32, 64));
-        mx[qt] += bh2[qt];
+        if (MODE == 1) mx[qt] += bh2[qt];
+        else mx[qt] *= sl2;
       }
       if (!__all(mx[0] <= mrun[0] + RESCALE_THR && mx[1] <= mrun[1] + RESCALE_THR)) {
 #pragma unroll
@@ -1473,7 +1477,8 @@ __global__ __launch_bounds__(256, 2) void gattn_kernel(AttnArgs p) {
         for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            pf[qt][tt >> 1][(tt & 1) * 4 + r] = (half_t)__builtin_amdgcn_exp2f(st[tt][qt][r] - moff);
+            pf[qt][tt >> 1][(tt & 1) * 4 + r] =
+                (half_t)__builtin_amdgcn_exp2f(MODE == 1 ? st[tt][qt][r] - moff : fmaf(st[tt][qt][r], sl2, -moff));
       }
     }
     // O^T += V^T P^T; row sums on the matrix pipe
