@@ -1646,29 +1646,31 @@ extern "C" int psam_attention_f16(const void* qkv, void* out, const float* rel_h
 //   windowed             : relq fp16 [B,H,N,2,32] = hi/lo halves of (rel_h[0:K] | rel_w[0:K] | 0) / scale, the extra
 //                          k-slots of the window attention's S^T MFMA (caller zero-fills the buffer once).
 // Rpack: fp16 [2 (h,w)][2 (hi,lo)][RP][HDP], zero padded; RP = 128 (global) or 32 (windowed).
-template <int HD>
+template <int HD, int QT>
 __global__ __launch_bounds__(256) void relpos_mfma_kernel(const half_t* __restrict__ qkv, const half_t* __restrict__ Rpack,
                                                           float* __restrict__ rel_h, float* __restrict__ rel_w,
                                                           half_t* __restrict__ relq, int N, int H, int gw, int K, int RP,
                                                           int windowed, float inv_scale, long long ts, long long hs) {
+  // QT query tiles of 16 tokens per wave (64 * QT tokens per workgroup): every table fragment a wave fetches (98 KB of table per
+  // wave for the global form) serves QT MFMAs instead of one - the kernel was bound by exactly those L2 fetches
   constexpr int HDP = (HD + 31) / 32 * 32;
   constexpr int KS = HDP / 32;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int li = lane & 15, g = lane >> 4;
   const int h = blockIdx.y, b = blockIdx.z;
-  const int n0 = blockIdx.x * 64 + wv * 16;
-  // A operand: 16 query rows
-  half8_t qf[KS];
-  {
-    const half_t* qp = qkv + ((size_t)b * N + n0 + li) * (size_t)ts + (size_t)h * (size_t)hs;   // q = which 0
+  const int n0 = (blockIdx.x * 4 + wv) * 16 * QT;
+  half8_t qf[QT][KS];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    const half_t* qp = qkv + ((size_t)b * N + n0 + t * 16 + li) * (size_t)ts + (size_t)h * (size_t)hs;   // q = which 0
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int c0 = s * 32 + g * 8;
       if (c0 < HD) {
-        qf[s] = *reinterpret_cast<const half8_t*>(qp + c0);
+        qf[t][s] = *reinterpret_cast<const half8_t*>(qp + c0);
       } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) qf[s][e] = (half_t)0.f;
+        for (int e = 0; e < 8; ++e) qf[t][s][e] = (half_t)0.f;
       }
     }
   }
@@ -1677,35 +1679,42 @@ __global__ __launch_bounds__(256) void relpos_mfma_kernel(const half_t* __restri
   for (int tab = 0; tab < 2; ++tab) {
     const half_t* Rhi = Rpack + (size_t)(tab * 2 + 0) * RP * HDP;
     const half_t* Rlo = Rpack + (size_t)(tab * 2 + 1) * RP * HDP;
-#pragma unroll 1
+#pragma unroll 2
     for (int rt = 0; rt < RP / 16; ++rt) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      half8_t rh[KS], rl[KS];
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         const size_t off = (size_t)(rt * 16 + li) * HDP + s * 32 + g * 8;
-        half8_t rh = *reinterpret_cast<const half8_t*>(Rhi + off);
-        half8_t rl = *reinterpret_cast<const half8_t*>(Rlo + off);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[s], rh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[s], rl, acc, 0, 0, 0);
+        rh[s] = *reinterpret_cast<const half8_t*>(Rhi + off);
+        rl[s] = *reinterpret_cast<const half8_t*>(Rlo + off);
       }
-      // acc[e]: token n0 + g*4 + e, table row r = rt*16 + li
       const int r = rt * 16 + li;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int n = n0 + g * 4 + e;
-        int pos = tab == 0 ? n / gw : n % gw;
-        if (windowed) pos %= K;
-        const int k = pos - r + K - 1;
-        if (k >= 0 && k < K && r < 2 * K - 1) {
-          if (windowed) {
-            const float v = acc[e] * inv_scale;
-            const half_t hi = (half_t)v;
-            const half_t lo = (half_t)(v - (float)hi);
-            half_t* o = relq + (bh * N + n) * 64 + tab * K + k;
-            o[0] = hi;
-            o[32] = lo;
-          } else {
-            (tab == 0 ? rel_h : rel_w)[(bh * N + n) * 64 + k] = acc[e];
+      for (int t = 0; t < QT; ++t) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[t][s], rh[s], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[t][s], rl[s], acc, 0, 0, 0);
+        }
+        // acc[e]: token n0 + t*16 + g*4 + e, table row r
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int n = n0 + t * 16 + g * 4 + e;
+          int pos = tab == 0 ? n / gw : n % gw;
+          if (windowed) pos %= K;
+          const int k = pos - r + K - 1;
+          if (k >= 0 && k < K && r < 2 * K - 1) {
+            if (windowed) {
+              const float v = acc[e] * inv_scale;
+              const half_t hi = (half_t)v;
+              const half_t lo = (half_t)(v - (float)hi);
+              half_t* o = relq + (bh * N + n) * 64 + tab * K + k;
+              o[0] = hi;
+              o[32] = lo;
+            } else {
+              (tab == 0 ? rel_h : rel_w)[(bh * N + n) * 64 + k] = acc[e];
+            }
           }
         }
       }
@@ -1718,17 +1727,18 @@ extern "C" int psam_relpos(const void* qkv, const void* Rpack, float* rel_h, flo
   if (B <= 0 || N <= 0 || (N % 64) != 0 || K <= 0 || K > 64) return PSAM_ERR_ARG;
   if (windowed ? (K > 16 || !relq) : (!rel_h || !rel_w)) return PSAM_ERR_ARG;
   const int RP = windowed ? 32 : 128;
-  dim3 grid(N / 64, H, B), block(256);
+  dim3 block(256);
   hipStream_t s = (hipStream_t)stream;
   const float inv = 1.0f / scale;
   const long long ts = head_major ? hd : 3LL * H * hd, hs = head_major ? (long long)B * N * hd : hd;
-  if (hd == 64)
-    hipLaunchKernelGGL(relpos_mfma_kernel<64>, grid, block, 0, s, (const half_t*)qkv, (const half_t*)Rpack, rel_h, rel_w,
-                       (half_t*)relq, N, H, gw, K, RP, windowed, inv, ts, hs);
-  else if (hd == 80)
-    hipLaunchKernelGGL(relpos_mfma_kernel<80>, grid, block, 0, s, (const half_t*)qkv, (const half_t*)Rpack, rel_h, rel_w,
-                       (half_t*)relq, N, H, gw, K, RP, windowed, inv, ts, hs);
-  else
-    return PSAM_ERR_ARG;
+  const bool q4 = (N % 256) == 0;      // four query tiles per wave when the token count allows
+  dim3 grid(q4 ? N / 256 : N / 64, H, B);
+#define PSAM_RELPOS_LAUNCH(HD_, QT_)                                                                                        \
+  hipLaunchKernelGGL((relpos_mfma_kernel<HD_, QT_>), grid, block, 0, s, (const half_t*)qkv, (const half_t*)Rpack, rel_h, rel_w, \
+                     (half_t*)relq, N, H, gw, K, RP, windowed, inv, ts, hs)
+  if (hd == 64) { if (q4) PSAM_RELPOS_LAUNCH(64, 4); else PSAM_RELPOS_LAUNCH(64, 1); }
+  else if (hd == 80) { if (q4) PSAM_RELPOS_LAUNCH(80, 4); else PSAM_RELPOS_LAUNCH(80, 1); }
+  else return PSAM_ERR_ARG;
+#undef PSAM_RELPOS_LAUNCH
   return psam_launch_status();
 }
