@@ -946,7 +946,8 @@ __global__ __launch_bounds__(896, 4) void wattn_p_kernel(AttnArgs p, int nitems)
   const float LOG2E = 1.4426950408889634f;
   const float RESCALE_THR = 8.0f;
 
-  __shared__ __attribute__((aligned(16))) half_t Kb[2 * IMG];
+  __shared__ __attribute__((aligned(16))) half_t Kb0[IMG];
+  __shared__ __attribute__((aligned(16))) half_t Kb1[IMG];
   __shared__ __attribute__((aligned(16))) half_t Vs[IMG];
   __shared__ __attribute__((aligned(16))) half_t Tab[2 * 2 * 32 * RLD];
   __shared__ __attribute__((aligned(16))) half_t Oht[13 * 64 * 8];
@@ -968,25 +969,25 @@ __global__ __launch_bounds__(896, 4) void wattn_p_kernel(AttnArgs p, int nitems)
   const int it0 = (int)((long long)sx * cnt_x / nwg_x), it1 = (int)((long long)(sx + 1) * cnt_x / nwg_x);
   if (it0 >= it1) return;
 
-  // Everything that depends only on the lane is computed once: per DMA piece the key's position inside the window, its 16-byte
-  // chunk and whether the slot exists (packed: kx | ky << 4 | chunk << 8 | zero-row << 12 | active << 13); per item only the
-  // window origin, two compares and one multiply-add per piece remain (the integer divisions of the index math were most of
-  // the per-item instruction count, and a third of them on the one scalar unit the 14 waves share).
-  int geo[2][NDMA];
-#pragma unroll
-  for (int w2 = 0; w2 < 2; ++w2)
-#pragma unroll
-    for (int i = 0; i < NDMA; ++i) {
-      const int S = (wv + i * NW) * 64 + lane;
-      const int R = S / RC, c = S - R * RC;
-      const int rho = R & 31, C = R >> 5;
-      int key;
-      if (w2 == 0) key = C * 32 + ((rho >> 2) & 3) * 8 + (rho >> 4) * 4 + (rho & 3);
-      else key = C * 32 + ((rho >> 4) * 2 + ((rho >> 2) & 1)) * 8 + ((rho >> 3) & 1) * 4 + (rho & 3);
-      const int kk = key < NKEY ? key : 0;
-      const int ky = kk / WS, kx = kk - ky * WS;
-      geo[w2][i] = kx | (ky << 4) | (c << 8) | ((key >= NKEY ? 1 : 0) << 12) | ((R < KROWS && c < CH) ? (1 << 13) : 0);
-    }
+  // Per DMA piece the key's position inside the window, its 16-byte chunk and whether the slot exists, packed as
+  // kx | ky << 4 | chunk << 8 | zero-row << 12 | active << 13: a function of the lane and the piece only (constant divisors).
+  // It is RECOMPUTED per piece (~15 VALU) rather than hoisted out of the item loop: hoisted, the six values were spilled to
+  // scratch at the 128-register budget, and every reload - a VMEM load the compiler waits for with vmcnt(0) - drained the DMA
+  // queue right before the next piece was issued (the ISA showed scratch_load / s_waitcnt vmcnt(0) in front of each
+  // global_load_lds: the pipelining across items was void).
+  auto geo_of = [&](int w2, int i) -> int {
+    int lane_v = lane;
+    asm volatile("" : "+v"(lane_v));      // opaque: keeps the computation inside the item loop (see above)
+    const int S = (wv + i * NW) * 64 + lane_v;
+    const int R = S / RC, c = S - R * RC;
+    const int rho = R & 31, C = R >> 5;
+    int key;
+    if (w2 == 0) key = C * 32 + ((rho >> 2) & 3) * 8 + (rho >> 4) * 4 + (rho & 3);
+    else key = C * 32 + ((rho >> 4) * 2 + ((rho >> 2) & 1)) * 8 + ((rho >> 3) & 1) * 4 + (rho & 3);
+    const int kk = key < NKEY ? key : 0;
+    const int ky = kk / WS, kx = kk - ky * WS;
+    return kx | (ky << 4) | (c << 8) | ((key >= NKEY ? 1 : 0) << 12) | ((R < KROWS && c < CH) ? (1 << 13) : 0);
+  };
   const int ndma_w = (wv + 2 * NW < NINS) ? 3 : 2;   // DMA instructions this wave issues per image (33 = 5 x 3 + 9 x 2)
   const int qidx = wv * 16 + li;                     // this lane's query (window-local; >= 196: none)
   const int qy = (qidx * 4682) >> 16, qx = qidx - 14 * qy;
@@ -1016,14 +1017,20 @@ __global__ __launch_bounds__(896, 4) void wattn_p_kernel(AttnArgs p, int nitems)
 #pragma unroll
     for (int i = 0; i < NDMA; ++i) {
       if (wv + i * NW < NINS) {
-        const int gq = geo[which - 1][i];
+        const int gq = geo_of(which - 1, i);
         const int y = im.wy14 + ((gq >> 4) & 15), xx = im.wx14 + (gq & 15);
         const half_t* src = (y < p.gh && xx < p.gw) ? base + (size_t)(unsigned)((y * p.gw + xx) * (int)rs) : padw;
         src = (gq & (1 << 12)) ? zero_row : src;
         src += ((gq >> 8) & 15) * 8;
-        if (gq & (1 << 13))
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                           (__attribute__((address_space(3))) void*)(img + (wv + i * NW) * 512), 16, 0, 0);
+        // The DMA is issued as inline asm, not through __builtin_amdgcn_global_load_lds: the compiler models the builtin as a
+        // pending LDS write and - across the item loop, where it cannot see the hand-placed counted waits - protects every
+        // later read of the same array with s_waitcnt vmcnt(0), which drains the NEXT item's prefetch (seen in the ISA in front
+        // of the first V read of every item). Unknown to its model, the DMA can only make its own waits more conservative.
+        if (gq & (1 << 13)) {
+          const unsigned ldsb = (unsigned)(size_t)(__attribute__((address_space(3))) half_t*)(img + (wv + i * NW) * 512);
+          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                       :: "v"(src), "s"(__builtin_amdgcn_readfirstlane(ldsb)) : "memory", "m0");
+        }
       }
     }
   };
@@ -1046,7 +1053,7 @@ __global__ __launch_bounds__(896, 4) void wattn_p_kernel(AttnArgs p, int nitems)
 
   // ---- once per workgroup: tables into LDS, first item's K / Q / V ---------------------------------------------------
   Item cur = item_at(it0);
-  dma_image(cur, 1, Kb);
+  dma_image(cur, 1, Kb0);
   half8_t qf[KS];
   int qtok;
   bool qvalid;
@@ -1067,9 +1074,14 @@ __global__ __launch_bounds__(896, 4) void wattn_p_kernel(AttnArgs p, int nitems)
   const float inv_scale = 1.0f / p.scale;
   float* ts = Scr + wv * 512;                                      // [32 r][16 q] fp32, one table at a time
 
-#pragma unroll 1
-  for (int it = it0; it < it1; ++it) {
-    const half_t* Ks = Kb + ((it - it0) & 1) * IMG;
+  // The two K buffers are separate arrays and the item body is instantiated once per buffer parity, so that every K-fragment
+  // read names its array at compile time: a read through a run-time selected pointer cannot be told apart from the pending DMA
+  // into the OTHER buffer, and the compiler put s_waitcnt vmcnt(0) in front of the first one - draining the next item's
+  // prefetch at the start of every item (seen in the ISA).
+  auto body = [&](auto par_c, int it) {
+    constexpr int PAR = decltype(par_c)::value;
+    const half_t* Ks = PAR ? Kb1 : Kb0;
+    half_t* Knext = PAR ? Kb0 : Kb1;
     // requests for the next item: K image into the other buffer, query fragments into registers
     const bool has_next = it + 1 < it1;
     Item nxt = cur;
@@ -1078,7 +1090,7 @@ __global__ __launch_bounds__(896, 4) void wattn_p_kernel(AttnArgs p, int nitems)
     bool qvalid_n = false;
     if (has_next) {
       nxt = item_next(cur);
-      dma_image(nxt, 1, Kb + (((it - it0) & 1) ^ 1) * IMG);
+      dma_image(nxt, 1, Knext);
       load_q(nxt, qn, qtok_n, qvalid_n);
     } else {
 #pragma unroll
@@ -1106,16 +1118,31 @@ __global__ __launch_bounds__(896, 4) void wattn_p_kernel(AttnArgs p, int nitems)
                   &Tab[((tab * 2 + part) * 32 + tile * 16 + li) * RLD + (s * 4 + g) * 8]);
               D = __builtin_amdgcn_mfma_f32_16x16x32_f16(rf, qf[s], D, 0, 0, 0);
             }
-#pragma unroll
-          for (int i = 0; i < 4; ++i) ts[(tile * 16 + g * 4 + i) * 16 + li] = D[i];
+          // (scratch writes as inline asm for the same reason as the gather reads below; the s_nops cover the MFMA-result ->
+          // LDS-data hazard the compiler would otherwise pad)
+          const unsigned waddr = (unsigned)(size_t)(__attribute__((address_space(3))) float*)(ts + (tile * 16 + g * 4) * 16 + li);
+          asm volatile("s_nop 7\n\ts_nop 7\n\tds_write2_b32 %0, %1, %2 offset1:16\n\tds_write2_b32 %0, %3, %4 offset0:32 offset1:48"
+                       :: "v"(waddr), "v"(D[0]), "v"(D[1]), "v"(D[2]), "v"(D[3]) : "memory");
         }
+        // The gather reads are issued as inline asm: for an ordinary LDS load the compiler cannot rule out that it reads what a
+        // pending LDS-DMA writes and puts s_waitcnt vmcnt(0) in front of it - which here would wait for the NEXT item's K image
+        // and query loads, requested a moment ago (seen in the ISA; it made the prefetch across items void). LDS operations of
+        // one wave execute in order, so the reads see the ds_writes above.
+        float gv[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int j = g * 8 + e;                       // k-slot: 0..13 rel_h, 14..27 rel_w, 28..31 unused
+          const int r = ((tab ? qx : qy) + 13 - (tab ? j - 14 : j)) & 31;   // every lane reads; lanes that do not own the slot discard
+          const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) float*)(ts + r * 16 + li);
+          asm volatile("ds_read_b32 %0, %1" : "=v"(gv[e]) : "v"(addr));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(gv[0]), "+v"(gv[1]), "+v"(gv[2]), "+v"(gv[3]), "+v"(gv[4]), "+v"(gv[5]), "+v"(gv[6]), "+v"(gv[7]));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int j = g * 8 + e;
           const bool mine = tab == 0 ? (j < 14) : (j >= 14 && j < 28);
-          const int r = ((tab ? qx : qy) + 13 - (tab ? j - 14 : j)) & 31;   // every lane reads (no divergent waits); others discard
-          const float v = ts[r * 16 + li] * inv_scale;
-          vals[e] = mine ? v : vals[e];
+          vals[e] = mine ? gv[e] * inv_scale : vals[e];
         }
       }
 #pragma unroll
@@ -1200,7 +1227,9 @@ __global__ __launch_bounds__(896, 4) void wattn_p_kernel(AttnArgs p, int nitems)
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __syncthreads();
+        // (a raw barrier: __syncthreads() carries a fence whose vmcnt(0) would drain the next item's prefetch)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
       }
 #pragma unroll
       for (int s2 = 0; s2 < NS2; ++s2) {
@@ -1233,6 +1262,12 @@ __global__ __launch_bounds__(896, 4) void wattn_p_kernel(AttnArgs p, int nitems)
     }
     chunk(std::integral_constant<int, 1>{}, 12, false);
 
+    // next item's K image and query fragments have landed (they had the whole item). The asm "use" tells the compiler the
+    // prefetched fragments are complete HERE: otherwise their first use - the next item's first MFMA, just after that item's
+    // own prefetch was issued - gets its s_waitcnt vmcnt(0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(qn[s]));
     {
       float l = lrun;
       l += __shfl_xor(l, 16, 64);
@@ -1247,15 +1282,20 @@ __global__ __launch_bounds__(896, 4) void wattn_p_kernel(AttnArgs p, int nitems)
         }
       }
     }
-    // next item's K image and query fragments have landed (they had the whole item); every wave is done with K(it) and V(it)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // every wave is done with K(it) and V(it); the output stores stay in flight across the barrier (they are older than
+    // anything the next item waits for with a count)
+    __builtin_amdgcn_s_barrier();
     if (has_next) dma_image(nxt, 2, Vs);
     cur = nxt;
 #pragma unroll
     for (int s = 0; s < KS; ++s) qf[s] = qn[s];
     qtok = qtok_n;
     qvalid = qvalid_n;
+  };
+#pragma unroll 1
+  for (int it = it0; it < it1; it += 2) {
+    body(std::integral_constant<int, 0>{}, it);
+    if (it + 1 < it1) body(std::integral_constant<int, 1>{}, it + 1);
   }
 }
 
