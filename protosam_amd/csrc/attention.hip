@@ -928,7 +928,7 @@ __global__ __launch_bounds__(448, 4) void wattn_kernel(AttnArgs p) {
 //   * two barriers per item.
 // LDS: K 2 x 33 280 + V 33 280 + tables 20 480 + one-hot 13 312 + 14 x 2 KiB prologue scratch = 162 304 bytes.
 #ifndef PSAM_WATTN_NTT
-#define PSAM_WATTN_NTT 2   // 64-key chunks (4) spill 26 VGPRs at the 128-register budget: 419 vs 349 us
+#define PSAM_WATTN_NTT 2   // 64-key chunks (4): 322 vs 314 us - no gain
 #endif
 template <int HD>
 __global__ __launch_bounds__(896, 4) void wattn_p_kernel(AttnArgs p, int nitems) {
