@@ -1686,9 +1686,6 @@ __device__ __forceinline__ void persist_epilogue(const f32x16 (&acc)[2][2][2], h
     float ps1[4] = {0.f, 0.f, 0.f, 0.f}, ps2[4] = {0.f, 0.f, 0.f, 0.f};   // folded LayerNorm: row sums over the wave's 64 columns
     half4_t hx[2][4];                                                      // and half(x) of the current 32-row strip
     pre(0, ra);
-    __builtin_amdgcn_sched_barrier(0);
-    issue_next();
-    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int blk = 0; blk < 8; ++blk) {
       const f32x16& a = acc[blk >> 2][(blk >> 1) & 1][blk & 1];
@@ -1699,6 +1696,15 @@ __device__ __forceinline__ void persist_epilogue(const f32x16 (&acc)[2][2][2], h
       __builtin_amdgcn_sched_barrier(0);
       if (blk < 7) pre(blk + 1, (blk & 1) ? ra : rb);
       __builtin_amdgcn_sched_barrier(0);
+#ifndef PSAM_EPI32_NEXT_AT
+#define PSAM_EPI32_NEXT_AT 0   // block after whose residual request the next tile's first DMAs go out. Loads complete in order, so
+#endif                         // residual rows requested behind 80 KiB of DMA wait for it; issuing the DMA only after the LAST request
+                               // (6) measured slightly slower than right away (997 vs 1001 TFLOP/s in the pipeline): the DMA's own
+                               // latency is the longer pole
+      if (blk == PSAM_EPI32_NEXT_AT) {
+        issue_next();
+        __builtin_amdgcn_sched_barrier(0);
+      }
       const float4 (&r)[4] = (blk & 1) ? rb : ra;
       const float4 bv = bvv[blk & 1], gv = gvv[blk & 1];
       const int mb = mbase + (blk >> 1) * 32, n = nbase + (blk & 1) * 32 + c * 4;
