@@ -1728,32 +1728,44 @@ __global__ __launch_bounds__(256) void relpos_mfma_kernel(const half_t* __restri
         rh[s] = *reinterpret_cast<const half8_t*>(Rhi + off);
         rl[s] = *reinterpret_cast<const half8_t*>(Rlo + off);
       }
-      const int r = rt * 16 + li;
 #pragma unroll
       for (int t = 0; t < QT; ++t) {
+        // table fragment as the A operand, query fragment as B: lane (li, g) then holds token n0 + 16 t + li against FOUR
+        // consecutive table rows r0 .. r0 + 3 = four consecutive key indices k0 .. k0 - 3 of one output row: one 16-byte store per
+        // lane instead of four scattered 4-byte ones (the kernel was bound by the issue of those)
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[t][s], rh[s], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[t][s], rl[s], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(rh[s], qf[t][s], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(rl[s], qf[t][s], acc, 0, 0, 0);
         }
-        // acc[e]: token n0 + t*16 + g*4 + e, table row r
+        const int n = n0 + t * 16 + li;
+        const int r0 = rt * 16 + g * 4;
+        int pos = tab == 0 ? n / gw : n % gw;
+        if (windowed) pos %= K;
+        const int k0 = pos - r0 + K - 1;               // key index of acc[0]; acc[e] belongs to k0 - e
+        if (windowed) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int n = n0 + t * 16 + g * 4 + e;
-          int pos = tab == 0 ? n / gw : n % gw;
-          if (windowed) pos %= K;
-          const int k = pos - r + K - 1;
-          if (k >= 0 && k < K && r < 2 * K - 1) {
-            if (windowed) {
+          for (int e = 0; e < 4; ++e) {
+            const int kk = k0 - e;
+            if (kk >= 0 && kk < K && r0 + e < 2 * K - 1) {
               const float v = acc[e] * inv_scale;
               const half_t hi = (half_t)v;
               const half_t lo = (half_t)(v - (float)hi);
-              half_t* o = relq + (bh * N + n) * 64 + tab * K + k;
+              half_t* o = relq + (bh * N + n) * 64 + tab * K + kk;
               o[0] = hi;
               o[32] = lo;
-            } else {
-              (tab == 0 ? rel_h : rel_w)[(bh * N + n) * 64 + k] = acc[e];
+            }
+          }
+        } else {
+          float* o = (tab == 0 ? rel_h : rel_w) + (bh * N + n) * 64;
+          if (k0 - 3 >= 0 && k0 < K && r0 + 3 < 2 * K - 1) {
+            *reinterpret_cast<float4*>(o + k0 - 3) = make_float4(acc[3], acc[2], acc[1], acc[0]);   // 4-byte aligned is enough
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int kk = k0 - e;
+              if (kk >= 0 && kk < K && r0 + e < 2 * K - 1) o[kk] = acc[e];
             }
           }
         }
