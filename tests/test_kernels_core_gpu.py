@@ -236,7 +236,8 @@ def test_attention_global_relpos(dev, H, hd):
     torch.testing.assert_close(out.float(), ref, rtol=2e-3, atol=2e-3)
 
 
-@pytest.mark.parametrize("B,g,H,hd", [(2, 64, 2, 64), (2, 64, 2, 80), (3, 32, 3, 80), (1, 20, 1, 64), (5, 30, 16, 80)])
+@pytest.mark.parametrize("B,g,H,hd", [(2, 64, 2, 64), (2, 64, 2, 80), (3, 32, 3, 80), (1, 20, 1, 64), (5, 30, 16, 80),
+                                      (1, 24, 2, 80)])   # (24 x 24 = 576 tokens: psam_relpos' one-tile-per-wave form)
 def test_attention_window_relpos(dev, B, g, H, hd):
     """14x14 windows over a g x g map, zero-padded tokens carry the qkv bias (image_encoder.py:267-271): the two-kernel path
     (psam_relpos -> relq) and the three window kernels of the fused path (attn_kernel, wattn_kernel, the persistent
