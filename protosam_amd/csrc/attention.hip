@@ -926,6 +926,9 @@ __global__ __launch_bounds__(448, 4) void wattn_kernel(AttnArgs p) {
 //   * the rel-pos tables and the one-hot fragments live in LDS for the lifetime of the workgroup (the per-item loads of the
 //     24 KiB table from L2 were most of the old prologue's time);
 //   * two barriers per item.
+// (Tried: the 14th wave, whose query rows do not exist, as a dedicated loader issuing all 66 DMA pieces of an item - one wave's
+// serial address arithmetic + DMA issue takes as long as the whole item, 314 -> 488 us; the same wave merely skipping its
+// pointless arithmetic - no measurable change. Both dropped.)
 // LDS: K 2 x 33 280 + V 33 280 + tables 20 480 + one-hot 13 312 + 14 x 2 KiB prologue scratch = 162 304 bytes.
 #ifndef PSAM_WATTN_NTT
 #define PSAM_WATTN_NTT 2   // 64-key chunks (4): 322 vs 314 us - no gain
