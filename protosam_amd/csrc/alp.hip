@@ -20,6 +20,8 @@
 // All arithmetic is fp32 (the x20 logit scale leaves no room for fp16 operands): the similarity GEMM
 // runs on v_mfma_f32_32x32x2_f32, which is bit-wise an fp32 fma chain.
 #include "common.h"
+#include <stdlib.h>
+#include <type_traits>
 
 #define META_NBG 0
 #define META_NFG 1
@@ -293,13 +295,14 @@ __global__ __launch_bounds__(256) void alp_sim_kernel(const float* __restrict__ 
 
 // ---- kernel E: merge proto-tile partials -> pred[b, bank, pix] = sum(softmax(d) * d) --------------------
 __global__ void alp_combine_kernel(const float* __restrict__ part, const int* __restrict__ meta, int npt, int npix,
-                                   int npix_pad, float* __restrict__ pred, int which_only) {
+                                   int npix_pad, float* __restrict__ pred, int which_only, int gsize) {
   const int z = blockIdx.y;  // b*2 + bank
   if (which_only >= 0 && (z & 1) != which_only) return;
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   if (x >= npix) return;
   const int n = (z & 1) ? meta[META_NFG] : meta[META_NBG];
-  const int nt = (n + 63) / 64;
+  // (an empty bank: kernel D2's first group still writes (-inf, 0, 0); kernel D writes nothing; either way pred = 0 / 0)
+  const int nt = n > 0 ? (n + gsize - 1) / gsize : (gsize == 96 ? 1 : 0);
   float m = -INFINITY, Z = 0.f, W = 0.f;
   for (int i = 0; i < nt && i < npt; ++i) {
     const float* p = part + (((size_t)z * npt + i) * npix_pad + x) * 3;
@@ -312,6 +315,151 @@ __global__ void alp_combine_kernel(const float* __restrict__ part, const int* __
     m = mm;
   }
   pred[(size_t)z * npix + x] = W / Z;
+}
+
+// ---- kernel D2: similarity GEMM + softmax-weighted sum in ONE pass (the default; D + E above are kept for A/B) -------------
+// One workgroup = 64 query pixels of one (batch, bank) against one GROUP of 96 prototypes (three 32 x 32 MFMA tiles per wave),
+// two waves of 32 pixels each; grid.y walks the groups (validation pools the 36 x 36 support map 2 x 2: up to 325 prototypes
+// per bank, typically ~300 background and a few dozen foreground ones - a first version that looped over the groups inside
+// the workgroup ran at the MFMA rate per wave but left the background workgroups four times as long as the foreground ones:
+// 343 us). The K loop (C = 768 in stages of 32) is double-buffered through registers with one barrier per stage; operands are
+// fetched as float4 (kernel D: 16 scalar loads and 16 scalar LDS writes per thread and stage, two barriers, no overlap of loads
+// and MFMAs: 384 us per 16-slice step for ~100 us of fp32-MFMA work). LDS rows are 36 floats: a ds_read_b128 of the 32 rows of a fragment is conflict-free, and
+// MFMA s of a stage consumes k = {s, s + 16}, so one float4 per lane feeds four MFMAs. |q|^2 comes from the fragments already in
+// registers. A bank of one group writes pred = W / Z directly; otherwise the per-pixel (max, Z, W) of the group goes to `part`
+// and kernel E merges the groups.
+#define S2_LD 36
+__global__ __launch_bounds__(128) void alp_sim2_kernel(const float* __restrict__ qry, size_t q_bstride, int ld, int npix, int C,
+                                                       const float* __restrict__ bank, int cap, const int* __restrict__ meta,
+                                                       float eps, float sim_scale, float* __restrict__ pred, int which_only, int dbg,
+                                                       float* __restrict__ part, int npt, int npix_pad) {
+  __shared__ __attribute__((aligned(16))) float Qs[2][64 * S2_LD];
+  __shared__ __attribute__((aligned(16))) float Ps[2][96 * S2_LD];
+  const int z = blockIdx.z, b = z >> 1, which = z & 1;
+  if (which_only >= 0 && which != which_only) return;
+  const int n = which ? meta[META_NFG] : meta[META_NBG];
+  const int g0 = blockIdx.y * 96;
+  if (g0 >= n && g0 > 0) return;
+  const int x0 = blockIdx.x * 64;
+  const float* Q = qry + (size_t)b * q_bstride;
+  const float* P = bank + (size_t)(which * cap) * C;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int lr = lane & 31, lk = lane >> 5;
+  const int srow = t >> 3, sc4 = (t & 7) * 4;           // staging: rows srow + 16 i, floats sc4 .. sc4 + 3 of the stage
+  const int nst = C / 32;
+
+  float m = -INFINITY, Z = 0.f, W = 0.f, qsq = 0.f;
+  // global -> register prefetch TWO stages ahead (two register sets, the stage loop unrolled by two so that the sets are
+  // static): with 46 KiB of LDS only three workgroups = 1.5 waves per SIMD are resident, so a stage's loads have to be hidden by
+  // the wave's own MFMAs - one stage (48 MFMAs, ~1.5 us) is shorter than the load latency under load, two are not
+  float4 qreg[2][4], preg[2][6];
+  {
+    f32x16 acc[3];
+#pragma unroll
+    for (int pt = 0; pt < 3; ++pt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[pt][r] = 0.f;
+    auto load_stage = [&](int st, auto set_c) {
+      constexpr int SET = decltype(set_c)::value;
+      const int k0 = st * 32 + sc4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int x = x0 + srow + 16 * i;
+        qreg[SET][i] = x < npix ? *reinterpret_cast<const float4*>(Q + (size_t)x * ld + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int pr = g0 + srow + 16 * i;
+        preg[SET][i] = pr < n ? *reinterpret_cast<const float4*>(P + (size_t)pr * C + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    };
+    auto store_stage = [&](int buf, auto set_c) {
+      constexpr int SET = decltype(set_c)::value;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&Qs[buf][(srow + 16 * i) * S2_LD + sc4]) = qreg[SET][i];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) *reinterpret_cast<float4*>(&Ps[buf][(srow + 16 * i) * S2_LD + sc4]) = preg[SET][i];
+    };
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    load_stage(0, C0{});
+    if (nst > 1) load_stage(1, C1{});
+    store_stage(0, C0{});
+    __syncthreads();
+    // stage st lives in LDS buffer st & 1 and was carried in register set st & 1
+    auto stage = [&](auto par_c, int st) {
+      constexpr int PAR = decltype(par_c)::value;
+      using CP = std::integral_constant<int, PAR>;
+      using CN = std::integral_constant<int, PAR ^ 1>;
+      if (st + 2 < nst && !(dbg & 1)) load_stage(st + 2, CP{});      // set PAR is free: stage st went to LDS an iteration ago
+      if (!(dbg & 2))
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 qv = *reinterpret_cast<const float4*>(&Qs[PAR][(wv * 32 + lr) * S2_LD + 16 * lk + 4 * j]);
+        qsq += (qv.x * qv.x + qv.y * qv.y) + (qv.z * qv.z + qv.w * qv.w);
+        const float qe[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+        for (int pt = 0; pt < 3; ++pt) {
+          const float4 pv = *reinterpret_cast<const float4*>(&Ps[PAR][(pt * 32 + lr) * S2_LD + 16 * lk + 4 * j]);
+          const float pe[4] = {pv.x, pv.y, pv.z, pv.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(pe[e], qe[e], acc[pt], 0, 0, 0);
+        }
+      }
+      if (st + 1 < nst && !(dbg & 4)) store_stage(PAR ^ 1, CN{});     // stage st + 1, requested one stage ago
+      if (!(dbg & 8)) __syncthreads();
+    };
+    for (int st = 0; st < nst; st += 2) {
+      stage(C0{}, st);
+      if (st + 1 < nst) stage(C1{}, st + 1);
+    }
+    // acc[pt][r]: prototype g0 + pt*32 + (r&3) + 8*(r>>2) + 4*lk, pixel x0 + wv*32 + lr
+    qsq += __shfl_xor(qsq, 32, 64);
+    const float qinv = sim_scale / fmaxf(sqrtf(qsq), eps);
+    float d[3][16];
+    float mg = -INFINITY;
+#pragma unroll
+    for (int pt = 0; pt < 3; ++pt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int pr = g0 + pt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        d[pt][r] = pr < n ? acc[pt][r] * qinv : -INFINITY;
+        mg = fmaxf(mg, d[pt][r]);
+      }
+    if (mg > -INFINITY) {
+      const float mm = fmaxf(m, mg);
+      const float ea = m > -INFINITY ? expf(m - mm) : 0.f;
+      float Zg = 0.f, Wg = 0.f;
+#pragma unroll
+      for (int pt = 0; pt < 3; ++pt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (d[pt][r] > -INFINITY) {
+            const float e = expf(d[pt][r] - mm);
+            Zg += e;
+            Wg += e * d[pt][r];
+          }
+      Z = Z * ea + Zg;
+      W = W * ea + Wg;
+      m = mm;
+    }
+  }
+  // the two lane halves hold disjoint prototype subsets of the same pixel
+  const float mo = __shfl_xor(m, 32, 64), Zo = __shfl_xor(Z, 32, 64), Wo = __shfl_xor(W, 32, 64);
+  const float mm = fmaxf(m, mo);
+  const float ea = m > -INFINITY ? expf(m - mm) : 0.f, eb = mo > -INFINITY ? expf(mo - mm) : 0.f;
+  const float Zt = Z * ea + Zo * eb, Wt = W * ea + Wo * eb;
+  const int x = x0 + wv * 32 + lr;
+  if (lk == 0 && x < npix) {
+    if (npt == 1) {
+      pred[(size_t)z * npix + x] = Wt / Zt;
+    } else {
+      float* o = part + (((size_t)z * npt + blockIdx.y) * npix_pad + x) * 3;
+      o[0] = mm;
+      o[1] = Zt;
+      o[2] = Wt;
+    }
+  }
 }
 
 // mres: scratch fp32 [2*h*w] (nearest-resized fg mask, then bg mask). bmask may be null (= 1 - mask).
@@ -340,9 +488,22 @@ extern "C" int psam_alp_sim(const float* qry, long long q_bstride, int ld, int B
   if (B <= 0 || npix <= 0 || (C % 32) != 0 || cap < 2) return PSAM_ERR_ARG;
   const int npt = (cap + 63) / 64, nxt = (npix + 63) / 64, npix_pad = nxt * 64;
   hipStream_t s = (hipStream_t)stream;
+  static int v2 = -1;
+  if (v2 < 0) { const char* e = getenv("PSAM_ALP_SIM2"); v2 = e ? atoi(e) : 1; }
+  if (v2 && (ld % 4) == 0 && (reinterpret_cast<uintptr_t>(qry) & 15) == 0 && (q_bstride % 4) == 0) {
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("PSAM_ALP_DBG"); dbg = e ? atoi(e) : 0; }
+    const int ng = (cap + 95) / 96;          // (<= ceil(cap / 64): `part` as sized for kernel D is large enough)
+    hipLaunchKernelGGL(alp_sim2_kernel, dim3(nxt, ng, 2 * B), dim3(128), 0, s, qry, (size_t)q_bstride, ld, npix, C, bank, cap,
+                       meta, eps, sim_scale, pred, which_only, dbg, part, ng, npix_pad);
+    if (ng > 1)
+      hipLaunchKernelGGL(alp_combine_kernel, dim3((npix + 255) / 256, 2 * B), dim3(256), 0, s, part, meta, ng, npix, npix_pad, pred,
+                         which_only, 96);
+    return psam_launch_status();
+  }
   hipLaunchKernelGGL(alp_sim_kernel, dim3(nxt, npt, 2 * B), dim3(256), 0, s, qry, (size_t)q_bstride, ld, npix, C, bank,
                      cap, meta, eps, sim_scale, part, npt, npix_pad, which_only);
   hipLaunchKernelGGL(alp_combine_kernel, dim3((npix + 255) / 256, 2 * B), dim3(256), 0, s, part, meta, npt, npix,
-                     npix_pad, pred, which_only);
+                     npix_pad, pred, which_only, 64);
   return psam_launch_status();
 }
