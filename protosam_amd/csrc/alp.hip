@@ -318,8 +318,8 @@ __global__ void alp_combine_kernel(const float* __restrict__ part, const int* __
 }
 
 // ---- kernel D2: similarity GEMM + softmax-weighted sum in ONE pass (the default; D + E above are kept for A/B) -------------
-// One workgroup = 64 query pixels of one (batch, bank) against one GROUP of 96 prototypes (three 32 x 32 MFMA tiles per wave),
-// two waves of 32 pixels each; grid.y walks the groups (validation pools the 36 x 36 support map 2 x 2: up to 325 prototypes
+// One workgroup = 128 query pixels of one (batch, bank) against one GROUP of 96 prototypes (three 32 x 32 MFMA tiles per wave),
+// four waves of 32 pixels each sharing the group's LDS image (64.5 KiB: two workgroups = two waves per SIMD per CU); grid.y walks the groups (validation pools the 36 x 36 support map 2 x 2: up to 325 prototypes
 // per bank, typically ~300 background and a few dozen foreground ones - a first version that looped over the groups inside
 // the workgroup ran at the MFMA rate per wave but left the background workgroups four times as long as the foreground ones:
 // 343 us). The K loop (C = 768 in stages of 32) is double-buffered through registers with one barrier per stage; operands are
@@ -329,18 +329,21 @@ __global__ void alp_combine_kernel(const float* __restrict__ part, const int* __
 // registers. A bank of one group writes pred = W / Z directly; otherwise the per-pixel (max, Z, W) of the group goes to `part`
 // and kernel E merges the groups.
 #define S2_LD 36
-__global__ __launch_bounds__(128) void alp_sim2_kernel(const float* __restrict__ qry, size_t q_bstride, int ld, int npix, int C,
+template <int NWV>   // waves per workgroup = 32-pixel strips sharing one prototype group's LDS image
+__global__ __launch_bounds__(NWV * 64) void alp_sim2_kernel(const float* __restrict__ qry, size_t q_bstride, int ld, int npix, int C,
                                                        const float* __restrict__ bank, int cap, const int* __restrict__ meta,
                                                        float eps, float sim_scale, float* __restrict__ pred, int which_only, int dbg,
                                                        float* __restrict__ part, int npt, int npix_pad) {
-  __shared__ __attribute__((aligned(16))) float Qs[2][64 * S2_LD];
+  constexpr int PX = NWV * 32, NT = NWV * 64;
+  constexpr int QI = PX * 8 / NT, PI = 96 * 8 / NT, RSTEP = NT / 8;   // float4 loads per thread and stage, row step between them
+  __shared__ __attribute__((aligned(16))) float Qs[2][PX * S2_LD];
   __shared__ __attribute__((aligned(16))) float Ps[2][96 * S2_LD];
   const int z = blockIdx.z, b = z >> 1, which = z & 1;
   if (which_only >= 0 && which != which_only) return;
   const int n = which ? meta[META_NFG] : meta[META_NBG];
   const int g0 = blockIdx.y * 96;
   if (g0 >= n && g0 > 0) return;
-  const int x0 = blockIdx.x * 64;
+  const int x0 = blockIdx.x * PX;
   const float* Q = qry + (size_t)b * q_bstride;
   const float* P = bank + (size_t)(which * cap) * C;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(128) void alp_sim2_kernel(const float* __restrict__
   // global -> register prefetch TWO stages ahead (two register sets, the stage loop unrolled by two so that the sets are
   // static): with 46 KiB of LDS only three workgroups = 1.5 waves per SIMD are resident, so a stage's loads have to be hidden by
   // the wave's own MFMAs - one stage (48 MFMAs, ~1.5 us) is shorter than the load latency under load, two are not
-  float4 qreg[2][4], preg[2][6];
+  float4 qreg[2][QI], preg[2][PI];
   {
     f32x16 acc[3];
 #pragma unroll
@@ -363,22 +366,22 @@ __global__ __launch_bounds__(128) void alp_sim2_kernel(const float* __restrict__
       constexpr int SET = decltype(set_c)::value;
       const int k0 = st * 32 + sc4;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int x = x0 + srow + 16 * i;
+      for (int i = 0; i < QI; ++i) {
+        const int x = x0 + srow + RSTEP * i;
         qreg[SET][i] = x < npix ? *reinterpret_cast<const float4*>(Q + (size_t)x * ld + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const int pr = g0 + srow + 16 * i;
+      for (int i = 0; i < PI; ++i) {
+        const int pr = g0 + srow + RSTEP * i;
         preg[SET][i] = pr < n ? *reinterpret_cast<const float4*>(P + (size_t)pr * C + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     };
     auto store_stage = [&](int buf, auto set_c) {
       constexpr int SET = decltype(set_c)::value;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&Qs[buf][(srow + 16 * i) * S2_LD + sc4]) = qreg[SET][i];
+      for (int i = 0; i < QI; ++i) *reinterpret_cast<float4*>(&Qs[buf][(srow + RSTEP * i) * S2_LD + sc4]) = qreg[SET][i];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) *reinterpret_cast<float4*>(&Ps[buf][(srow + 16 * i) * S2_LD + sc4]) = preg[SET][i];
+      for (int i = 0; i < PI; ++i) *reinterpret_cast<float4*>(&Ps[buf][(srow + RSTEP * i) * S2_LD + sc4]) = preg[SET][i];
     };
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
@@ -494,8 +497,14 @@ extern "C" int psam_alp_sim(const float* qry, long long q_bstride, int ld, int B
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("PSAM_ALP_DBG"); dbg = e ? atoi(e) : 0; }
     const int ng = (cap + 95) / 96;          // (<= ceil(cap / 64): `part` as sized for kernel D is large enough)
-    hipLaunchKernelGGL(alp_sim2_kernel, dim3(nxt, ng, 2 * B), dim3(128), 0, s, qry, (size_t)q_bstride, ld, npix, C, bank, cap,
-                       meta, eps, sim_scale, pred, which_only, dbg, part, ng, npix_pad);
+    static int nwv = -1;
+    if (nwv < 0) { const char* e = getenv("PSAM_ALP_WAVES"); nwv = e ? atoi(e) : 4; }   // measured: 246 us with two-wave workgroups, 192 us with four (16-slice step)
+    if (nwv == 4)
+      hipLaunchKernelGGL(alp_sim2_kernel<4>, dim3((npix + 127) / 128, ng, 2 * B), dim3(256), 0, s, qry, (size_t)q_bstride, ld, npix, C,
+                         bank, cap, meta, eps, sim_scale, pred, which_only, dbg, part, ng, npix_pad);
+    else
+      hipLaunchKernelGGL(alp_sim2_kernel<2>, dim3(nxt, ng, 2 * B), dim3(128), 0, s, qry, (size_t)q_bstride, ld, npix, C, bank, cap,
+                         meta, eps, sim_scale, pred, which_only, dbg, part, ng, npix_pad);
     if (ng > 1)
       hipLaunchKernelGGL(alp_combine_kernel, dim3((npix + 255) / 256, 2 * B), dim3(256), 0, s, part, meta, ng, npix, npix_pad, pred,
                          which_only, 96);
