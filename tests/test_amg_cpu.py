@@ -97,6 +97,8 @@ def test_custom_points_label_rule():
     assert not g._fast_path(np.zeros((1024, 1024, 3), np.uint8))
     g = SamAutomaticMaskGenerator(sam, points_per_side=8)
     assert g._fast_path(np.zeros((1024, 768, 3), np.uint8)) and not g._fast_path(np.zeros((48, 44, 3), np.uint8))
+    with pytest.raises(ImportError):                                            # pycocotools is absent, as it may be for the
+        SamAutomaticMaskGenerator(sam, points_per_side=8, output_mode="coco_rle")   # reference (:116-117): same error type
     with pytest.raises(AssertionError):
         SamAutomaticMaskGenerator(sam, points_per_side=None)
     with pytest.raises(AssertionError):

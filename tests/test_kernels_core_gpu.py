@@ -167,6 +167,35 @@ def test_gemm_splitk_residual(dev, M, N, K, ks):
     assert (zp - refp).abs().max().item() < tol
 
 
+def test_gemm_splitk_needs_a_registered_workspace(dev):
+    """Without a workspace (psam_gemm_set_workspace(NULL)) the fc2-per-slice shape stays on the single-pass kernel: the result is
+    bit-identical to the forced 128-tile kernel; registering a workspace again switches the split-K path back on."""
+    from protosam_amd import _lib, ops
+    M, N, K = 4096, 1280, 5120
+    a = _rand((M, K), dev, 1.0, 1).half()
+    w = _rand((N, K), dev, 0.05, 2).half()
+    x0 = _rand((M, N), dev, 1.0, 3)
+    ops.gemm(a, w, None, out=x0.clone(), epilogue=ops.EPI_F32, resid=x0.clone())       # (registers the default workspace)
+    y = x0.clone()
+    ops.gemm_set_tile(1)
+    try:
+        ops.gemm(a, w, None, out=y, epilogue=ops.EPI_F32, resid=y)
+    finally:
+        ops.gemm_set_tile(0)
+    ws = ops._GEMM_WS
+    try:
+        _lib.check(_lib.lib().psam_gemm_set_workspace(0, 0), "psam_gemm_set_workspace")
+        x = x0.clone()
+        ops.gemm(a, w, None, out=x, epilogue=ops.EPI_F32, resid=x)
+        assert torch.equal(x, y)
+        assert _lib.lib().psam_gemm_set_workspace(ws.data_ptr() + 4, 1024) == 1      # misaligned: bad argument
+    finally:
+        _lib.check(_lib.lib().psam_gemm_set_workspace(ws.data_ptr(), ws.numel()), "psam_gemm_set_workspace")
+    x = x0.clone()
+    ops.gemm(a, w, None, out=x, epilogue=ops.EPI_F32, resid=x)
+    assert not torch.equal(x, y) and (x - y).abs().max().item() < 2e-4                # split-K: another summation order
+
+
 @pytest.mark.parametrize("M,D", [(5, 256), (1297, 768), (4096, 1280), (33, 1024)])
 @pytest.mark.parametrize("eps", [1e-6, 1e-5])
 def test_layernorm(dev, M, D, eps):
