@@ -1310,7 +1310,9 @@ __global__ __launch_bounds__(896, 4) void wattn_p_kernel(AttnArgs p, int nitems)
 // transposing writes, no second barrier: the ablation of attn_kernel had the staging at 830 of 1798 us, un-overlapped with the
 // 1180 us of scores + softmax + PV.
 // (Tried on top: rel_w folded into the score MFMA as 64 one-hot k-slots - 16 more MFMAs per tile for one fma + one LDS read +
-// one subtract less per score, no rel_w stage in LDS: 2083 -> 2183 us, dropped.)
+// one subtract less per score, no rel_w stage in LDS: 2083 -> 2183 us, dropped. The score accumulators started at
+// (rel_h - running max) / (scale*log2e), so that the per-score subtraction only happens on tiles that raise the maximum: 2066 us,
+// within the noise - dropped as well.)
 template <int HD, int MODE, bool FULL>
 __global__ __launch_bounds__(256, 2) void gattn_kernel(AttnArgs p) {
   constexpr int NW = 4, NT = 256, QB = 128;
