@@ -37,15 +37,26 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     return;
   }
   const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * ldx);
-  float4 v[LN_MAXV];
+  const float4* w4 = reinterpret_cast<const float4*>(w);
+  const float4* b4 = reinterpret_cast<const float4*>(b);
+  float4 v[LN_MAXV], wv[LN_MAXV], bv[LN_MAXV];
   float s = 0.f;
 #pragma unroll
   for (int k = 0; k < LN_MAXV; ++k) {
     int i = lane + 64 * k;
-    if (i < nv) {
-      v[k] = xr[i];
-      s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
-    }
+    if (i < nv) v[k] = xr[i];
+  }
+  // the affine parameters are requested right behind the row (they return in order, after it): one exposed latency per wave
+  // instead of two
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k) {
+    int i = lane + 64 * k;
+    if (i < nv) { wv[k] = w4[i]; bv[k] = b4[i]; }
+  }
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k) {
+    int i = lane + 64 * k;
+    if (i < nv) s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
   }
   const float mean = wave_sum(s) / (float)D;
   float q = 0.f;
@@ -59,13 +70,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
   const float var = wave_sum(q) / (float)D;
   const float rstd = 1.0f / sqrtf(var + eps);
-  const float4* w4 = reinterpret_cast<const float4*>(w);
-  const float4* b4 = reinterpret_cast<const float4*>(b);
 #pragma unroll
   for (int k = 0; k < LN_MAXV; ++k) {
     int i = lane + 64 * k;
     if (i < nv) {
-      float4 ww = w4[i], bb = b4[i];
+      float4 ww = wv[k], bb = bv[k];
       float o0 = (v[k].x - mean) * rstd * ww.x + bb.x;
       float o1 = (v[k].y - mean) * rstd * ww.y + bb.y;
       float o2 = (v[k].z - mean) * rstd * ww.z + bb.z;
