@@ -70,7 +70,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
 
 // XCD-aware bijective block remap (8 XCDs; block b runs on XCD b % 8): gives each XCD a
 // contiguous chunk of the logical tile space so neighbouring tiles share an L2.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+__host__ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int nx = 8;
   int xcd = bid % nx, idx = bid / nx;
   int q = nwg / nx, r = nwg % nx;

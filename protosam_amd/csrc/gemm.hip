@@ -21,6 +21,9 @@
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
+#include <map>
+#include <string>
+#include <vector>
 
 enum { EPI_F16 = 0, EPI_GELU_F16 = 1, EPI_F32 = 2, EPI_RELU_F16 = 3 };
 
@@ -83,7 +86,7 @@ static inline bool xcd_maps_apply() { device_geometry(); return g_num_xcds == 8 
 // that minimises rows + cols per region) and each XCD walks its region in 4-row strips, column by column, so any 32
 // consecutive tiles of an XCD form a ~4 x 8 patch (12 operand panels instead of 33 for a row-major chunk).
 // Measured on 8192^3 (256x256 tiles): DMA-only time 1213 us (contiguous chunk per XCD) -> 500 us (2-D spread).
-__device__ __forceinline__ bool tile_map(int bid, int ntm, int ntn, int mode, int& tm, int& tn) {
+__host__ __device__ __forceinline__ bool tile_map(int bid, int ntm, int ntn, int mode, int& tm, int& tn) {
   if (mode == 1) {
     if (bid >= ntm * ntn) return false;
     tm = bid / ntn;
@@ -113,7 +116,7 @@ __device__ __forceinline__ bool tile_map(int bid, int ntm, int ntn, int mode, in
   const int nr = ((rx + 1) * ntm) / xm - r0, nc = ((cx + 1) * ntn) / xn - c0;
   if (nr <= 0 || nc <= 0 || idx >= nr * nc) return false;
   const int strip = idx / (4 * nc), rem = idx - strip * 4 * nc;
-  const int rows = min(4, nr - strip * 4);
+  const int rows = (nr - strip * 4) < 4 ? (nr - strip * 4) : 4;
   tm = r0 + strip * 4 + rem % rows;
   tn = c0 + rem / rows;
   return true;
@@ -2415,6 +2418,101 @@ static void launch256(const GemmArgs& p, hipStream_t s) {
                      C::LDS_BYTES, s, p);
 }
 
+
+// ---- tile 15: the hand-scheduled assembly kernels of gemm_asm_gen.py (code object embedded by gemm_asm_blob.S) ----------------
+// Four waves / 128x128 wave tiles / whole K-tile of fragments in registers / LDS-DMA two K-tiles ahead through buffer descriptors;
+// one persistent workgroup per CU walks a host-built list of 256x256 tiles (the same XCD-aware order as tile 11). Same MFMA and the
+// same k order as tiles 10 / 11 / 13, same epilogue arithmetic: bit-identical results (tests/test_kernels_core_gpu.py).
+extern "C" const unsigned char psam_gemm_asm_co[];
+extern "C" const unsigned char psam_gemm_asm_co_end[];
+struct AsmGemmArgs {
+  const void* A; const void* W; const void* bias; void* out; const void* resid; const void* gamma; const void* tab;
+  int M, N, K, lda, ldw, ldo, ldr, G, flags, pad;
+};
+static_assert(sizeof(AsmGemmArgs) == 96, "kernarg layout of gemm_asm_gen.py");
+static hipModule_t g_asm_mod = nullptr;
+static hipFunction_t g_asm_fn[3] = {nullptr, nullptr, nullptr};
+static int g_asm_state = 0;   // 0 not tried, 1 loaded, -1 failed
+static bool asm_load() {
+  if (g_asm_state != 0) return g_asm_state > 0;
+  g_asm_state = -1;
+  const char* path = getenv("PSAM_GEMM_ASM_CO");          // (experiments: a code object built from another schedule)
+  hipError_t st = path ? hipModuleLoad(&g_asm_mod, path) : hipModuleLoadData(&g_asm_mod, psam_gemm_asm_co);
+  if (st != hipSuccess) { (void)hipGetLastError(); return false; }
+  const char* suf = getenv("PSAM_GEMM_ASM_VARIANT");
+  const char* names[3] = {"psam_gemm_asm_f16", "psam_gemm_asm_gelu", "psam_gemm_asm_f32"};
+  for (int i = 0; i < 3; ++i) {
+    std::string n = std::string(names[i]) + (suf ? suf : "");
+    if (hipModuleGetFunction(&g_asm_fn[i], g_asm_mod, n.c_str()) != hipSuccess) { (void)hipGetLastError(); return false; }
+  }
+  g_asm_state = 1;
+  return true;
+}
+struct AsmTable { int grid; int* dev; };
+static std::map<unsigned long long, AsmTable> g_asm_tabs;
+// work list of workgroup b: entry i at tab[i * G + b] = tm | tn << 16, terminated (and padded two rows deep) by -1
+static const AsmTable* asm_table(int ntm, int ntn, int mode) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long key = ((unsigned long long)ntm << 40) | ((unsigned long long)ntn << 16) | ((unsigned long long)mode << 8) | (unsigned)dev;
+  auto it = g_asm_tabs.find(key);
+  if (it != g_asm_tabs.end()) return &it->second;
+  const int total = tile_map_grid(ntm, ntn, mode);
+  const int G = total < num_cus() ? total : num_cus();
+  std::vector<std::vector<int>> lists(G);
+  for (int b = 0; b < G; ++b)
+    for (int idx = b; idx < total; idx += G) {
+      int tm = 0, tn = 0;
+      if (tile_map(idx, ntm, ntn, mode, tm, tn)) lists[b].push_back(tm | (tn << 16));
+    }
+  size_t rows = 0;
+  for (auto& l : lists) rows = l.size() > rows ? l.size() : rows;
+  rows += 3;
+  std::vector<int> h(rows * G, -1);
+  for (int b = 0; b < G; ++b)
+    for (size_t i = 0; i < lists[b].size(); ++i) h[i * G + b] = lists[b][i];
+  AsmTable t;
+  t.grid = G;
+  t.dev = nullptr;
+  if (hipMalloc((void**)&t.dev, h.size() * sizeof(int)) != hipSuccess) return nullptr;
+  if (hipMemcpy(t.dev, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  return &(g_asm_tabs[key] = t);
+}
+static bool asm_eligible(const GemmArgs& p, int epilogue, bool lnf) {
+  if (lnf || p.head_hd || p.out_seg || p.resid_mod || epilogue > EPI_F32) return false;
+  if (p.N % 256 || p.K % 64 || p.K < 128 || p.M < 1) return false;
+  if ((p.lda % 8) || (p.ldw % 8) || (reinterpret_cast<uintptr_t>(p.A) & 15) || (reinterpret_cast<uintptr_t>(p.W) & 15)) return false;
+  const unsigned long long lim = 0xffffffffull;
+  if ((unsigned long long)p.M * p.lda * 2 > lim || (unsigned long long)p.N * p.ldw * 2 > lim) return false;
+  if (p.bias && (reinterpret_cast<uintptr_t>(p.bias) & 15)) return false;
+  if (epilogue == EPI_F32) {
+    if ((p.ldo % 4) || (reinterpret_cast<uintptr_t>(p.out) & 15) || (unsigned long long)p.M * p.ldo * 4 > lim) return false;
+    if (p.resid && ((p.ldr % 4) || (reinterpret_cast<uintptr_t>(p.resid) & 15) || (unsigned long long)p.M * p.ldr * 4 > lim)) return false;
+    if (p.gamma && (reinterpret_cast<uintptr_t>(p.gamma) & 15)) return false;
+  } else {
+    if (!p.wide16 || (unsigned long long)p.M * p.ldo * 2 > lim) return false;
+  }
+  return true;
+}
+static int launch_asm(const GemmArgs& p, int epilogue, hipStream_t s) {
+  if (!asm_load()) return PSAM_ERR_LAUNCH;
+  const int ntm = (p.M + 255) / 256, ntn = p.N / 256;
+  const AsmTable* t = asm_table(ntm, ntn, pick_map_mode(ntm, ntn));
+  if (!t) return PSAM_ERR_LAUNCH;
+  AsmGemmArgs a;
+  a.A = p.A; a.W = p.W; a.bias = p.bias; a.out = p.out; a.resid = p.resid; a.gamma = p.gamma; a.tab = t->dev;
+  a.M = p.M; a.N = p.N; a.K = p.K; a.lda = p.lda; a.ldw = p.ldw; a.ldo = p.ldo; a.ldr = p.resid ? p.ldr : 0; a.G = t->grid;
+  a.flags = p.gamma ? 1 : 0;
+  a.pad = 0;
+  size_t sz = sizeof(a);
+  void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  if (hipModuleLaunchKernel(g_asm_fn[epilogue], t->grid, 1, 1, 256, 1, 1, 0, s, nullptr, extra) != hipSuccess) {
+    (void)hipGetLastError();
+    return PSAM_ERR_LAUNCH;
+  }
+  return PSAM_OK;
+}
+
 // tile choice: 0 = auto, 1 = 128x128x64 double buffer, 2 = 256x128 / 3 = 256x256 staggered ring, 5 = 256x256 plain ring,
 // 6 = wave-specialised 384x128, 7 = 256x256x64 8-phase, 8 = 7 with one barrier per phase, 9 = four waves with 128x128
 // wave tiles and register staging (experimental), 10 = 8-phase with K-split phases, 11 = its persistent form (the default
@@ -2513,6 +2611,13 @@ static int gemm_dispatch(const void* A, const void* W, const float* bias, void* 
   if (ln_prod || ln_cons) {   // the folded-LayerNorm epilogues live in the 128x128 kernel and the persistent 256x256 ones
     if (tsel != 11 && tsel != 14) tsel = 1;
     if (ln_cons && !p.wide16) return PSAM_ERR_ARG;
+  }
+  if (tsel == 15) {
+    if (asm_eligible(p, epilogue, ln_prod || ln_cons)) return launch_asm(p, epilogue, s);
+    tsel = (N % 256 == 0 && K >= 128) ? 11 : 1;    // shapes / layouts the assembly kernels do not take
+    if (head_hd && tsel != 11) tsel = 1;
+    if (tsel == 11 && epilogue != EPI_F32 && !p.wide16) tsel = 1;
+    if ((ln_prod || ln_cons) && tsel != 11) tsel = 1;
   }
   if ((tsel == 3 || tsel == 5) && N % 256 == 0) {
     if (tsel == 3) {
