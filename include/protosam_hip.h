@@ -55,6 +55,9 @@ int psam_ln_finalize(const float* stats, int M, int D, float eps, float* mr, voi
  * 2 = 256x128x32 / 3 = 256x256x32 (two staggered wave groups) and 5 = 256x256x32 (plain) with a 4-deep direct-to-LDS
  * DMA ring. */
 int psam_gemm_set_tile(int tile);
+/* Schedule variant of the assembly GEMM (tile 15): 0 = the shipped kernels; n > 0 selects the numbered experiment kernels of a
+ * library built with `make GENFLAGS=--experiments` (csrc/gemm_asm_gen.py; a missing variant makes the next GEMM return an error). */
+int psam_gemm_asm_variant(int variant);
 /* Device scratch for the split-K form of psam_gemm_f16 (fp32 partial sums, [ksplit][M][N]): used only when registered and
  * large enough; EPI 2 on few 256x256 tiles with K >= 2048 then runs `ksplit` workgroups per tile + one reduce pass
  * (deterministic). 16-byte aligned; the caller keeps it alive and must not share it between concurrently running streams.

@@ -2428,25 +2428,35 @@ extern "C" const unsigned char psam_gemm_asm_co_end[];
 struct AsmGemmArgs {
   const void* A; const void* W; const void* bias; void* out; const void* resid; const void* gamma; const void* tab;
   int M, N, K, lda, ldw, ldo, ldr, G, flags, pad;
+  void* trace;   // experiment variants only (gemm_asm_gen.py --experiments): uint4 per workgroup {k-loop cycles, epilogue cycles, K-tiles, 0}
 };
-static_assert(sizeof(AsmGemmArgs) == 96, "kernarg layout of gemm_asm_gen.py");
+static_assert(sizeof(AsmGemmArgs) == 104, "kernarg layout of gemm_asm_gen.py");
 static hipModule_t g_asm_mod = nullptr;
-static hipFunction_t g_asm_fn[3] = {nullptr, nullptr, nullptr};
-static int g_asm_state = 0;   // 0 not tried, 1 loaded, -1 failed
-static bool asm_load() {
-  if (g_asm_state != 0) return g_asm_state > 0;
-  g_asm_state = -1;
-  const char* path = getenv("PSAM_GEMM_ASM_CO");          // (experiments: a code object built from another schedule)
-  hipError_t st = path ? hipModuleLoad(&g_asm_mod, path) : hipModuleLoadData(&g_asm_mod, psam_gemm_asm_co);
-  if (st != hipSuccess) { (void)hipGetLastError(); return false; }
-  const char* suf = getenv("PSAM_GEMM_ASM_VARIANT");
-  const char* names[3] = {"psam_gemm_asm_f16", "psam_gemm_asm_gelu", "psam_gemm_asm_f32"};
-  for (int i = 0; i < 3; ++i) {
-    std::string n = std::string(names[i]) + (suf ? suf : "");
-    if (hipModuleGetFunction(&g_asm_fn[i], g_asm_mod, n.c_str()) != hipSuccess) { (void)hipGetLastError(); return false; }
+static std::map<int, std::vector<hipFunction_t>> g_asm_fns;   // variant -> {f16, gelu, f32}
+static int g_asm_variant = 0;   // 0 = the shipped schedule; > 0: experiment builds (kernel names carry the suffix _v<n>)
+static int g_asm_state = 0;     // 0 not tried, 1 loaded, -1 failed
+extern "C" int psam_gemm_asm_variant(int v) {
+  g_asm_variant = v;
+  return PSAM_OK;
+}
+static const hipFunction_t* asm_load() {
+  if (g_asm_state == 0) {
+    g_asm_state = -1;
+    const char* path = getenv("PSAM_GEMM_ASM_CO");          // (experiments: a code object built from another schedule)
+    hipError_t st = path ? hipModuleLoad(&g_asm_mod, path) : hipModuleLoadData(&g_asm_mod, psam_gemm_asm_co);
+    if (st != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    g_asm_state = 1;
   }
-  g_asm_state = 1;
-  return true;
+  if (g_asm_state < 0) return nullptr;
+  auto it = g_asm_fns.find(g_asm_variant);
+  if (it != g_asm_fns.end()) return it->second.data();
+  const char* names[3] = {"psam_gemm_asm_f16", "psam_gemm_asm_gelu", "psam_gemm_asm_f32"};
+  std::vector<hipFunction_t> f(3, nullptr);
+  for (int i = 0; i < 3; ++i) {
+    std::string n = std::string(names[i]) + (g_asm_variant > 0 ? "_v" + std::to_string(g_asm_variant) : std::string());
+    if (hipModuleGetFunction(&f[i], g_asm_mod, n.c_str()) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  }
+  return (g_asm_fns[g_asm_variant] = f).data();
 }
 struct AsmTable { int grid; int* dev; };
 static std::map<unsigned long long, AsmTable> g_asm_tabs;
@@ -2495,7 +2505,8 @@ static bool asm_eligible(const GemmArgs& p, int epilogue, bool lnf) {
   return true;
 }
 static int launch_asm(const GemmArgs& p, int epilogue, hipStream_t s) {
-  if (!asm_load()) return PSAM_ERR_LAUNCH;
+  const hipFunction_t* fns = asm_load();
+  if (!fns) return PSAM_ERR_LAUNCH;
   const int ntm = (p.M + 255) / 256, ntn = p.N / 256;
   const AsmTable* t = asm_table(ntm, ntn, pick_map_mode(ntm, ntn));
   if (!t) return PSAM_ERR_LAUNCH;
@@ -2504,11 +2515,26 @@ static int launch_asm(const GemmArgs& p, int epilogue, hipStream_t s) {
   a.M = p.M; a.N = p.N; a.K = p.K; a.lda = p.lda; a.ldw = p.ldw; a.ldo = p.ldo; a.ldr = p.resid ? p.ldr : 0; a.G = t->grid;
   a.flags = p.gamma ? 1 : 0;
   a.pad = 0;
+  a.trace = nullptr;
+  static const char* tr = getenv("PSAM_GEMM_ASM_TRACE");
+  const bool trace = tr && g_asm_variant > 0;
+  if (trace) { (void)hipMalloc(&a.trace, (size_t)t->grid * 16); (void)hipMemsetAsync(a.trace, 0, (size_t)t->grid * 16, s); }
   size_t sz = sizeof(a);
   void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  if (hipModuleLaunchKernel(g_asm_fn[epilogue], t->grid, 1, 1, 256, 1, 1, 0, s, nullptr, extra) != hipSuccess) {
+  if (hipModuleLaunchKernel(fns[epilogue], t->grid, 1, 1, 256, 1, 1, 0, s, nullptr, extra) != hipSuccess) {
     (void)hipGetLastError();
     return PSAM_ERR_LAUNCH;
+  }
+  if (trace) {   // debugging aid (synchronous): shader cycles inside the k-loops and the epilogues, wave 0 of every workgroup
+    std::vector<unsigned> h((size_t)t->grid * 4);
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h.data(), a.trace, h.size() * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(a.trace);
+    double loop = 0, epi = 0, kt = 0;
+    for (int b = 0; b < t->grid; ++b) { loop += h[b * 4]; epi += h[b * 4 + 1]; kt += h[b * 4 + 2]; }
+    const double tiles = kt / (p.K / 64);
+    if (kt > 0) fprintf(stderr, "asm v%d %dx%dx%d epi%d: %.0f cycles per K-tile, %.0f cycles per epilogue (%.1f tiles per workgroup)\n", g_asm_variant, p.M, p.N,
+                        p.K, epilogue, loop / kt, epi / tiles, tiles / t->grid);
   }
   return PSAM_OK;
 }

@@ -187,6 +187,11 @@ def gemm_set_tile(tile):
     _lib.check(_lib.lib().psam_gemm_set_tile(int(tile)), "psam_gemm_set_tile")
 
 
+def gemm_asm_variant(v):
+    """Experiment kernels of the assembly GEMM (library built with GENFLAGS=--experiments); 0 = shipped schedule."""
+    _lib.check(_lib.lib().psam_gemm_asm_variant(int(v)), "psam_gemm_asm_variant")
+
+
 def im2col(x, B, H, W, C, kh, kw, stride, dil, pad, ldo=None, out=None):
     """token-major half map [B, H*W, C] -> half [B*Ho*Wo, ldo] (column (ky*kw+kx)*C + c; zero K padding up to ldo)."""
     _req(x, torch.float16, "x")
