@@ -2573,6 +2573,9 @@ static int pick_tile(int M, int N, int K, int epilogue) {
     if (K >= 768 && t256 * 100 >= rounds * ncu * (short_f32 ? 95 : 80)) {
       static int f32p = -1;
       if (f32p < 0) { const char* e = getenv("PSAM_GEMM_F32_PERSIST"); f32p = e ? atoi(e) : 1; }
+      static int asm_on = -1;   // the assembly kernels (tile 15) take every shape the persistent HIP kernel took, when eligible (gemm_dispatch)
+      if (asm_on < 0) { const char* e = getenv("PSAM_GEMM_ASM"); asm_on = e ? atoi(e) : 1; }
+      if (asm_on) return 15;
       return epilogue == EPI_F32 && !f32p ? 10 : 11;
     }
   }
@@ -2630,21 +2633,17 @@ static int gemm_dispatch(const void* A, const void* W, const float* bias, void* 
   dim3 grid(tile_map_grid(ntm, ntn, p.map_mode)), block(256);
   hipStream_t s = (hipStream_t)stream;
   int tsel = epilogue == EPI_RELU_F16 ? 1 : pick_tile(M, N, K, epilogue);
-  if (head_hd && tsel != 1 && tsel != 7 && tsel != 8 && tsel != 10 && tsel != 11 && tsel != 13 && tsel != 14) tsel = 1;   // the head-major store lives in the staged epilogue  // the ReLU epilogue lives in the 128x128 kernel
-  // the slab epilogues store fp16 rows with 16-byte instructions when the layout allows (tiles 7 / 8 / 10 require it)
+  // the slab epilogues store fp16 rows with 16-byte instructions when the layout allows (tiles 7 / 8 / 10 / 11 / 15 require it)
   p.wide16 = (ldo % 8) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (!head_hd || head_hd % 8 == 0);
+  // the assembly kernels (tile 15) take plain row-major operands; everything else they were picked for goes to the persistent HIP kernel
+  if (tsel == 15 && !asm_eligible(p, epilogue, ln_prod || ln_cons)) tsel = (N % 256 == 0) ? 11 : 1;
+  if (head_hd && tsel != 1 && tsel != 7 && tsel != 8 && tsel != 10 && tsel != 11 && tsel != 13 && tsel != 14) tsel = 1;   // the head-major store lives in the staged epilogue  // the ReLU epilogue lives in the 128x128 kernel
   if ((tsel == 7 || tsel == 8 || tsel == 10 || tsel == 11 || tsel == 13 || tsel == 14) && epilogue != EPI_F32 && !p.wide16) tsel = 1;
   if (ln_prod || ln_cons) {   // the folded-LayerNorm epilogues live in the 128x128 kernel and the persistent 256x256 ones
     if (tsel != 11 && tsel != 14) tsel = 1;
     if (ln_cons && !p.wide16) return PSAM_ERR_ARG;
   }
-  if (tsel == 15) {
-    if (asm_eligible(p, epilogue, ln_prod || ln_cons)) return launch_asm(p, epilogue, s);
-    tsel = (N % 256 == 0 && K >= 128) ? 11 : 1;    // shapes / layouts the assembly kernels do not take
-    if (head_hd && tsel != 11) tsel = 1;
-    if (tsel == 11 && epilogue != EPI_F32 && !p.wide16) tsel = 1;
-    if ((ln_prod || ln_cons) && tsel != 11) tsel = 1;
-  }
+  if (tsel == 15) return launch_asm(p, epilogue, s);
   if ((tsel == 3 || tsel == 5) && N % 256 == 0) {
     if (tsel == 3) {
       if (epilogue == EPI_F16) launch256<EPI_F16, 256, 1>(p, s);

@@ -38,7 +38,7 @@ def test_gemm(dev, M, N, K, epi):
         torch.testing.assert_close(out, resid + gamma * ref, rtol=1e-4, atol=2e-4)
 
 
-@pytest.mark.parametrize("tile", [2, 3, 5, 6, 7, 8, 9, 10, 11, 13, 14])
+@pytest.mark.parametrize("tile", [2, 3, 5, 6, 7, 8, 9, 10, 11, 13, 14, 15])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (1297, 768, 768), (4096, 1280, 1280), (1000, 512, 192)])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_gemm_large_tiles(dev, tile, M, N, K, epi):
@@ -80,7 +80,7 @@ def test_gemm_persistent_tile_walks_many_tiles(dev, M, N, K, epi):
     resid = _rand((M, N), dev, 1.0, 24) if epi == 2 else None
     gamma = _rand((N,), dev, 1.0, 25) if epi == 2 else None
     outs = []
-    for tile in (10, 11, 13, 14):
+    for tile in (10, 11, 13, 14, 15):   # 15 = the assembly kernels (csrc/gemm_asm_gen.py)
         ops.gemm_set_tile(tile)
         try:
             if epi == 2:
