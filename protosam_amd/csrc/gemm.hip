@@ -19,6 +19,7 @@
 // (slot ^= (row>>1)&7) that makes the ds_read_b128 fragment reads bank-conflict-free is applied on
 // the DMA's per-lane SOURCE address, because the LDS side of the DMA is lane-linear.
 #include "common.h"
+#include "gemm_asm_meta.h"   // generated: PSAM_ASM2_E_* (gemm_asm_gen.py --meta)
 #include <stdlib.h>
 #include <type_traits>
 #include <map>
@@ -2432,14 +2433,14 @@ struct AsmGemmArgs {
 };
 static_assert(sizeof(AsmGemmArgs) == 104, "kernarg layout of gemm_asm_gen.py");
 static hipModule_t g_asm_mod = nullptr;
-static std::map<int, std::vector<hipFunction_t>> g_asm_fns;   // variant -> {f16, gelu, f32}
+static std::map<int, std::vector<hipFunction_t>> g_asm_fns;   // family * 1000 + variant -> {f16, gelu, f32}
 static int g_asm_variant = 0;   // 0 = the shipped schedule; > 0: experiment builds (kernel names carry the suffix _v<n>)
 static int g_asm_state = 0;     // 0 not tried, 1 loaded, -1 failed
 extern "C" int psam_gemm_asm_variant(int v) {
   g_asm_variant = v;
   return PSAM_OK;
 }
-static const hipFunction_t* asm_load() {
+static const hipFunction_t* asm_load(int family = 1) {
   if (g_asm_state == 0) {
     g_asm_state = -1;
     const char* path = getenv("PSAM_GEMM_ASM_CO");          // (experiments: a code object built from another schedule)
@@ -2448,23 +2449,28 @@ static const hipFunction_t* asm_load() {
     g_asm_state = 1;
   }
   if (g_asm_state < 0) return nullptr;
-  auto it = g_asm_fns.find(g_asm_variant);
+  const int key = family * 1000 + g_asm_variant;
+  auto it = g_asm_fns.find(key);
   if (it != g_asm_fns.end()) return it->second.data();
-  const char* names[3] = {"psam_gemm_asm_f16", "psam_gemm_asm_gelu", "psam_gemm_asm_f32"};
+  const char* names[3] = {"f16", "gelu", "f32"};
   std::vector<hipFunction_t> f(3, nullptr);
   for (int i = 0; i < 3; ++i) {
-    std::string n = std::string(names[i]) + (g_asm_variant > 0 ? "_v" + std::to_string(g_asm_variant) : std::string());
+    std::string n = std::string(family == 2 ? "psam_gemm_asm2_" : "psam_gemm_asm_") + names[i] +
+                    (g_asm_variant > 0 ? "_v" + std::to_string(g_asm_variant) : std::string());
     if (hipModuleGetFunction(&f[i], g_asm_mod, n.c_str()) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   }
-  return (g_asm_fns[g_asm_variant] = f).data();
+  return (g_asm_fns[key] = f).data();
 }
 struct AsmTable { int grid; int* dev; };
 static std::map<unsigned long long, AsmTable> g_asm_tabs;
 // work list of workgroup b: entry i at tab[i * G + b] = tm | tn << 16, terminated (and padded two rows deep) by -1
-static const AsmTable* asm_table(int ntm, int ntn, int mode) {
+// halves > 0 (tile 16): every 256x256 tile of the map becomes its 256x128 halves (tm, 2 tn), (tm, 2 tn + 1) back to back - they share
+// the A panel - and `halves` is the number of 128-column blocks of the matrix (the last tile column may have one)
+static const AsmTable* asm_table(int ntm, int ntn, int mode, int halves = 0) {
   int dev = 0;
   (void)hipGetDevice(&dev);
-  const unsigned long long key = ((unsigned long long)ntm << 40) | ((unsigned long long)ntn << 16) | ((unsigned long long)mode << 8) | (unsigned)dev;
+  const unsigned long long key = ((unsigned long long)ntm << 40) | ((unsigned long long)ntn << 20) | ((unsigned long long)(halves ? 1 : 0) << 19) |
+                                 ((unsigned long long)(halves & 1) << 18) | ((unsigned long long)mode << 8) | (unsigned)dev;
   auto it = g_asm_tabs.find(key);
   if (it != g_asm_tabs.end()) return &it->second;
   const int total = tile_map_grid(ntm, ntn, mode);
@@ -2473,7 +2479,10 @@ static const AsmTable* asm_table(int ntm, int ntn, int mode) {
   for (int b = 0; b < G; ++b)
     for (int idx = b; idx < total; idx += G) {
       int tm = 0, tn = 0;
-      if (tile_map(idx, ntm, ntn, mode, tm, tn)) lists[b].push_back(tm | (tn << 16));
+      if (!tile_map(idx, ntm, ntn, mode, tm, tn)) continue;
+      if (!halves) { lists[b].push_back(tm | (tn << 16)); continue; }
+      lists[b].push_back(tm | ((2 * tn) << 16));
+      if (2 * tn + 1 < halves) lists[b].push_back(tm | ((2 * tn + 1) << 16));
     }
   size_t rows = 0;
   for (auto& l : lists) rows = l.size() > rows ? l.size() : rows;
@@ -2504,11 +2513,22 @@ static bool asm_eligible(const GemmArgs& p, int epilogue, bool lnf) {
   }
   return true;
 }
-static int launch_asm(const GemmArgs& p, int epilogue, hipStream_t s) {
-  const hipFunction_t* fns = asm_load();
+// tile 16 (half-tile ping-pong, epilogue hidden under the next half-tile): same operand rules, N in blocks of 128, and the K loop
+// must be long enough to carry the previous half-tile's epilogue (E + 1 K-tiles)
+static bool asm2_eligible(const GemmArgs& p, int epilogue, bool lnf) {
+  if (epilogue > EPI_F32 || (p.N % 128)) return false;
+  GemmArgs q = p;
+  q.N = 256;   // (the 256-column rule of the first family does not apply)
+  if (!asm_eligible(q, epilogue, lnf)) return false;
+  if ((unsigned long long)p.N * p.ldw * 2 > 0xffffffffull) return false;
+  const int e = epilogue == EPI_F16 ? PSAM_ASM2_E_F16 : epilogue == EPI_GELU_F16 ? PSAM_ASM2_E_GELU : PSAM_ASM2_E_F32;
+  return p.K / 64 >= e + 1 && p.K / 64 >= 3;
+}
+static int launch_asm(const GemmArgs& p, int epilogue, hipStream_t s, int family = 1) {
+  const hipFunction_t* fns = asm_load(family);
   if (!fns) return PSAM_ERR_LAUNCH;
-  const int ntm = (p.M + 255) / 256, ntn = p.N / 256;
-  const AsmTable* t = asm_table(ntm, ntn, pick_map_mode(ntm, ntn));
+  const int ntm = (p.M + 255) / 256, ntn = family == 2 ? (p.N + 255) / 256 : p.N / 256;
+  const AsmTable* t = asm_table(ntm, ntn, pick_map_mode(ntm, ntn), family == 2 ? p.N / 128 : 0);
   if (!t) return PSAM_ERR_LAUNCH;
   AsmGemmArgs a;
   a.A = p.A; a.W = p.W; a.bias = p.bias; a.out = p.out; a.resid = p.resid; a.gamma = p.gamma; a.tab = t->dev;
@@ -2636,6 +2656,7 @@ static int gemm_dispatch(const void* A, const void* W, const float* bias, void* 
   // the slab epilogues store fp16 rows with 16-byte instructions when the layout allows (tiles 7 / 8 / 10 / 11 / 15 require it)
   p.wide16 = (ldo % 8) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (!head_hd || head_hd % 8 == 0);
   // the assembly kernels (tile 15) take plain row-major operands; everything else they were picked for goes to the persistent HIP kernel
+  if (tsel == 16 && !asm2_eligible(p, epilogue, ln_prod || ln_cons)) tsel = 15;
   if (tsel == 15 && !asm_eligible(p, epilogue, ln_prod || ln_cons)) tsel = (N % 256 == 0) ? 11 : 1;
   if (head_hd && tsel != 1 && tsel != 7 && tsel != 8 && tsel != 10 && tsel != 11 && tsel != 13 && tsel != 14) tsel = 1;   // the head-major store lives in the staged epilogue  // the ReLU epilogue lives in the 128x128 kernel
   if ((tsel == 7 || tsel == 8 || tsel == 10 || tsel == 11 || tsel == 13 || tsel == 14) && epilogue != EPI_F32 && !p.wide16) tsel = 1;
@@ -2644,6 +2665,7 @@ static int gemm_dispatch(const void* A, const void* W, const float* bias, void* 
     if (ln_cons && !p.wide16) return PSAM_ERR_ARG;
   }
   if (tsel == 15) return launch_asm(p, epilogue, s);
+  if (tsel == 16) return launch_asm(p, epilogue, s, 2);
   if ((tsel == 3 || tsel == 5) && N % 256 == 0) {
     if (tsel == 3) {
       if (epilogue == EPI_F16) launch256<EPI_F16, 256, 1>(p, s);

@@ -8,6 +8,7 @@ from protosam_amd import ops
 dev = torch.device("cuda:0")
 mode = sys.argv[1] if len(sys.argv) > 1 else "quick"
 bench = "bench" in sys.argv[2:]
+TILE = 16 if "t16" in sys.argv[2:] else 15
 
 
 def run(tile, a, w, bias, epi, resid, gamma):
@@ -34,6 +35,10 @@ def timeit(fn, n=6, w=2):
 cases = [(256, 256, 128), (256, 256, 192), (512, 512, 256), (300, 256, 640), (1297, 768, 768), (4096, 1280, 1280)]
 if mode == "full":
     cases += [(20000, 1536, 128), (33000, 2304, 192), (4096, 5120, 1280), (4096, 1280, 5120), (70001, 768, 128), (65536, 1280, 1280)]
+if TILE == 16:
+    cases = [(256, 128, 1280), (256, 256, 1280), (512, 384, 1280), (300, 256, 1344), (1297, 768, 768), (4096, 1280, 1280)]
+    if mode == "full":
+        cases += [(20000, 1536, 1152), (4096, 5120, 1280), (4096, 1280, 5120), (70001, 640, 1088), (65536, 1280, 1280)]
 bad = 0
 for (M, N, K) in cases:
     g = torch.Generator().manual_seed(M + N + K)
@@ -47,7 +52,7 @@ for (M, N, K) in cases:
         for (b_, r_, g_) in variants:
             ref_tile = 11 if (K >= 768 and N % 256 == 0) else 1
             o_ref = run(ref_tile, a, w, b_, epi, r_, g_)
-            o_asm = run(15, a, w, b_, epi, r_, g_)
+            o_asm = run(TILE, a, w, b_, epi, r_, g_)
             torch.cuda.synchronize()
             same = torch.equal(o_ref, o_asm)
             d = (o_ref.float() - o_asm.float()).abs().max().item()
@@ -69,7 +74,7 @@ if bench:
             out.normal_()
         res = []
         for rep in range(2):
-            for tl in (11, 15):
+            for tl in (11, 15, 16):
                 ops.gemm_set_tile(tl)
                 if epi == 2:
                     t = timeit(lambda: ops.gemm(a, w, bias, out=out, epilogue=ops.EPI_F32, resid=out))
