@@ -33,7 +33,7 @@ for sh in shapes.split(";"):
     for rep in range(2):
         ops.gemm_set_tile(11)
         res.append(f"t11={2*M*N*K/timeit(fn)/1e12:5.0f}")
-        ops.gemm_set_tile(15)
+        ops.gemm_set_tile(int(os.environ.get('TILE', '15')))
         for v in variants:
             ops.gemm_asm_variant(v)
             os.environ["PSAM_TRACE_QUIET"] = "1"

@@ -59,7 +59,8 @@ for (M, N, K) in cases:
             nan = int(torch.isnan(o_asm.float()).sum().item())
             print(f"{M}x{N}x{K} epi{epi} bias={b_ is not None} resid={r_ is not None} gamma={g_ is not None}: "
                   f"bit-identical={same} maxdiff={d:.3e} nan={nan}", flush=True)
-            if not same and d > (2e-3 if epi < 2 else 2e-4):
+            tol = (2e-3 if epi < 2 else 2e-4) * (4 if TILE == 16 else 1) * max(1.0, o_ref.float().abs().max().item() / 8)
+            if not same and d > tol:
                 bad += 1
 print("FAILED cases:", bad, flush=True)
 
