@@ -51,9 +51,9 @@ int psam_gemm_f16_ln(const void* A, const void* W, const float* bias, void* out,
 int psam_ln_finalize(const float* stats, int M, int D, float eps, float* mr, void* stream);
 
 
-/* Tile override for psam_gemm_f16: 0 auto (default; also env PSAM_GEMM_TILE), 1 = 128x128x64 double-buffered,
- * 2 = 256x128x32 / 3 = 256x256x32 (two staggered wave groups) and 5 = 256x256x32 (plain) with a 4-deep direct-to-LDS
- * DMA ring. */
+/* Tile override for psam_gemm_f16: 0 auto (default; also env PSAM_GEMM_TILE), 1 = 128x128x64 (HIP), 11 = 256x256x64 persistent
+ * 8-wave kernel (HIP), 15 = assembly kernels (csrc/gemm_asm_gen.py, the default large tile), 16 = half-tile ping-pong assembly
+ * kernels (csrc/gemm_asm2_gen.py, experimental); a tile that cannot take the call's layout falls back (16 -> 15 -> 11 -> 1). */
 int psam_gemm_set_tile(int tile);
 /* Schedule variant of the assembly GEMM (tile 15): 0 = the shipped kernels; n > 0 selects the numbered experiment kernels of a
  * library built with `make GENFLAGS=--experiments` (csrc/gemm_asm_gen.py; a missing variant makes the next GEMM return an error). */

@@ -579,300 +579,9 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs p) {
     store_slab_staged<EPI, false, LNF>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], slab, m0 + wm * 64, n0 + wn * 64, lane, p);
 }
 
-// =====================================================================================================
-// Large-tile variant: 256 x BN x 32 k-steps, 512 threads = 8 waves (2 x 4), wave tile 128 x BN/4, 4-deep LDS ring
-// (4 x 32 KiB for BN = 256) filled by direct-to-LDS DMA three k-steps ahead. The load path (L2 -> LDS, ~20 B/clk/CU)
-// is what bounds a 128x128 tile (64 FLOP/B); the 256x256 tile halves the bytes per FLOP. One raw s_barrier per
-// k-step; the DMA queue is never drained inside the loop: `s_waitcnt vmcnt(2*LPT)` only retires the k-step about to
-// be read and leaves the next two in flight across the barrier.
-//   iteration t:  wait(tile t landed, own pieces) -> barrier (everyone's pieces landed; everyone finished reading
-//                 tile t-1) -> issue DMA of tile t+3 into the slot of tile t-1 -> MFMAs on tile t.
-template <int BN_>
-struct G256 {
-  static constexpr int BM_ = 256, BK_ = 32, NST = 4;
-  static constexpr int WN = BN_ / 4;        // wave tile width
-  static constexpr int NJ = WN / 32;        // 32-wide MFMA tiles per wave along N
-  static constexpr int A_EL = BM_ * BK_;    // halfs per stage (A)
-  static constexpr int B_EL = BN_ * BK_;
-  static constexpr int ST_EL = A_EL + B_EL;
-  static constexpr int PA = 2;              // 1-KiB A pieces per wave per stage (16 pieces / 8 waves)
-  static constexpr int PB = BN_ / 128;      // 1-KiB B pieces per wave per stage
-  static constexpr int LPT = PA + PB;       // DMA instructions per thread per stage
-  static constexpr int LDS_BYTES = NST * ST_EL * 2;
-};
-
-__device__ __forceinline__ int lds_off32(int row, int chunk) {
-  // [rows][32] fp16 tile (64-byte rows, 4 rows per 256-byte bank row): slot ^= (row>>2)&3 is conflict-free for the
-  // 16-lane groups of ds_read_b128
-  return row * 32 + ((chunk ^ ((row >> 2) & 3)) << 3);
-}
-
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-template <int EPI, int BN_, int STAG>
-__global__ __launch_bounds__(512) void gemm256_f16_kernel(GemmArgs p) {
-  using C = G256<BN_>;
-  extern __shared__ __attribute__((aligned(16))) half_t ring[];  // the ONLY LDS object of this kernel
-
-  const int ntn = p.N / BN_;
-  const int ntm = (p.M + C::BM_ - 1) / C::BM_;
-  int tm, tn;
-  if (!tile_map(blockIdx.x, ntm, ntn, p.map_mode, tm, tn)) return;
-  const int m0 = tm * C::BM_;
-  const int n0 = tn * BN_;
-
-  const int t = threadIdx.x;
-  const int lane = t & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wv >> 2, wn = wv & 3;
-  const int lr = lane & 31, lg = lane >> 5;
-
-  // DMA source pointers: piece q = 16 tile rows; lane -> (row = q*16 + lane/4, slot = lane%4), chunk = slot ^ ((row>>2)&3)
-  const half_t* ag[C::PA];
-  const half_t* wg[C::PB];
-#pragma unroll
-  for (int j = 0; j < C::PA; ++j) {
-    const int row = (wv * C::PA + j) * 16 + (lane >> 2);
-    const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-    int am = m0 + row;
-    am = am < p.M ? am : p.M - 1;
-    ag[j] = p.A + (size_t)am * p.lda + chunk * 8;
-  }
-#pragma unroll
-  for (int j = 0; j < C::PB; ++j) {
-    const int row = (wv * C::PB + j) * 16 + (lane >> 2);
-    const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-    wg[j] = p.W + (size_t)(n0 + row) * p.ldw + chunk * 8;
-  }
-
-  auto stage = [&](int kt) {
-    half_t* base = ring + (kt & (C::NST - 1)) * C::ST_EL;
-#pragma unroll
-    for (int j = 0; j < C::PA; ++j) glds16(ag[j] + kt * C::BK_, base + (wv * C::PA + j) * 512);
-#pragma unroll
-    for (int j = 0; j < C::PB; ++j) glds16(wg[j] + kt * C::BK_, base + C::A_EL + (wv * C::PB + j) * 512);
-  };
-
-  f32x16 acc[4][C::NJ];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < C::NJ; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // residual rows of the first epilogue pass, fetched before any DMA is queued (they are the OLDEST entries of the
-  // in-order vmcnt queue, so the counted waits below are unchanged)
-  float4 rpre[16];
-  const bool has_res = (EPI == EPI_F32) && (C::NJ == 2) && p.resid != nullptr;
-  if (EPI == EPI_F32 && C::NJ == 2 && has_res) prefetch_resid(p, m0 + wm * 128, n0 + wn * 64, lane, rpre);
-  const int nk = p.K / C::BK_;
-  if (STAG == 0) {
-    // plain ring: one barrier per k-step, DMA of k-step t+3 issued right after it, fragments read and consumed in place
-    stage(0);
-    if (nk > 1) stage(1);
-    if (nk > 2) stage(2);
-    for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 2 < nk)
-        wait_vmcnt<2 * C::LPT>();
-      else if (kt + 1 < nk)
-        wait_vmcnt<C::LPT>();
-      else
-        wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      if (kt + 3 < nk) stage(kt + 3);
-      const half_t* sa = ring + (kt & (C::NST - 1)) * C::ST_EL;
-      const half_t* sw = sa + C::A_EL;
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        half8_t fa[4], fb[C::NJ];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          fa[i] = *reinterpret_cast<const half8_t*>(&sa[lds_off32(wm * 128 + i * 32 + lr, s * 2 + lg)]);
-#pragma unroll
-        for (int j = 0; j < C::NJ; ++j)
-          fb[j] = *reinterpret_cast<const half8_t*>(&sw[lds_off32(wn * C::WN + j * 32 + lr, s * 2 + lg)]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < C::NJ; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);  // D^T
-      }
-    }
-  } else {
-  // Two wave groups (waves 0-3 / 4-7: one wave of each per SIMD) run the same phase sequence one barrier apart, so
-  // while one group is in its MFMA phase the other issues DMA and reads fragments:
-  //   L_s: issue DMA of k-step s+3 (into the slot of k-step s-1), read the 12 fragments of k-step s into registers,
-  //        wait until this wave's pieces of k-step s+1 have landed (two k-steps stay in flight), lgkmcnt(0), barrier
-  //   M_s: 16 MFMAs, barrier
-  // Slot reuse is safe: k-step s-1 was last read in L_{s-1} (lagging group: one phase before the leading group's L_s)
-  // and those reads were retired by the lgkmcnt(0) before that phase's closing barrier. A k-step is read only after a
-  // barrier that every wave passed after waiting for its own pieces of it.
-  stage(0);
-  if (nk > 1) stage(1);
-  if (nk > 2) stage(2);
-  if (nk > 2)
-    wait_vmcnt<2 * C::LPT>();
-  else if (nk > 1)
-    wait_vmcnt<C::LPT>();
-  else
-    wait_vmcnt<0>();
-  __builtin_amdgcn_s_barrier();
-  if (wm == 1) __builtin_amdgcn_s_barrier();  // stagger the second group by one phase
-  asm volatile("" ::: "memory");
-
-  for (int kt = 0; kt < nk; ++kt) {
-    // ---- L phase -------------------------------------------------------------------------------------------------
-    if (kt + 3 < nk) stage(kt + 3);
-    const half_t* sa = ring + (kt & (C::NST - 1)) * C::ST_EL;
-    const half_t* sw = sa + C::A_EL;
-    half8_t fa[2][4], fb[2][C::NJ];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        fa[s][i] = *reinterpret_cast<const half8_t*>(&sa[lds_off32(wm * 128 + i * 32 + lr, s * 2 + lg)]);
-#pragma unroll
-      for (int j = 0; j < C::NJ; ++j)
-        fb[s][j] = *reinterpret_cast<const half8_t*>(&sw[lds_off32(wn * C::WN + j * 32 + lr, s * 2 + lg)]);
-    }
-    if (kt + 3 < nk)
-      wait_vmcnt<2 * C::LPT>();
-    else if (kt + 2 < nk)
-      wait_vmcnt<C::LPT>();
-    else
-      wait_vmcnt<0>();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- M phase -------------------------------------------------------------------------------------------------
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < C::NJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[s][j], fa[s][i], acc[i][j], 0, 0, 0);  // D^T
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-  }
-  if (wm == 0) __builtin_amdgcn_s_barrier();  // balance the stagger
-
-  }
-
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < C::NJ; ++j)
-      store_acc32<EPI>(acc[i][j], m0 + wm * 128 + i * 32 + lr, n0 + wn * C::WN + j * 32 + 4 * lg, p);
-}
-
-// =====================================================================================================
-// Wave-specialised variant: 384 x 128 x 32 k-steps, 512 threads = 6 consumer waves (3 x 2, wave tile 128 x 64) + 2 loader
-// waves that issue ALL direct-to-LDS DMA (16 one-KiB pieces each per k-step) and never touch the matrix pipe. A wave
-// stalled at VMEM issue cannot issue its MFMAs (in-order issue); with every wave both loading and computing, DMA time
-// and MFMA time add up (measured: 195 + 164 us ~ 365 us on 32768x3840x1280), with dedicated loaders they overlap.
-// Same 4-deep ring and barrier protocol as the plain ring kernel: loader waits for its pieces of k-step t, everyone
-// meets at the barrier, loader then refills the slot of k-step t-1 with k-step t+3 while the consumers work on t.
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_ws_f16_kernel(GemmArgs p) {
-  constexpr int BMW = 384, BNW = 128, BKW = 32, NST = 4;
-  constexpr int A_EL = BMW * BKW, B_EL = BNW * BKW, ST_EL = A_EL + B_EL;  // 16384 halfs = 32 KiB per stage
-  constexpr int NPIECE = (BMW + BNW) / 16;                              // 32 one-KiB pieces per stage
-  constexpr int LP = NPIECE / 2;                                        // per loader wave
-  extern __shared__ __attribute__((aligned(16))) half_t ring[];
-
-  const int ntn = p.N / BNW;
-  const int ntm = (p.M + BMW - 1) / BMW;
-  int tm, tn;
-  if (!tile_map(blockIdx.x, ntm, ntn, p.map_mode, tm, tn)) return;
-  const int m0 = tm * BMW, n0 = tn * BNW;
-  const int t = threadIdx.x, lane = t & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int nk = p.K / BKW;
-
-  if (wv >= 6) {
-    // ---------------- loader wave ----------------
-    const int ld = wv - 6;
-    const half_t* src[LP];
-#pragma unroll
-    for (int j = 0; j < LP; ++j) {
-      const int piece = ld * LP + j;                 // 0..23: A rows, 24..31: W rows
-      const int row = piece * 16 + (lane >> 2);      // row inside the stacked [A | W] stage image
-      const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-      if (piece < BMW / 16) {
-        int am = m0 + row;
-        am = am < p.M ? am : p.M - 1;
-        src[j] = p.A + (size_t)am * p.lda + chunk * 8;
-      } else {
-        src[j] = p.W + (size_t)(n0 + row - BMW) * p.ldw + chunk * 8;
-      }
-    }
-    auto stage = [&](int kt) {
-      half_t* base = ring + (kt & (NST - 1)) * ST_EL + (ld * LP) * 512;
-#pragma unroll
-      for (int j = 0; j < LP; ++j) glds16(src[j] + kt * BKW, base + j * 512);
-    };
-    stage(0);
-    if (nk > 1) stage(1);
-    if (nk > 2) stage(2);
-    for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 2 < nk)
-        wait_vmcnt<2 * LP>();
-      else if (kt + 1 < nk)
-        wait_vmcnt<LP>();
-      else
-        wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      if (kt + 3 < nk) stage(kt + 3);
-    }
-    return;
-  }
-
-  // ---------------- consumer wave ----------------
-  const int wm = wv >> 1, wn = wv & 1;
-  const int lr = lane & 31, lg = lane >> 5;
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  for (int kt = 0; kt < nk; ++kt) {
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    const half_t* sa = ring + (kt & (NST - 1)) * ST_EL;
-    const half_t* sw = sa + A_EL;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      half8_t fa[4], fb[2];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        fa[i] = *reinterpret_cast<const half8_t*>(&sa[lds_off32(wm * 128 + i * 32 + lr, s * 2 + lg)]);
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        fb[j] = *reinterpret_cast<const half8_t*>(&sw[lds_off32(wn * 64 + j * 32 + lr, s * 2 + lg)]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);  // D^T
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      store_acc32<EPI>(acc[i][j], m0 + wm * 128 + i * 32 + lr, n0 + wn * 64 + j * 32 + 4 * lg, p);
 }
 
 
@@ -897,708 +606,8 @@ __device__ __forceinline__ int lds_off64(int row, int chunk) {
   return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3);
 }
 
-template <int EPI, bool DBG = false>
-__global__ __launch_bounds__(512) void gemm8p_f16_kernel(GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) half_t ring[];  // [buf 2][A0 A1 B0 B1][128][64]
-  constexpr int HT = 128 * 64;                                     // halfs per half-tile
-  const int ntn = p.N / 256;
-  const int ntm = (p.M + 255) / 256;
-  int tm, tn;
-  if (!tile_map(blockIdx.x, ntm, ntn, p.map_mode, tm, tn)) return;
-  const int m0 = tm * 256, n0 = tn * 256;
-  const int t = threadIdx.x, lane = t & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wr = wv >> 2, wc = wv & 3;
-  const int lr = lane & 31, lg = lane >> 5;
-
-  // DMA sources. Instruction j of a half-tile covers local rows j*64 + t/8 (8 lanes = one 128-byte row), slot t%8.
-  const half_t* asrc[2];  // half 0; half 1 = + 64 rows
-  const half_t* bsrc[2];  // half 0; half 1 = + 32 rows
-  int a_clamp[2][2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int lrow = j * 64 + (t >> 3);
-    const int chunk = (t & 7) ^ ((lrow >> 1) & 7);
-    const int arow = (lrow >> 6) * 128 + (lrow & 63);       // + h*64
-    const int brow = (lrow >> 5) * 64 + (lrow & 31);        // + h*32
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      int am = m0 + arow + h * 64;
-      a_clamp[j][h] = (am < p.M ? am : p.M - 1) - (m0 + arow);   // row delta actually fetched (ragged last tile)
-    }
-    asrc[j] = p.A + (size_t)(m0 + arow) * p.lda + chunk * 8;
-    bsrc[j] = p.W + (size_t)(n0 + brow) * p.ldw + chunk * 8;
-  }
-  // stage half-tile `which` (0 A0, 1 A1, 2 B0, 3 B1) of K-tile kt
-  const int dbg = DBG ? p.dbg : 0;  // 1: no DMA in the loop, 2: no fragment reads, 4: no MFMA, 8: no epilogue, 16: no barriers
-  auto stage = [&](int which, int kt) {
-    if (DBG && (dbg & 1) && kt > 1) return;
-    half_t* dst = ring + ((kt & 1) * 4 + which) * HT + wv * 512;
-    const int h = which & 1;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const half_t* g = which < 2 ? asrc[j] + (ptrdiff_t)a_clamp[j][h] * p.lda : bsrc[j] + (size_t)h * 32 * p.ldw;
-      glds16(g + kt * 64, dst + j * 4096);
-    }
-  };
-
-  f32x16 acc[2][2][2];  // [a][i][b]: rows m0 + wr*128 + a*64 + i*32 + lr, cols n0 + wc*64 + b*32 + ...
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][i][b][r] = 0.f;
-
-  const int nk = p.K / 64;
-  // prologue: A0 B0 B1 A1 of K-tile 0, A0 B0 of K-tile 1 (the steady schedule's phases 3/4 of "K-tile -1")
-  stage(0, 0); stage(2, 0); stage(3, 0); stage(1, 0);
-  if (nk > 1) { stage(0, 1); stage(2, 1); wait_vmcnt<8>(); } else { wait_vmcnt<4>(); }
-  __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger the second wave row by one barrier
-  asm volatile("" ::: "memory");
-
-  half8_t fa[2][4], fb0[4], fb1[4];
-  const int arow0 = wr * 64 + lr, brow0 = wc * 32 + lr;
-
-#define PHASE_SYNC_IN()                                   \
-  if (!(DBG && (dbg & 16))) __builtin_amdgcn_s_barrier(); \
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
-  __builtin_amdgcn_sched_barrier(0);                      \
-  __builtin_amdgcn_s_setprio(1);
-#define PHASE_SYNC_OUT()                                  \
-  __builtin_amdgcn_s_setprio(0);                          \
-  __builtin_amdgcn_sched_barrier(0);                      \
-  if (!(DBG && (dbg & 16))) __builtin_amdgcn_s_barrier(); \
-  asm volatile("" ::: "memory");
-#define RD(dst, off) if (!(DBG && (dbg & 2))) dst = *reinterpret_cast<const half8_t*>(&buf[off])
-#define MMA(c, a_, b_) if (!(DBG && (dbg & 4))) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, c, 0, 0, 0)
-
-  if (DBG) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) fa[i][s2] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2) fb0[s2] = fb1[s2] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
-  }
-  for (int kt = 0; kt < nk; ++kt) {
-    const half_t* buf = ring + (kt & 1) * 4 * HT;
-    const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
-    // ---- phase 1: read B0, A0; stage B1(kt+1); quadrant (A0, B0) -------------------------------------------------
-#pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2)
-      RD(fb0[s2], 2 * HT + lds_off64(brow0, s2 * 2 + lg));
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2)
-        RD(fa[i][s2], 0 * HT + lds_off64(arow0 + i * 32, s2 * 2 + lg));
-    if (more1) stage(3, kt + 1);
-    if (more2) wait_vmcnt<8>(); else wait_vmcnt<0>();
-    PHASE_SYNC_IN();
-#pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        MMA(acc[0][i][0], fb0[s2], fa[i][s2]);
-    PHASE_SYNC_OUT();
-    // ---- phase 2: read B1; stage A1(kt+1); quadrant (A0, B1) -----------------------------------------------------
-#pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2)
-      RD(fb1[s2], 3 * HT + lds_off64(brow0, s2 * 2 + lg));
-    if (more1) stage(1, kt + 1);
-    if (more2) wait_vmcnt<8>(); else wait_vmcnt<0>();
-    PHASE_SYNC_IN();
-#pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        MMA(acc[0][i][1], fb1[s2], fa[i][s2]);
-    PHASE_SYNC_OUT();
-    // ---- phase 3: read A1; stage A0(kt+2); quadrant (A1, B1) -----------------------------------------------------
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2)
-        RD(fa[i][s2], 1 * HT + lds_off64(arow0 + i * 32, s2 * 2 + lg));
-    if (more2) { stage(0, kt + 2); wait_vmcnt<8>(); } else { wait_vmcnt<0>(); }
-    PHASE_SYNC_IN();
-#pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        MMA(acc[1][i][1], fb1[s2], fa[i][s2]);
-    PHASE_SYNC_OUT();
-    // ---- phase 4: no reads; stage B0(kt+2); quadrant (A1, B0) ----------------------------------------------------
-    if (more2) { stage(2, kt + 2); wait_vmcnt<8>(); } else { wait_vmcnt<0>(); }
-    PHASE_SYNC_IN();
-#pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        MMA(acc[1][i][0], fb0[s2], fa[i][s2]);
-    PHASE_SYNC_OUT();
-  }
-#undef PHASE_SYNC_IN
-#undef PHASE_SYNC_OUT
-#undef RD
-#undef MMA
-  if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the stagger
-  if (DBG && (dbg & 8)) return;
-
-  // epilogue: every wave parks its two 64x64 slabs, one after the other, in its own 16 KiB of the (idle, fully landed,
-  // no longer read) ring and re-reads them row-contiguously: each store instruction covers 4 rows x 128/256 bytes
-  float* slab = reinterpret_cast<float*>(ring) + wv * 4096;
-  store_wave_tile_128x64<EPI>(acc, slab, m0 + wr * 128, n0 + wc * 64, lane, p);
-}
-
-template <int EPI, bool DBG = false>
-static void launch8p(const GemmArgs& p, hipStream_t s) {
-  constexpr int LDS = 2 * 4 * 128 * 64 * 2;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm8p_f16_kernel<EPI, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr = true;
-  }
-  const int ntm = (p.M + 255) / 256, ntn = p.N / 256;
-  hipLaunchKernelGGL((gemm8p_f16_kernel<EPI, DBG>), dim3(tile_map_grid(ntm, ntn, p.map_mode)), dim3(512), LDS, s, p);
-}
 
 
-// =====================================================================================================
-// Tile 8: the 8-phase kernel's geometry, half-tile DMA schedule and LDS image, with ONE barrier per phase instead of
-// two. The two wave rows run the same phase in the same barrier interval but in opposite order: row 0 opens the
-// interval with the phase's MFMAs (its fragments were read in the previous interval) and then reads the NEXT phase's
-// fragments; row 1 reads the phase's fragments first and then issues its MFMAs. On every SIMD one wave therefore starts
-// on the matrix pipe while the other starts on LDS, and they swap without a rendezvous. An empty barrier interval costs
-// ~270 cycles on this chip (measured: tile 7 with everything but the barriers removed), more than the 256 cycles of a
-// phase's MFMAs, so halving the barrier count matters more than any instruction placement inside a phase.
-// Row 0 reads a half-tile one interval before row 1, so the counted wait moves one phase earlier: vmcnt(6) (three
-// half-tiles in flight). Refill distance (>= 2 phases after the last read of either row) is unchanged.
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm8h_f16_kernel(GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) half_t ring[];  // [buf 2][A0 A1 B0 B1][128][64]
-  constexpr int HT = 128 * 64;
-  const int ntn = p.N / 256;
-  const int ntm = (p.M + 255) / 256;
-  int tm, tn;
-  if (!tile_map(blockIdx.x, ntm, ntn, p.map_mode, tm, tn)) return;
-  const int m0 = tm * 256, n0 = tn * 256;
-  const int t = threadIdx.x, lane = t & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wr = wv >> 2, wc = wv & 3;
-  const int lr = lane & 31, lg = lane >> 5;
-
-  // DMA sources as 32-bit element offsets from the (wave-uniform) operand bases: instruction j of a half-tile covers
-  // local rows j*64 + t/8 (8 lanes = one 128-byte row), LDS slot t%8 <- source chunk slot ^ ((row>>1)&7)
-  unsigned aoff[2][2], boff[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int lrow = j * 64 + (t >> 3);
-    const int chunk = (t & 7) ^ ((lrow >> 1) & 7);
-    const int arow = (lrow >> 6) * 128 + (lrow & 63);       // + h*64
-    const int brow = (lrow >> 5) * 64 + (lrow & 31);        // + h*32
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      int am = m0 + arow + h * 64;
-      am = am < p.M ? am : p.M - 1;                          // ragged last row tile: re-read the last row
-      aoff[j][h] = (unsigned)am * (unsigned)p.lda + chunk * 8;
-    }
-    boff[j] = (unsigned)(n0 + brow) * (unsigned)p.ldw + chunk * 8;
-  }
-  const unsigned bh = 32u * (unsigned)p.ldw;
-  auto stage = [&](int which, int kt) {  // 0 A0, 1 A1, 2 B0, 3 B1
-    half_t* dst = ring + ((kt & 1) * 4 + which) * HT + wv * 512;
-    const int h = which & 1;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const half_t* g = which < 2 ? p.A + (aoff[j][h] + (unsigned)kt * 64u) : p.W + (boff[j] + h * bh + (unsigned)kt * 64u);
-      glds16(g, dst + j * 4096);
-    }
-  };
-
-  f32x16 acc[2][2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][i][b][r] = 0.f;
-
-  half8_t fa[2][4], fb0[4], fb1[4];
-  const int arow0 = wr * 64 + lr, brow0 = wc * 32 + lr;
-  const int nk = p.K / 64;
-
-#define RD_A(bufp, h)                                                                                             \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int s2 = 0; s2 < 4; ++s2)                   \
-      fa[i][s2] = *reinterpret_cast<const half8_t*>(&(bufp)[(h) * HT + lds_off64(arow0 + i * 32, s2 * 2 + lg)]);
-#define RD_B(dst, bufp, h)                                                                                        \
-  _Pragma("unroll") for (int s2 = 0; s2 < 4; ++s2)                                                                 \
-      dst[s2] = *reinterpret_cast<const half8_t*>(&(bufp)[(2 + (h)) * HT + lds_off64(brow0, s2 * 2 + lg)]);
-#define MMA_Q(a, b, fb)                                                                                           \
-  __builtin_amdgcn_s_setprio(1);                                                                                  \
-  _Pragma("unroll") for (int s2 = 0; s2 < 4; ++s2) _Pragma("unroll") for (int i = 0; i < 2; ++i)                   \
-      acc[a][i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[s2], fa[i][s2], acc[a][i][b], 0, 0, 0);           \
-  __builtin_amdgcn_s_setprio(0);
-#define LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0)
-#define END_INTERVAL(more)                                                                                        \
-  if (more) wait_vmcnt<6>(); else wait_vmcnt<0>();                                                                \
-  __builtin_amdgcn_sched_barrier(0);                                                                              \
-  __builtin_amdgcn_s_barrier();                                                                                   \
-  asm volatile("" ::: "memory");                                                                                  \
-  __builtin_amdgcn_sched_barrier(0)
-
-  stage(0, 0); stage(2, 0); stage(3, 0); stage(1, 0);
-  if (nk > 1) { stage(0, 1); stage(2, 1); wait_vmcnt<8>(); } else { wait_vmcnt<4>(); }
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  if (wr == 0) {
-    RD_B(fb0, ring, 0)
-    RD_A(ring, 0)
-  }
-  if (nk > 1) wait_vmcnt<6>(); else wait_vmcnt<2>();
-  __builtin_amdgcn_sched_barrier(0);
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-
-  auto main_loop = [&](auto role_c) {
-  constexpr int ROLE = decltype(role_c)::value;
-  for (int kt = 0; kt < nk; ++kt) {
-    const half_t* buf = ring + (kt & 1) * 4 * HT;
-    const half_t* nbuf = ring + ((kt + 1) & 1) * 4 * HT;
-    const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
-    // ---- phase 1: quadrant (A0, B0); DMA B1(kt+1) ---------------------------------------------------------------
-    if (ROLE == 0) {
-      LGKM0();
-      MMA_Q(0, 0, fb0)
-      __builtin_amdgcn_sched_barrier(0);
-      RD_B(fb1, buf, 1)
-      if (more1) stage(3, kt + 1);
-    } else {
-      RD_B(fb0, buf, 0)
-      RD_A(buf, 0)
-      if (more1) stage(3, kt + 1);
-      LGKM0();
-      MMA_Q(0, 0, fb0)
-    }
-    END_INTERVAL(more2);
-    // ---- phase 2: quadrant (A0, B1); DMA A1(kt+1) ---------------------------------------------------------------
-    if (ROLE == 0) {
-      LGKM0();
-      MMA_Q(0, 1, fb1)
-      __builtin_amdgcn_sched_barrier(0);
-      RD_A(buf, 1)
-      if (more1) stage(1, kt + 1);
-    } else {
-      RD_B(fb1, buf, 1)
-      if (more1) stage(1, kt + 1);
-      LGKM0();
-      MMA_Q(0, 1, fb1)
-    }
-    END_INTERVAL(more2);
-    // ---- phase 3: quadrant (A1, B1); DMA A0(kt+2) ---------------------------------------------------------------
-    if (ROLE == 0) {
-      LGKM0();
-      MMA_Q(1, 1, fb1)
-      __builtin_amdgcn_sched_barrier(0);
-      if (more2) stage(0, kt + 2);
-    } else {
-      RD_A(buf, 1)
-      if (more2) stage(0, kt + 2);
-      LGKM0();
-      MMA_Q(1, 1, fb1)
-    }
-    END_INTERVAL(more2);
-    // ---- phase 4: quadrant (A1, B0); DMA B0(kt+2); row 0 reads (A0, B0) of K-tile kt+1 ---------------------------
-    if (ROLE == 0) {
-      MMA_Q(1, 0, fb0)
-      __builtin_amdgcn_sched_barrier(0);
-      if (more1) {
-        RD_B(fb0, nbuf, 0)
-        RD_A(nbuf, 0)
-      }
-      if (more2) stage(2, kt + 2);
-    } else {
-      if (more2) stage(2, kt + 2);
-      MMA_Q(1, 0, fb0)
-    }
-    END_INTERVAL(more2);
-  }
-  };
-  if (wr == 0) main_loop(std::integral_constant<int, 0>{}); else main_loop(std::integral_constant<int, 1>{});
-#undef RD_A
-#undef RD_B
-#undef MMA_Q
-#undef LGKM0
-#undef END_INTERVAL
-
-  float* slab = reinterpret_cast<float*>(ring) + wv * 4096;
-  store_wave_tile_128x64<EPI>(acc, slab, m0 + wr * 128, n0 + wc * 64, lane, p);
-}
-
-template <int EPI>
-static void launch8h(const GemmArgs& p, hipStream_t s) {
-  constexpr int LDS = 2 * 4 * 128 * 64 * 2;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm8h_f16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr = true;
-  }
-  const int ntm = (p.M + 255) / 256, ntn = p.N / 256;
-  hipLaunchKernelGGL((gemm8h_f16_kernel<EPI>), dim3(tile_map_grid(ntm, ntn, p.map_mode)), dim3(512), LDS, s, p);
-}
-
-
-// =====================================================================================================
-// Tile 9 (experimental): 256 x 256 x 64, FOUR waves (2 x 2), wave tile 128 x 128 = 4 x 4 MFMA 32x32x16 tiles (256
-// accumulator registers, one wave per SIMD), operands staged through REGISTERS (global_load_dwordx4 -> ds_write_b128) into
-// two 64 KiB LDS buffers. Rationale: with one wave per SIMD nothing else can cover an issue stall, so the cheap-to-issue
-// plain loads (the data lands asynchronously) replace the direct-to-LDS DMA (tens of cycles of issue each), and the
-// 128 x 128 wave tile needs a third less LDS read traffic per FLOP than 128 x 64. One barrier per K-tile.
-template <int EPI>
-__global__ __launch_bounds__(256) void gemm4w_f16_kernel(GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) half_t ring[];  // [buf 2][A | B][256][64]
-  constexpr int TE = 256 * 64;                                     // halfs per operand tile
-  const int ntn = p.N / 256;
-  const int ntm = (p.M + 255) / 256;
-  int tm, tn;
-  if (!tile_map(blockIdx.x, ntm, ntn, p.map_mode, tm, tn)) return;
-  const int m0 = tm * 256, n0 = tn * 256;
-  const int t = threadIdx.x, lane = t & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wr = wv >> 1, wc = wv & 1;
-  const int lr = lane & 31, lg = lane >> 5;
-
-  // staging: piece j (0..7) of an operand tile = rows j*32 + t/8, 16-byte slot t%8 of the 128-byte row; the LDS image is
-  // XOR-swizzled on the write (slot ^ ((row>>1)&7)) exactly as the fragment reads expect
-  const int srow = t >> 3, sslot = t & 7;
-  unsigned aoff[8], boff[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    int am = m0 + j * 32 + srow;
-    am = am < p.M ? am : p.M - 1;
-    aoff[j] = (unsigned)am * (unsigned)p.lda + sslot * 8;
-    boff[j] = (unsigned)(n0 + j * 32 + srow) * (unsigned)p.ldw + sslot * 8;
-  }
-  int soff[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) soff[j] = lds_off64(j * 32 + srow, sslot);
-
-  f32x16 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nk = p.K / 64;
-  // The staging loads are inline asm: written as plain C++ loads hipcc either sinks them next to their ds_writes (latency
-  // fully exposed) or, when pinned at the top with a sched_barrier, parks them in scratch. As asm the 16 requests are issued
-  // at the top of the iteration, fly under the 64 MFMAs, and one explicit s_waitcnt ahead of the LDS writes orders them.
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  u32x4 ra[8], rb[8];
-  unsigned abyte[8], bbyte[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { abyte[j] = aoff[j] * 2u; bbyte[j] = boff[j] * 2u; }
-  // The staging loads are inline asm: written as plain C++ loads hipcc either sinks them next to their ds_writes (latency
-  // fully exposed) or, when pinned with a sched_barrier, parks them in scratch. Each request produces a fresh value that is
-  // consumed (s_waitcnt, ds_write) in the SAME iteration: a value in flight across the loop back-edge can be "copied" by a
-  // compiler-inserted v_mov before it has landed (tried: requests re-issued right after the LDS writes = one full iteration
-  // of cover and 3-4 % faster, but wrong results).
-#define G4W_LD(j, kb)                                                                                              \
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(ra[j]) : "v"(abyte[j] + (kb)), "s"(p.A) : "memory");       \
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(rb[j]) : "v"(bbyte[j] + (kb)), "s"(p.W) : "memory");
-#define G4W_WAIT()                                                                                                 \
-  asm volatile("s_waitcnt vmcnt(0)"                                                                                \
-               : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(ra[6]), "+v"(ra[7]),  \
-                 "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(rb[4]), "+v"(rb[5]), "+v"(rb[6]), "+v"(rb[7])   \
-               :: "memory")
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { G4W_LD(j, 0u) }
-  G4W_WAIT();
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    *reinterpret_cast<u32x4*>(ring + soff[j]) = ra[j];
-    *reinterpret_cast<u32x4*>(ring + TE + soff[j]) = rb[j];
-  }
-  __syncthreads();
-  const int arow = wr * 128 + lr, brow = wc * 128 + lr;
-  for (int kt = 0; kt < nk; ++kt) {
-    const half_t* sa = ring + (kt & 1) * 2 * TE;
-    const half_t* sb = sa + TE;
-    half_t* da = ring + ((kt + 1) & 1) * 2 * TE;
-    // next K-tile -> registers (the last iteration re-reads its own tile: no branch around the loads). The 16 requests are
-    // issued in the shadows of k-substep 0's MFMAs, the 16 LDS writes in those of k-substep 3 (by then the data has had
-    // ~1500 cycles to land): with one wave per SIMD an instruction only costs matrix-pipe time if no MFMA follows it soon
-    // enough. Fragments of k-substep s2+1 are requested before the 16 MFMAs of s2 (two register sets).
-    const unsigned kb = (unsigned)(kt + 1 < nk ? kt + 1 : kt) * 128u;
-    half8_t fa[2][4], fb[2][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      fa[0][i] = *reinterpret_cast<const half8_t*>(&sa[lds_off64(arow + i * 32, lg)]);
-      fb[0][i] = *reinterpret_cast<const half8_t*>(&sb[lds_off64(brow + i * 32, lg)]);
-    }
-#pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2) {
-      if (s2 < 3) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          fa[(s2 + 1) & 1][i] = *reinterpret_cast<const half8_t*>(&sa[lds_off64(arow + i * 32, (s2 + 1) * 2 + lg)]);
-          fb[(s2 + 1) & 1][i] = *reinterpret_cast<const half8_t*>(&sb[lds_off64(brow + i * 32, (s2 + 1) * 2 + lg)]);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (s2 == 3) G4W_WAIT();
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (s2 == 0) {
-#pragma unroll
-          for (int j = 2 * i; j < 2 * i + 2; ++j) { G4W_LD(j, kb) }
-        }
-        if (s2 == 3) {
-#pragma unroll
-          for (int j = 2 * i; j < 2 * i + 2; ++j) {
-            *reinterpret_cast<u32x4*>(da + soff[j]) = ra[j];
-            *reinterpret_cast<u32x4*>(da + TE + soff[j]) = rb[j];
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[s2 & 1][j], fa[s2 & 1][i], acc[i][j], 0, 0, 0);  // D^T
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    __syncthreads();
-  }
-#undef G4W_LD
-#undef G4W_WAIT
-
-  float* slab = reinterpret_cast<float*>(ring) + wv * 4096;
-#pragma unroll
-  for (int i = 0; i < 4; i += 2)
-#pragma unroll
-    for (int j = 0; j < 4; j += 2)
-      store_slab_staged<EPI, false>(acc[i][j], acc[i][j + 1], acc[i + 1][j], acc[i + 1][j + 1], slab,
-                                    m0 + wr * 128 + i * 32, n0 + wc * 128 + j * 32, lane, p);
-}
-
-template <int EPI>
-static void launch4w(const GemmArgs& p, hipStream_t s) {
-  constexpr int LDS = 2 * 2 * 256 * 64 * 2;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm4w_f16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr = true;
-  }
-  const int ntm = (p.M + 255) / 256, ntn = p.N / 256;
-  hipLaunchKernelGGL((gemm4w_f16_kernel<EPI>), dim3(tile_map_grid(ntm, ntn, p.map_mode)), dim3(256), LDS, s, p);
-}
-
-
-// =====================================================================================================
-// Tile 10: the 8-phase kernel (tile 7: geometry, LDS image, staggered wave rows, two barriers per phase) with the K-tile cut
-// the other way: a phase is one 64-row x 64-column half of the wave tile over HALF the K-tile (2 k-substeps), i.e. 8 MFMAs on
-// FOUR independent accumulators (tile 7: two accumulators x 4 k-substeps, every MFMA depending on the one two slots earlier),
-// and the fragment reads are 8 / 8 / 4 / 4 per phase instead of 12 / 4 / 8 / 0:
-//   phase 1: (A0 k01) x (B0 B1 k01)   phase 2: (A0 k23) x (B0 B1 k23)   phase 3: (A1 k01) x kept B k01   phase 4: (A1 k23) x kept B k23
-// Half-tiles A0, B0, B1 are last read in phase 2, A1 in phase 4; DMA (one half-tile per phase, >= 2 phases after its last
-// read, consumption order):  phase 1(t): B0(t+1)   phase 2(t): B1(t+1)   phase 3(t): A1(t+1)   phase 4(t): A0(t+2)
-// Waits: phase 4 leaves the two newest half-tiles in flight (vmcnt 4: A0 B0 B1 of t+1 have landed for phase 1),
-// phases 1-3 leave three (vmcnt 6: by phase 2 this retires A1(t) for phase 3).
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm8k_f16_kernel(GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) half_t ring[];  // [buf 2][A0 A1 B0 B1][128][64]
-  constexpr int HT = 128 * 64;
-  const int ntn = p.N / 256;
-  const int ntm = (p.M + 255) / 256;
-  int tm, tn;
-  if (!tile_map(blockIdx.x, ntm, ntn, p.map_mode, tm, tn)) return;
-  const int m0 = tm * 256, n0 = tn * 256;
-  const int t = threadIdx.x, lane = t & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wr = wv >> 2, wc = wv & 3;
-  const int lr = lane & 31, lg = lane >> 5;
-  if (p.dbg & 32) return;
-  unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
-  unsigned long long cy0 = 0;
-  if (p.trace) { tr0 = wall_clock64(); cy0 = __builtin_amdgcn_s_memtime(); }
-  if (p.stagger > 0 && blockIdx.x < 256) {
-    const int n = (int)(((blockIdx.x * 167u) & 255u) * (unsigned)p.stagger) >> 8;
-    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(8);
-  }
-
-  unsigned aoff[2][2], boff[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int lrow = j * 64 + (t >> 3);
-    const int chunk = (t & 7) ^ ((lrow >> 1) & 7);
-    const int arow = (lrow >> 6) * 128 + (lrow & 63);
-    const int brow = (lrow >> 5) * 64 + (lrow & 31);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      int am = m0 + arow + h * 64;
-      am = am < p.M ? am : p.M - 1;
-      aoff[j][h] = (unsigned)am * (unsigned)p.lda + chunk * 8;
-    }
-    boff[j] = (unsigned)(n0 + brow) * (unsigned)p.ldw + chunk * 8;
-  }
-  const unsigned bh = 32u * (unsigned)p.ldw;
-  auto stage = [&](int which, int kt) {  // 0 A0, 1 A1, 2 B0, 3 B1
-    half_t* dst = ring + ((kt & 1) * 4 + which) * HT + wv * 512;
-    const int h = which & 1;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const half_t* g = which < 2 ? p.A + (aoff[j][h] + (unsigned)kt * 64u) : p.W + (boff[j] + h * bh + (unsigned)kt * 64u);
-      glds16(g, dst + j * 4096);
-    }
-  };
-
-  f32x16 acc[2][2][2];  // [a][i][b]
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][i][b][r] = 0.f;
-
-  half8_t fa[2][2];      // [i][k within the half]
-  half8_t fb[2][2][2];   // [k half][b][k within the half]: both halves stay resident for phases 3 / 4
-  const int arow0 = wr * 64 + lr, brow0 = wc * 32 + lr;
-  const int nk = p.K / 64;
-
-#define RD_A(bufp, h, kh)                                                                                         \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int k2 = 0; k2 < 2; ++k2)                   \
-      fa[i][k2] = *reinterpret_cast<const half8_t*>(&(bufp)[(h) * HT + lds_off64(arow0 + i * 32, ((kh) * 2 + k2) * 2 + lg)]);
-#define RD_B(bufp, kh)                                                                                            \
-  _Pragma("unroll") for (int b = 0; b < 2; ++b) _Pragma("unroll") for (int k2 = 0; k2 < 2; ++k2)                   \
-      fb[kh][b][k2] = *reinterpret_cast<const half8_t*>(&(bufp)[(2 + b) * HT + lds_off64(brow0, ((kh) * 2 + k2) * 2 + lg)]);
-#define MMA_H(a, kh)                                                                                              \
-  _Pragma("unroll") for (int k2 = 0; k2 < 2; ++k2) _Pragma("unroll") for (int i = 0; i < 2; ++i)                   \
-      _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                               \
-          acc[a][i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[kh][b][k2], fa[i][k2], acc[a][i][b], 0, 0, 0);
-#define PHASE_SYNC_IN()                                   \
-  __builtin_amdgcn_s_barrier();                           \
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
-  __builtin_amdgcn_sched_barrier(0);                      \
-  __builtin_amdgcn_s_setprio(1);
-#define PHASE_SYNC_OUT()                                  \
-  __builtin_amdgcn_s_setprio(0);                          \
-  __builtin_amdgcn_sched_barrier(0);                      \
-  __builtin_amdgcn_s_barrier();                           \
-  asm volatile("" ::: "memory");
-
-  stage(0, 0); stage(2, 0); stage(3, 0); stage(1, 0);
-  if (nk > 1) { stage(0, 1); wait_vmcnt<4>(); } else { wait_vmcnt<2>(); }
-  __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger the second wave row by one barrier
-  asm volatile("" ::: "memory");
-  if (p.trace) tr1 = wall_clock64();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const half_t* buf = ring + (kt & 1) * 4 * HT;
-    const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
-    // ---- phase 1 ---------------------------------------------------------------------------------------------------
-    RD_B(buf, 0)
-    __builtin_amdgcn_sched_barrier(0);
-    RD_A(buf, 0, 0)
-    if (more1) stage(2, kt + 1);
-    if (more1) wait_vmcnt<6>(); else wait_vmcnt<0>();
-    PHASE_SYNC_IN();
-    MMA_H(0, 0)
-    PHASE_SYNC_OUT();
-    // ---- phase 2 ---------------------------------------------------------------------------------------------------
-    RD_B(buf, 1)
-    __builtin_amdgcn_sched_barrier(0);
-    RD_A(buf, 0, 1)
-    if (more1) stage(3, kt + 1);
-    if (more1) wait_vmcnt<6>(); else wait_vmcnt<0>();
-    PHASE_SYNC_IN();
-    MMA_H(0, 1)
-    PHASE_SYNC_OUT();
-    // ---- phase 3 ---------------------------------------------------------------------------------------------------
-    RD_A(buf, 1, 0)
-    if (more1) stage(1, kt + 1);
-    if (more1) wait_vmcnt<6>(); else wait_vmcnt<0>();
-    PHASE_SYNC_IN();
-    MMA_H(1, 0)
-    PHASE_SYNC_OUT();
-    // ---- phase 4 ---------------------------------------------------------------------------------------------------
-    RD_A(buf, 1, 1)
-    if (more2) { stage(0, kt + 2); wait_vmcnt<4>(); } else if (more1) { wait_vmcnt<2>(); } else { wait_vmcnt<0>(); }
-    PHASE_SYNC_IN();
-    MMA_H(1, 1)
-    PHASE_SYNC_OUT();
-  }
-#undef RD_A
-#undef RD_B
-#undef MMA_H
-#undef PHASE_SYNC_IN
-#undef PHASE_SYNC_OUT
-  if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the stagger
-  if (p.trace) tr2 = wall_clock64();
-  if (p.dbg & 8) { if (acc[0][0][0][0] == 123.456f) reinterpret_cast<half_t*>(p.out)[0] = (half_t)acc[1][1][1][3]; return; }
-
-  float* slab = reinterpret_cast<float*>(ring) + wv * 4096;
-  if (p.dbg & 64) {   // LDS part of the epilogue only
-    float sum = 0.f;
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      slab_park(acc[a][0][0], acc[a][0][1], acc[a][1][0], acc[a][1][1], slab, lane);
-#pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const int row = it * 4 + (lane >> 4);
-        float4 v = *reinterpret_cast<const float4*>(&slab[row * 64 + (((lane & 15) ^ (row & 15)) << 2)]);
-        sum += v.x + v.y + v.z + v.w;
-      }
-    }
-    if (sum == 123.456f) reinterpret_cast<half_t*>(p.out)[0] = (half_t)sum;
-    return;
-  }
-  if (p.dbg & 128) {  // direct stores from the accumulator layout
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-          store_acc32<EPI>(acc[a][i][b], m0 + wr * 128 + a * 64 + i * 32 + lr, n0 + wc * 64 + b * 32 + 4 * lg, p);
-    return;
-  }
-  store_wave_tile_128x64<EPI>(acc, slab, m0 + wr * 128, n0 + wc * 64, lane, p);
-  if (p.trace && lane == 0) {
-    const unsigned long long tr3 = wall_clock64();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned long long tr4 = wall_clock64();
-    unsigned hw;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    unsigned long long* o = p.trace + ((size_t)blockIdx.x * 8 + wv) * 8;
-    o[0] = tr0; o[1] = tr1; o[2] = tr2; o[3] = tr3; o[4] = tr4; o[5] = hw; o[6] = xcc; o[7] = __builtin_amdgcn_s_memtime() - cy0;
-  }
-}
-
-template <int EPI>
-static void launch8k(const GemmArgs& p, hipStream_t s) {
-  constexpr int LDS = 2 * 4 * 128 * 64 * 2;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm8k_f16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr = true;
-  }
-  const int ntm = (p.M + 255) / 256, ntn = p.N / 256;
-  hipLaunchKernelGGL((gemm8k_f16_kernel<EPI>), dim3(tile_map_grid(ntm, ntn, p.map_mode)), dim3(512), LDS, s, p);
-}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Tile 11: the 8-phase kernel above made PERSISTENT for the fp16-output epilogues. One workgroup per CU walks tiles
@@ -2045,380 +1054,6 @@ static void launch8kp_splitk(const GemmArgs& p, hipStream_t s) {
                      p.resid, p.ldr, p.resid_mod, reinterpret_cast<float*>(p.out), p.ldo, p.M, p.N);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Tile 14: tile 11 with TWO phases of 16 MFMAs per K-tile instead of four of 8 (same 256x256x64 macro tile, 8 waves as 2 x 4,
-// wave tile 128x64, same ring, persistent walk and epilogues; results bit-identical to tiles 10 / 11: every accumulator sees
-// its k16 steps in the same order).
-// Why: per barrier interval one wave row issues MFMAs (8 x 32 = 256 cycles in tile 11) while the other reads fragments and
-// issues DMA; the measured interval is ~370 cycles, and the part above 256 is per-interval latency (the load row's LDS read
-// latency + DMA issue + the barrier hand-off), not throughput - an interval with nothing but its barriers costs ~250 cycles
-// (tools/abl_matrix.sh). Twice the work per interval amortises it: 512 MFMA cycles against 16 / 8 ds_read_b128 + 4 DMA.
-//   phase A(t): MFMA rows 0..63 of the wave tile x 64 columns x K = 64   (16 MFMA; A0, B0, B1 fragments: 16 ds_read_b128)
-//   phase B(t): MFMA rows 64..127                                       (16 MFMA; A1 fragments: 8 reads, B fragments kept)
-// DMA issue (two half-tiles per load part, in consumption order, 4 - 6 intervals ahead of the first read):
-//   load A(t): B0(t+1) B1(t+1)      load B(t): A1(t+1) A0(t+2)          prologue: A0(0) B0(0) B1(0) A1(0) A0(1)
-// Counted waits at the END of a load part, before its barrier (what the NEXT load part reads has landed for every wave once
-// the barrier is passed): after load A vmcnt(6) - only A0(t+1) and this part's four stay in flight, A1(t) is in; after load B
-// vmcnt(4). lgkmcnt(0) also sits BEFORE the barrier: the lagging wave row's reads of A0(t) retire before the leading row,
-// one interval later, refills that half-tile with A0(t+2).
-template <int EPI, bool LNF = false>
-__global__ __launch_bounds__(512) void gemm8q_f16_kernel(GemmArgs p, int total) {
-  extern __shared__ __attribute__((aligned(16))) half_t ring[];  // [buf 2][A0 A1 B0 B1][128][64] + 8 x 4 KiB slabs
-  constexpr int HT = 128 * 64;
-  const int ntn = p.N / 256;
-  const int ntm = (p.M + 255) / 256;
-  const int t = threadIdx.x, lane = t & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wr = wv >> 2, wc = wv & 3;
-  const int lr = lane & 31, lg = lane >> 5;
-  half_t* slab = ring + 8 * HT + wv * 2048;
-  const int nk = p.K / 64;
-  const unsigned bh = 32u * (unsigned)p.ldw;
-  const int arow0 = wr * 64 + lr, brow0 = wc * 32 + lr;
-
-  int idx = blockIdx.x, tm = 0, tn = 0;
-  while (idx < total && !tile_map(idx, ntm, ntn, p.map_mode, tm, tn)) idx += gridDim.x;
-  if (idx >= total) return;
-
-  unsigned aoff[2][2], boff[2];
-  auto offsets = [&](int m0, int n0) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int lrow = j * 64 + (t >> 3);
-      const int chunk = (t & 7) ^ ((lrow >> 1) & 7);
-      const int arow = (lrow >> 6) * 128 + (lrow & 63);
-      const int brow = (lrow >> 5) * 64 + (lrow & 31);
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        int am = m0 + arow + h * 64;
-        am = am < p.M ? am : p.M - 1;
-        aoff[j][h] = (unsigned)am * (unsigned)p.lda + chunk * 8;
-      }
-      boff[j] = (unsigned)(n0 + brow) * (unsigned)p.ldw + chunk * 8;
-    }
-  };
-  auto stage = [&](int which, int kt) {  // 0 A0, 1 A1, 2 B0, 3 B1
-    half_t* dst = ring + ((kt & 1) * 4 + which) * HT + wv * 512;
-    const int h = which & 1;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const half_t* g = which < 2 ? p.A + (aoff[j][h] + (unsigned)kt * 64u) : p.W + (boff[j] + h * bh + (unsigned)kt * 64u);
-      glds16(g, dst + j * 4096);
-    }
-  };
-  auto prologue = [&]() {
-    stage(0, 0); stage(2, 0); stage(3, 0); stage(1, 0);
-    if (nk > 1) stage(0, 1);
-  };
-
-  offsets(tm * 256, tn * 256);
-  prologue();
-
-  half8_t fa[2][4];   // [i][k16]
-  half8_t fb[2][4];   // [b][k16]
-
-#define RDQ_A(bufp, h)                                                                                            \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int k4 = 0; k4 < 4; ++k4)                   \
-      fa[i][k4] = *reinterpret_cast<const half8_t*>(&(bufp)[(h) * HT + lds_off64(arow0 + i * 32, k4 * 2 + lg)]);
-#define RDQ_B(bufp)                                                                                               \
-  _Pragma("unroll") for (int b = 0; b < 2; ++b) _Pragma("unroll") for (int k4 = 0; k4 < 4; ++k4)                   \
-      fb[b][k4] = *reinterpret_cast<const half8_t*>(&(bufp)[(2 + b) * HT + lds_off64(brow0, k4 * 2 + lg)]);
-#define MMAQ(a)                                                                                                   \
-  _Pragma("unroll") for (int k4 = 0; k4 < 4; ++k4) _Pragma("unroll") for (int i = 0; i < 2; ++i)                   \
-      _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                               \
-          acc[a][i][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[b][k4], fa[i][k4], acc[a][i][b], 0, 0, 0);
-#define Q_SYNC_IN()                                       \
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
-  __builtin_amdgcn_sched_barrier(0);                      \
-  __builtin_amdgcn_s_barrier();                           \
-  __builtin_amdgcn_sched_barrier(0);                      \
-  __builtin_amdgcn_s_setprio(1);
-#define Q_SYNC_OUT()                                      \
-  __builtin_amdgcn_s_setprio(0);                          \
-  __builtin_amdgcn_sched_barrier(0);                      \
-  __builtin_amdgcn_s_barrier();                           \
-  asm volatile("" ::: "memory");
-
-  bool first = true;
-  for (;;) {
-    const int m0 = tm * 256, n0 = tn * 256;
-    f32x16 acc[2][2][2];  // [a][i][b]
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[a][i][b][r] = 0.f;
-
-    // first tile: A0(0) B0(0) B1(0) have landed, A1(0) A0(1) may still fly. Later tiles: see tile 11 (stores and loads share
-    // the counter, so wait for all; the DMAs landed during the epilogue)
-    if (first) { if (nk > 1) wait_vmcnt<4>(); else wait_vmcnt<2>(); } else { wait_vmcnt<0>(); }
-    first = false;
-    __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger the second wave row by one barrier
-    asm volatile("" ::: "memory");
-
-    for (int kt = 0; kt < nk; ++kt) {
-      const half_t* buf = ring + (kt & 1) * 4 * HT;
-      const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
-      // ---- load A: B0 B1 A0 fragments of K-tile kt; DMA B0 B1 of kt + 1
-      RDQ_B(buf) __builtin_amdgcn_sched_barrier(0); RDQ_A(buf, 0) __builtin_amdgcn_sched_barrier(0);
-      if (more1) { stage(2, kt + 1); stage(3, kt + 1); }
-      if (more1) wait_vmcnt<6>(); else wait_vmcnt<0>();
-      Q_SYNC_IN();
-      MMAQ(0)
-      Q_SYNC_OUT();
-      // ---- load B: A1 fragments; DMA A1 of kt + 1, A0 of kt + 2
-      RDQ_A(buf, 1) __builtin_amdgcn_sched_barrier(0);
-      if (more1) stage(1, kt + 1);
-      if (more2) stage(0, kt + 2);
-      if (more2) { wait_vmcnt<4>(); } else if (more1) { wait_vmcnt<2>(); } else { wait_vmcnt<0>(); }
-      Q_SYNC_IN();
-      MMAQ(1)
-      Q_SYNC_OUT();
-    }
-    if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the stagger: every wave is done with the ring here
-
-    // next tile of this workgroup: request its first half-tiles now
-    int nidx = idx + gridDim.x, ntm_ = 0, ntn_ = 0;
-    while (nidx < total && !tile_map(nidx, ntm, ntn, p.map_mode, ntm_, ntn_)) nidx += gridDim.x;
-    const bool have = nidx < total;
-    if (have) {
-      offsets(ntm_ * 256, ntn_ * 256);
-      prologue();
-    }
-    __builtin_amdgcn_sched_barrier(0);
-
-    persist_epilogue<EPI, LNF>(acc, slab, m0 + wr * 128, n0 + wc * 64, lane, p);
-    if (!have) break;
-    idx = nidx; tm = ntm_; tn = ntn_;
-  }
-#undef RDQ_A
-#undef RDQ_B
-#undef MMAQ
-#undef Q_SYNC_IN
-#undef Q_SYNC_OUT
-}
-
-template <int EPI, bool LNF = false>
-static void launch8q(const GemmArgs& p, hipStream_t s) {
-  constexpr int LDS = 2 * 4 * 128 * 64 * 2 + 8 * 4096;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm8q_f16_kernel<EPI, LNF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr = true;
-  }
-  const int ntm = (p.M + 255) / 256, ntn = p.N / 256;
-  GemmArgs q = p;
-  q.map_mode = pick_map_mode(ntm, ntn);
-  const int total = tile_map_grid(ntm, ntn, q.map_mode);
-  hipLaunchKernelGGL((gemm8q_f16_kernel<EPI, LNF>), dim3(total < num_cus() ? total : num_cus()), dim3(512), LDS, s, q, total);
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Tile 13: FOUR waves (one per SIMD), 128x128 wave tiles, same 256x256x64 macro tile, DMA ring and persistent walk as tile
-// 11. Why: tools/micro/mfma_shadow_bench.hip - one wave per SIMD, back-to-back 32x32x16 MFMAs with this kernel's load mix
-// in their shadows (2 ds_read_b128 + 1 LDS-DMA per 4 MFMAs, two fragment sets alternating without copies) runs 35.3
-// cycles per MFMA = 2260 cycles per K-tile, against 2970 measured for the 8-wave kernels: a 128x128 wave tile needs 32
-// fragment reads per 64 MFMAs instead of 48, and a single in-order stream has no barrier-coupled intervals.
-// Schedule per K-tile kt (four k16 sub-steps of 16 MFMAs; fragment sets alternate, so the loop has no register rotation):
-//   S0: MFMA set 0 | read (kt, s1) -> set 1 | DMA pieces 8..15 of K-tile kt+1
-//   S1: MFMA set 1 | read (kt, s2) -> set 0
-//   S2: MFMA set 0 | read (kt, s3) -> set 1 ; lgkmcnt(0) ; vmcnt(0) ; ONE barrier
-//   S3: MFMA set 1 | read (kt+1, s0) -> set 0 | DMA pieces 0..7 of K-tile kt+2 (into the buffer the barrier just freed)
-// so a DMA piece is waited for 2 to 4 sub-steps (1100-2300 cycles) after it was issued.
-template <int EPI>
-__global__ __launch_bounds__(256, 1) void gemm4p_f16_kernel(GemmArgs p, int total) {
-  extern __shared__ __attribute__((aligned(16))) half_t ring[];  // [buf 2][A0 A1 B0 B1][128][64] + 4 x 8 KiB slabs
-  constexpr int HT = 128 * 64;
-  const int ntn = p.N / 256;
-  const int ntm = (p.M + 255) / 256;
-  const int t = threadIdx.x, lane = t & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wr = wv >> 1, wc = wv & 1;
-  const int lr = lane & 31, lg = lane >> 5;
-  half_t* slab = ring + 8 * HT + wv * 4096;
-  const int nk = p.K / 64;
-
-  int idx = blockIdx.x, tm = 0, tn = 0;
-  while (idx < total && !tile_map(idx, ntm, ntn, p.map_mode, tm, tn)) idx += gridDim.x;
-  if (idx >= total) return;
-
-  // DMA piece (which, j): rows j*32 + t/8 of half-tile `which` (8 lanes per 128-byte row), LDS slot t%8 <- source chunk
-  unsigned aoff[2][4], boff[2][4];
-  auto offsets = [&](int m0, int n0) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = j * 32 + (t >> 3);
-      const int chunk = (t & 7) ^ ((row >> 1) & 7);
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        int am = m0 + h * 128 + row;
-        am = am < p.M ? am : p.M - 1;
-        aoff[h][j] = (unsigned)am * (unsigned)p.lda + chunk * 8;
-        boff[h][j] = (unsigned)(n0 + h * 128 + row) * (unsigned)p.ldw + chunk * 8;
-      }
-    }
-  };
-  auto piece = [&](int q, int kt) {   // q = 0..15: which = q >> 2 (A0 A1 B0 B1), j = q & 3
-    const int which = q >> 2, j = q & 3;
-    half_t* dst = ring + ((kt & 1) * 4 + which) * HT + (j * 32 + wv * 8) * 64;
-    const half_t* g = which < 2 ? p.A + (aoff[which][j] + (unsigned)kt * 64u) : p.W + (boff[which - 2][j] + (unsigned)kt * 64u);
-    if (!(kt > 1 && (p.dbg & 1))) glds16(g, dst);
-  };
-
-  offsets(tm * 256, tn * 256);
-#pragma unroll
-  for (int q = 0; q < 16; ++q) piece(q, 0);
-  if (nk > 1) {
-#pragma unroll
-    for (int q = 0; q < 16; ++q) piece(q, 1);
-  }
-
-  half8_t fa[2][4], fb[2][4];   // [set][row block / column block]
-  const int arow = lr, brow = lr;
-#define SB() __builtin_amdgcn_sched_barrier(0)
-#define RDA(set, bufp, s, r) \
-  fa[set][r] = *reinterpret_cast<const half8_t*>(&(bufp)[wr * HT + lds_off64(arow + (r) * 32, (s) * 2 + lg)])
-#define RDB(set, bufp, s, r) \
-  fb[set][r] = *reinterpret_cast<const half8_t*>(&(bufp)[(2 + wc) * HT + lds_off64(brow + (r) * 32, (s) * 2 + lg)])
-#define MF(set, rb, cb) \
-  acc[(cb) >> 1][(rb) >> 1][(rb) & 1][(cb) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[set][cb], fa[set][rb], acc[(cb) >> 1][(rb) >> 1][(rb) & 1][(cb) & 1], 0, 0, 0)
-// one k16 sub-step: 16 MFMAs on fragment set `set`; X0..X7 go behind MFMAs 0..7, Y0..Y7 behind MFMAs 8..15
-#define SUBSTEP(set, X0, X1, X2, X3, X4, X5, X6, X7, Y0, Y1, Y2, Y3, Y4, Y5, Y6, Y7)                                  \
-  MF(set, 0, 0); X0; SB(); MF(set, 0, 1); X1; SB(); MF(set, 0, 2); X2; SB(); MF(set, 0, 3); X3; SB();                 \
-  MF(set, 1, 0); X4; SB(); MF(set, 1, 1); X5; SB(); MF(set, 1, 2); X6; SB(); MF(set, 1, 3); X7; SB();                 \
-  MF(set, 2, 0); Y0; SB(); MF(set, 2, 1); Y1; SB(); MF(set, 2, 2); Y2; SB(); MF(set, 2, 3); Y3; SB();                 \
-  MF(set, 3, 0); Y4; SB(); MF(set, 3, 1); Y5; SB(); MF(set, 3, 2); Y6; SB(); MF(set, 3, 3); Y7; SB();
-
-  bool first = true;
-  unsigned long long tcyc = 0, twall = 0, tks = 0;
-  for (;;) {
-    const int m0 = tm * 256, n0 = tn * 256;
-    f32x16 acc[2][2][2][2];  // [column half][a][i][b]: rows (2a+i)*32, columns (2*half+b)*32 of the 128x128 wave tile
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[c][a][i][b][r] = 0.f;
-
-    // K-tile 0 landed (the 8 pieces of K-tile 1 may fly); later tiles: the previous tile's stores are in the count
-    if (first) { if (nk > 1) wait_vmcnt<16>(); else wait_vmcnt<0>(); } else { wait_vmcnt<0>(); }
-    first = false;
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    RDA(0, ring, 0, 0); RDA(0, ring, 0, 1); RDA(0, ring, 0, 2); RDA(0, ring, 0, 3);
-    RDB(0, ring, 0, 0); RDB(0, ring, 0, 1); RDB(0, ring, 0, 2); RDB(0, ring, 0, 3);
-    SB();
-
-    unsigned long long c0 = 0, w0 = 0;
-    if (p.trace) { c0 = __builtin_amdgcn_s_memtime(); w0 = wall_clock64(); }
-    for (int kt = 0; kt < nk; ++kt) {
-      const half_t* buf = ring + (kt & 1) * 4 * HT;
-      const half_t* nbuf = ring + ((kt + 1) & 1) * 4 * HT;
-      const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
-      SUBSTEP(0, RDA(1, buf, 1, 0), RDA(1, buf, 1, 1), RDA(1, buf, 1, 2), RDA(1, buf, 1, 3), RDB(1, buf, 1, 0), RDB(1, buf, 1, 1), RDB(1, buf, 1, 2), RDB(1, buf, 1, 3),
- , , , , , , , )
-      SUBSTEP(1, RDA(0, buf, 2, 0), RDA(0, buf, 2, 1), RDA(0, buf, 2, 2), RDA(0, buf, 2, 3), RDB(0, buf, 2, 0), RDB(0, buf, 2, 1), RDB(0, buf, 2, 2), RDB(0, buf, 2, 3), , , , , , , , )
-      SUBSTEP(0, RDA(1, buf, 3, 0), RDA(1, buf, 3, 1), RDA(1, buf, 3, 2), RDA(1, buf, 3, 3), RDB(1, buf, 3, 0), RDB(1, buf, 3, 1), RDB(1, buf, 3, 2), RDB(1, buf, 3, 3), , , , , , , , )
-      // every wave is done reading this K-tile's buffer and has its pieces of the next one: one barrier per K-tile
-      if (!(p.dbg & 2)) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-      }
-      asm volatile("" ::: "memory");
-      // (after the last K-tile these reads fetch stale ring contents that nobody uses: no second copy of the MFMA stream)
-      SUBSTEP(1, RDA(0, nbuf, 0, 0); if (more2) piece(0, kt + 2), RDA(0, nbuf, 0, 1); if (more2) piece(1, kt + 2), RDA(0, nbuf, 0, 2); if (more2) piece(2, kt + 2), RDA(0, nbuf, 0, 3); if (more2) piece(3, kt + 2), RDB(0, nbuf, 0, 0); if (more2) piece(4, kt + 2), RDB(0, nbuf, 0, 1); if (more2) piece(5, kt + 2), RDB(0, nbuf, 0, 2); if (more2) piece(6, kt + 2), RDB(0, nbuf, 0, 3); if (more2) piece(7, kt + 2),
-                 if (more2) piece(8, kt + 2), if (more2) piece(9, kt + 2), if (more2) piece(10, kt + 2), if (more2) piece(11, kt + 2), if (more2) piece(12, kt + 2), if (more2) piece(13, kt + 2), if (more2) piece(14, kt + 2), if (more2) piece(15, kt + 2))
-    }
-
-    if (p.trace) { tcyc += __builtin_amdgcn_s_memtime() - c0; twall += wall_clock64() - w0; tks += nk; }
-    // next tile of this workgroup: request its first K-tile and half of the second now (the ring is idle)
-    int nidx = idx + gridDim.x, ntm_ = 0, ntn_ = 0;
-    while (nidx < total && !tile_map(nidx, ntm, ntn, p.map_mode, ntm_, ntn_)) nidx += gridDim.x;
-    const bool have = nidx < total;
-    if (have) {
-      offsets(ntm_ * 256, ntn_ * 256);
-#pragma unroll
-      for (int q = 0; q < 16; ++q) piece(q, 0);
-      if (nk > 1) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) piece(q, 1);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    persist_epilogue<EPI>(acc[0], slab, m0 + wr * 128, n0 + wc * 128, lane, p);
-    persist_epilogue<EPI>(acc[1], slab, m0 + wr * 128, n0 + wc * 128 + 64, lane, p);
-    if (!have) break;
-    idx = nidx; tm = ntm_; tn = ntn_;
-  }
-  if (p.trace && t == 0) { p.trace[blockIdx.x * 4 + 0] = tcyc; p.trace[blockIdx.x * 4 + 1] = twall; p.trace[blockIdx.x * 4 + 2] = tks; }
-#undef SB
-#undef RDA
-#undef RDB
-#undef MF
-#undef SUBSTEP
-}
-
-template <int EPI>
-static void launch4p(const GemmArgs& p, hipStream_t s) {
-  constexpr int LDS = 2 * 4 * 128 * 64 * 2 + 4 * 8192;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm4p_f16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr = true;
-  }
-  const int ntm = (p.M + 255) / 256, ntn = p.N / 256;
-  GemmArgs q = p;
-  q.map_mode = pick_map_mode(ntm, ntn);
-  const int total = tile_map_grid(ntm, ntn, q.map_mode);
-  static const char* tr = getenv("PSAM_GEMM_TRACE");
-  if (tr) { (void)hipMalloc((void**)&q.trace, 256 * 4 * sizeof(unsigned long long)); (void)hipMemsetAsync(q.trace, 0, 256 * 32, s); }
-  hipLaunchKernelGGL((gemm4p_f16_kernel<EPI>), dim3(total < num_cus() ? total : num_cus()), dim3(256), LDS, s, q, total);
-  if (tr) {   // debugging aid: cycles and wall time inside the k-loops (s_memtime / s_memrealtime at 100 MHz)
-    std::vector<unsigned long long> h(256 * 4);
-    (void)hipStreamSynchronize(s);
-    (void)hipMemcpy(h.data(), q.trace, h.size() * 8, hipMemcpyDeviceToHost);
-    (void)hipFree(q.trace);
-    double c = 0, w = 0, n = 0;
-    for (int b = 0; b < 256; ++b) { c += (double)h[b * 4]; w += (double)h[b * 4 + 1]; n += (double)h[b * 4 + 2]; }
-    if (n > 0) fprintf(stderr, "tile13 k-loop: %.0f cycles, %.3f us per K-tile -> %.3f GHz\n", c / n, w / n * 0.01, c / (w * 10.0));
-  }
-}
-
-template <int EPI>
-static void launch_ws(const GemmArgs& p, hipStream_t s) {
-  constexpr int LDS = 4 * (384 + 128) * 32 * 2;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm_ws_f16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr = true;
-  }
-  const int ntm = (p.M + 383) / 384, ntn = p.N / 128;
-  hipLaunchKernelGGL((gemm_ws_f16_kernel<EPI>), dim3(tile_map_grid(ntm, ntn, p.map_mode)), dim3(512), LDS, s, p);
-}
-
-template <int EPI, int BN_, int STAG>
-static void launch256(const GemmArgs& p, hipStream_t s) {
-  using C = G256<BN_>;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm256_f16_kernel<EPI, BN_, STAG>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-    attr = true;
-  }
-  const int ntm = (p.M + 255) / 256, ntn = p.N / BN_;
-  hipLaunchKernelGGL((gemm256_f16_kernel<EPI, BN_, STAG>), dim3(tile_map_grid(ntm, ntn, p.map_mode)), dim3(512),
-                     C::LDS_BYTES, s, p);
-}
-
 
 // ---- tile 15: the hand-scheduled assembly kernels of gemm_asm_gen.py (code object embedded by gemm_asm_blob.S) ----------------
 // Four waves / 128x128 wave tiles / whole K-tile of fragments in registers / LDS-DMA two K-tiles ahead through buffer descriptors;
@@ -2561,10 +1196,10 @@ static int launch_asm(const GemmArgs& p, int epilogue, hipStream_t s, int family
   return PSAM_OK;
 }
 
-// tile choice: 0 = auto, 1 = 128x128x64 double buffer, 2 = 256x128 / 3 = 256x256 staggered ring, 5 = 256x256 plain ring,
-// 6 = wave-specialised 384x128, 7 = 256x256x64 8-phase, 8 = 7 with one barrier per phase, 9 = four waves with 128x128
-// wave tiles and register staging (experimental), 10 = 8-phase with K-split phases, 11 = its persistent form (the default
-// large tile), 13 = four waves / 128x128 wave tiles / LDS-DMA / persistent (experimental, same speed as 11)
+// tile choice: 0 = auto; 1 = 128x128x64, four waves, two workgroups per CU (HIP); 11 = 256x256x64 persistent 8-wave kernel (HIP; the
+// folded-LayerNorm, head-major and split-K forms live here); 15 = the assembly kernels of gemm_asm_gen.py (256x256 tiles, four
+// waves, the default large tile); 16 = the half-tile ping-pong assembly kernels of gemm_asm2_gen.py (experimental). The other
+// HIP schedules of rounds 1 / 2 (tiles 2 ... 10, 13, 14) lost to these and are gone (history: DESIGN.md).
 // (PSAM_GEMM_TILE env var or psam_gemm_set_tile)
 static int g_tile_override = -1;
 extern "C" int psam_gemm_set_tile(int t) {
@@ -2577,10 +1212,8 @@ static int pick_tile(int M, int N, int K, int epilogue) {
     g_tile_override = e ? atoi(e) : 0;
   }
   if (g_tile_override > 0) return g_tile_override;
-  // measured on MI355X (tools/gemm_tiles.py, within-run A/B): the 256x256 8-phase kernel (7) beats the 128x128
-  // double-buffered kernel (1) by 5-20 % whenever its 256-tiles fill the 256 CUs to >= 80 % in their last round (one
-  // workgroup per CU, so a part-filled round is lost time); otherwise the 128x128 kernel with two workgroups per CU
-  // wins. 5 = plain 4-deep ring, 3 = its two-phase staggered variant, 6 = wave-specialised loaders (kept for A/B).
+  // a 256x256-tile kernel (one persistent workgroup per CU) wins whenever its tiles fill the CUs to >= 80 % in their last round (a
+  // part-filled round is lost time); otherwise the 128x128 kernel with two workgroups per CU (measured, tools/gemm_asm_check.py bench)
   if (N % 256 == 0) {
     const long t256 = (long)((M + 255) / 256) * (N / 256);
     const long ncu = num_cus();
@@ -2588,18 +1221,23 @@ static int pick_tile(int M, int N, int K, int epilogue) {
     // the fp32 residual epilogue with a short K (proj: 20 K-tiles) is better served by two workgroups per CU unless the
     // 256-tiles fill their rounds completely (65536x1280x1280: 603 vs 525 TFLOP/s; 32768x1280x1280, 2.5 rounds: 653 vs 689)
     const bool short_f32 = epilogue == EPI_F32 && K < 2048;
-    // 10 = 8-phase with K-split phases (7 = its quadrant-phase predecessor); 11 = its persistent form (fp16 outputs)
     // K >= 768: DINOv2-B's shapes at 16 slices (M = 20752) measured 5-45 % faster on the persistent 256-tile kernel than on the
     // 128-tile one (tools/gemm_tiles.py 1,11: qkv 790-820 vs 750, proj 730-760 vs 500-620, fc1 870 vs 740 TFLOP/s; fp32 epilogue
     // 557 vs 497); per-slice calls (M = 1297) fail the fill test and stay on the 128-tile kernel (350 vs 200)
     if (K >= 768 && t256 * 100 >= rounds * ncu * (short_f32 ? 95 : 80)) {
-      static int f32p = -1;
-      if (f32p < 0) { const char* e = getenv("PSAM_GEMM_F32_PERSIST"); f32p = e ? atoi(e) : 1; }
       static int asm_on = -1;   // the assembly kernels (tile 15) take every shape the persistent HIP kernel took, when eligible (gemm_dispatch)
       if (asm_on < 0) { const char* e = getenv("PSAM_GEMM_ASM"); asm_on = e ? atoi(e) : 1; }
-      if (asm_on) return 15;
-      return epilogue == EPI_F32 && !f32p ? 10 : 11;
+      return asm_on ? 15 : 11;
     }
+  }
+  // too few 256x256 tiles for the CUs (one slice through proj / fc1 / fc2: 80 ... 320 tiles): the half-tile assembly kernels have
+  // twice the work items (4096x1280x5120: 852 vs 576 TFLOP/s on tile 15, 671 split-K; 4096x5120x1280: 832 vs 734; gemm_dispatch
+  // falls back to the 128x128 kernel when their layout rules or minimum K are not met)
+  if (N % 128 == 0 && K >= 768) {
+    static int half_on = -1;
+    if (half_on < 0) { const char* e = getenv("PSAM_GEMM_HALF"); half_on = e ? atoi(e) : 1; }
+    const long th = (long)((M + 255) / 256) * (N / 128), ncu = num_cus();
+    if (half_on && th * 2 >= ncu) return 16;
   }
   return 1;
 }
@@ -2658,35 +1296,14 @@ static int gemm_dispatch(const void* A, const void* W, const float* bias, void* 
   // the slab epilogues store fp16 rows with 16-byte instructions when the layout allows (tiles 7 / 8 / 10 / 11 / 15 require it)
   p.wide16 = (ldo % 8) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (!head_hd || head_hd % 8 == 0);
   // the assembly kernels (tile 15) take plain row-major operands; everything else they were picked for goes to the persistent HIP kernel
-  if (tsel == 16 && !asm2_eligible(p, epilogue, ln_prod || ln_cons)) tsel = 15;
+  if (tsel == 16 && !asm2_eligible(p, epilogue, ln_prod || ln_cons)) tsel = g_tile_override > 0 ? 15 : 1;
   if (tsel == 15 && !asm_eligible(p, epilogue, ln_prod || ln_cons)) tsel = (N % 256 == 0) ? 11 : 1;
-  if (head_hd && tsel != 1 && tsel != 7 && tsel != 8 && tsel != 10 && tsel != 11 && tsel != 13 && tsel != 14) tsel = 1;   // the head-major store lives in the staged epilogue  // the ReLU epilogue lives in the 128x128 kernel
-  if ((tsel == 7 || tsel == 8 || tsel == 10 || tsel == 11 || tsel == 13 || tsel == 14) && epilogue != EPI_F32 && !p.wide16) tsel = 1;
-  if (ln_prod || ln_cons) {   // the folded-LayerNorm epilogues live in the 128x128 kernel and the persistent 256x256 ones
-    if (tsel != 11 && tsel != 14) tsel = 1;
-    if (ln_cons && !p.wide16) return PSAM_ERR_ARG;
-  }
+  if (tsel != 1 && tsel != 11 && tsel != 15 && tsel != 16) tsel = (N % 256 == 0) ? 11 : 1;   // (tiles 2 ... 14 of rounds 1 / 2 are gone)
+  if (tsel == 11 && (N % 256) != 0) tsel = 1;
+  if (tsel == 11 && epilogue != EPI_F32 && !p.wide16) tsel = 1;   // the persistent kernel stores fp16 rows with 16-byte instructions
+  if (ln_cons && !p.wide16) return PSAM_ERR_ARG;                  // (the folded-LayerNorm epilogues live in tiles 1 and 11)
   if (tsel == 15) return launch_asm(p, epilogue, s);
   if (tsel == 16) return launch_asm(p, epilogue, s, 2);
-  if ((tsel == 3 || tsel == 5) && N % 256 == 0) {
-    if (tsel == 3) {
-      if (epilogue == EPI_F16) launch256<EPI_F16, 256, 1>(p, s);
-      else if (epilogue == EPI_GELU_F16) launch256<EPI_GELU_F16, 256, 1>(p, s);
-      else launch256<EPI_F32, 256, 1>(p, s);
-    } else {
-      if (epilogue == EPI_F16) launch256<EPI_F16, 256, 0>(p, s);
-      else if (epilogue == EPI_GELU_F16) launch256<EPI_GELU_F16, 256, 0>(p, s);
-      else launch256<EPI_F32, 256, 0>(p, s);
-    }
-    return psam_launch_status();
-  }
-  if ((tsel == 11 || tsel == 13 || tsel == 14) && N % 256 == 0 && epilogue != EPI_F32 && !p.wide16) tsel = 10;
-  if (tsel == 13 && N % 256 == 0) {
-    if (epilogue == EPI_F16) launch4p<EPI_F16>(p, s);
-    else if (epilogue == EPI_GELU_F16) launch4p<EPI_GELU_F16>(p, s);
-    else launch4p<EPI_F32>(p, s);
-    return psam_launch_status();
-  }
   p.ksplit = 1;
   p.ks_ws = nullptr;
   // split-K (see launch8kp_splitk): only where the automatic choice fell back to the 128x128 kernel because too few 256-tiles
@@ -2714,15 +1331,15 @@ static int gemm_dispatch(const void* A, const void* W, const float* bias, void* 
     }
   }
   const bool lnf = ln_prod || ln_cons;
-  if (lnf && (tsel == 14 || tsel == 11) && N % 256 == 0) {   // separate instantiations: the plain kernels stay as they were
-    if (tsel == 14) {
-      if (epilogue == EPI_F16) launch8q<EPI_F16, true>(p, s);
-      else if (epilogue == EPI_GELU_F16) launch8q<EPI_GELU_F16, true>(p, s);
-      else launch8q<EPI_F32, true>(p, s);
-    } else {
+  if (tsel == 11) {
+    if (lnf) {   // separate instantiations: the plain kernels stay as they were
       if (epilogue == EPI_F16) launch8kp<EPI_F16, true>(p, s);
       else if (epilogue == EPI_GELU_F16) launch8kp<EPI_GELU_F16, true>(p, s);
       else launch8kp<EPI_F32, true>(p, s);
+    } else {
+      if (epilogue == EPI_F16) launch8kp<EPI_F16>(p, s);
+      else if (epilogue == EPI_GELU_F16) launch8kp<EPI_GELU_F16>(p, s);
+      else launch8kp<EPI_F32>(p, s);
     }
     return psam_launch_status();
   }
@@ -2732,69 +1349,6 @@ static int gemm_dispatch(const void* A, const void* W, const float* bias, void* 
       case EPI_GELU_F16: hipLaunchKernelGGL((gemm_f16_kernel<EPI_GELU_F16, true>), grid, block, 0, s, p); break;
       default: hipLaunchKernelGGL((gemm_f16_kernel<EPI_F32, true>), grid, block, 0, s, p); break;
     }
-    return psam_launch_status();
-  }
-  if (tsel == 14 && N % 256 == 0) {
-    if (epilogue == EPI_F16) launch8q<EPI_F16>(p, s);
-    else if (epilogue == EPI_GELU_F16) launch8q<EPI_GELU_F16>(p, s);
-    else launch8q<EPI_F32>(p, s);
-    return psam_launch_status();
-  }
-  if (tsel == 11 && N % 256 == 0) {
-    if (epilogue == EPI_F16) launch8kp<EPI_F16>(p, s);
-    else if (epilogue == EPI_GELU_F16) launch8kp<EPI_GELU_F16>(p, s);
-    else launch8kp<EPI_F32>(p, s);
-    return psam_launch_status();
-  }
-  if (tsel == 10 && N % 256 == 0) {
-    static const char* trace_path = getenv("PSAM_GEMM_TRACE");
-    const size_t nblk = (size_t)tile_map_grid((M + 255) / 256, N / 256, p.map_mode);
-    if (trace_path) {   // debugging aid: dump per-wave timestamps of this launch (synchronous)
-      (void)hipMalloc((void**)&p.trace, nblk * 64 * sizeof(unsigned long long));
-      (void)hipMemsetAsync(p.trace, 0, nblk * 64 * sizeof(unsigned long long), s);
-    }
-    if (epilogue == EPI_F16) launch8k<EPI_F16>(p, s);
-    else if (epilogue == EPI_GELU_F16) launch8k<EPI_GELU_F16>(p, s);
-    else launch8k<EPI_F32>(p, s);
-    if (trace_path) {
-      std::vector<unsigned long long> h(nblk * 64);
-      (void)hipStreamSynchronize(s);
-      (void)hipMemcpy(h.data(), p.trace, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-      (void)hipFree(p.trace);
-      FILE* f = fopen(trace_path, "wb");
-      if (f) { fwrite(h.data(), sizeof(unsigned long long), h.size(), f); fclose(f); }
-    }
-    return psam_launch_status();
-  }
-  if (tsel == 9 && N % 256 == 0) {
-    if (epilogue == EPI_F16) launch4w<EPI_F16>(p, s);
-    else if (epilogue == EPI_GELU_F16) launch4w<EPI_GELU_F16>(p, s);
-    else launch4w<EPI_F32>(p, s);
-    return psam_launch_status();
-  }
-  if (tsel == 8 && N % 256 == 0) {
-    if (epilogue == EPI_F16) launch8h<EPI_F16>(p, s);
-    else if (epilogue == EPI_GELU_F16) launch8h<EPI_GELU_F16>(p, s);
-    else launch8h<EPI_F32>(p, s);
-    return psam_launch_status();
-  }
-  if (tsel == 7 && N % 256 == 0) {
-    if (epilogue == EPI_F16 && p.dbg) launch8p<EPI_F16, true>(p, s);
-    else if (epilogue == EPI_F16) launch8p<EPI_F16>(p, s);
-    else if (epilogue == EPI_GELU_F16) launch8p<EPI_GELU_F16>(p, s);
-    else launch8p<EPI_F32>(p, s);
-    return psam_launch_status();
-  }
-  if (tsel == 6) {
-    if (epilogue == EPI_F16) launch_ws<EPI_F16>(p, s);
-    else if (epilogue == EPI_GELU_F16) launch_ws<EPI_GELU_F16>(p, s);
-    else launch_ws<EPI_F32>(p, s);
-    return psam_launch_status();
-  }
-  if (tsel == 2) {
-    if (epilogue == EPI_F16) launch256<EPI_F16, 128, 1>(p, s);
-    else if (epilogue == EPI_GELU_F16) launch256<EPI_GELU_F16, 128, 1>(p, s);
-    else launch256<EPI_F32, 128, 1>(p, s);
     return psam_launch_status();
   }
   switch (epilogue) {
