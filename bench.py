@@ -90,6 +90,35 @@ def launch_ranks(args):
     return p.returncode
 
 
+def _gemm_traffic(args, B):
+    """Average measured L2<->fabric bytes per launch of the four SAM block GEMMs (97 % of the GEMM FLOPs of a step) from the newest
+    profiles/r*_gemm_traffic_by_shape.json - or None when that file was measured on other kernel sources (git blob hashes differ),
+    on another batch shape, or is missing."""
+    import glob
+    import hashlib
+    import json as _json
+    root = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r*_gemm_traffic_by_shape.json")))
+    if not files or args.sam != "vit_h":
+        return None
+    try:
+        doc = _json.load(open(files[-1]))
+        for path, h in doc["sources"].items():
+            data = open(os.path.join(root, path), "rb").read()
+            if hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest() != h:
+                return None
+        M = min(args.micro, B) * 4096
+        tot = 0
+        for key in (f"{M}x3840x1280x0", f"{M}x1280x1280x2", f"{M}x5120x1280x1", f"{M}x1280x5120x2"):
+            sh = doc["shapes"][key]
+            tot += sh["read_bytes_per_launch"] + sh["write_bytes_per_launch"]
+        return {"bytes_per_launch_avg": tot // 4, "file": os.path.relpath(files[-1], root),
+                "note": "mean over the qkv / proj / fc1 / fc2 launches of a SAM ViT-H block at this batch; L2<->fabric requests "
+                        "(Infinity-Cache hits included: upper bound of HBM traffic), FETCH_SIZE doubled per the gfx950 correction"}
+    except Exception:
+        return None
+
+
 def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -180,9 +209,9 @@ def main():
                                            "two ViT encoders)",
                 "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F16_TFLOPS, 4),
-                # HBM bytes per launch come from rocprofv3 PMC passes, which cannot run inside this process: the measured figure
-                # for this round's kernel is in profiles/ (DESIGN.md cites the file); never read from a stale file here
-                "traffic": None, "launches": nl,
+                # HBM-side bytes per launch come from rocprofv3 PMC passes, which cannot run inside this process: taken from the
+                # per-shape file of tools/gemm_traffic_by_shape.sh ONLY when it was measured on the shipped kernel sources
+                "traffic": (_gemm_traffic(args, B) or {}).get("bytes_per_launch_avg"), "traffic_detail": _gemm_traffic(args, B), "launches": nl,
                 "avg_launch_us": round(tg / max(nl, 1) * 1e6, 2), "flop_per_launch_avg": round(fl / max(nl, 1)),
                 "gemm_time_share": round(tg / elapsed, 3)}
     res = {
