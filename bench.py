@@ -53,8 +53,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the per-slice / no-cache / stage / HBM-roofline legs")
     ap.add_argument("--cpu-slices", type=int, default=3, help="slices of the CPU baseline at all cores")
-    ap.add_argument("--cpu-1thread-slices", type=int, default=1, help="slices of the CPU baseline at 1 thread "
-                    "(validation_protosam.py:299); 0 skips it")
+    ap.add_argument("--cpu-1thread-slices", type=int, default=0, help="slices of the CPU baseline at 1 thread, as the reference "
+                    "runs (validation_protosam.py:299: one slice takes about a minute); 0 (default) skips it")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak: --batch slices per rank per step; strong: "
+                    "a step is ONE pass over the --slices volume, rank r takes z = r (mod world) (SURVEY 8e), one all-gather per step")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the BASELINE configs 2 / 3 / 5 legs of the default run")
     ap.add_argument("--cpu-sam-depth", type=int, default=None, help="debug: truncate both models' SAM depth")
     return ap.parse_args(argv)
 
@@ -68,6 +71,11 @@ def step_slices(s, parts, B, world, rank):
     zs = [pz[(base + j * world + rank) % len(pz)] for j in range(B)]
     zs.sort()
     return zs
+
+
+def strong_slices(n_slices, world, rank):
+    """--scaling strong: the slices of the whole volume rank `rank` owns, z = rank (mod world) (protosam_amd.runner.shard_slices)."""
+    return list(range(rank, n_slices, world))
 
 
 def launch_ranks(args):
@@ -151,12 +159,15 @@ def main():
     if rank == 0:
         log(f"built model + volume in {time.time() - t0:.1f}s (world {world})")
 
-    B = args.batch
+    strong = args.scaling == "strong"
+    if strong and args.slices % world:
+        raise SystemExit("--scaling strong needs --slices divisible by the number of ranks")
+    B = args.slices // world if strong else args.batch
     out = torch.zeros((B, 512, 512), dtype=torch.uint8, device=dev)
     parts = [[z for z in range(args.slices) if part_assign(z, args.slices) == pt] for pt in range(3)]
 
     def step(s, micro=None, volume=None):
-        zs = step_slices(s, parts, B, world, rank)
+        zs = strong_slices(args.slices, world, rank) if strong else step_slices(s, parts, B, world, rank)
         masks, st = run_slices(model, vol_d if volume is None else volume, sup_imgs, sup_masks, zs, dev, out=out,
                                batch=micro or args.micro)
         full = gather_masks(masks, world)
@@ -218,7 +229,7 @@ def main():
         "metric": "query-slices/sec (512x512) end-to-end ProtoSAM infer",
         "value": round(value, 3), "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-        "ms_per_step_std": round(float(np.std(step_ms)), 3), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step_std": round(float(np.std(step_ms)), 3), "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"ProtoSAM.forward per 512x512 slice: DINOv2 ViT-B/14 + ALP + SAM {args.sam} "
                                f"(encoder + prompt encoder + mask decoder), synthetic CT-like volume",
@@ -230,6 +241,10 @@ def main():
     }
     if world == 1 and not args.no_extras:     # single-GPU legs (they would need the other ranks for the all-gather otherwise)
         res.update(extras(args, model, step, ops, psmod, B, torch, dev))
+        if not strong:
+            res["rank_of_8_strong"] = rank_of_8(args, model, vol_d, sup_imgs, sup_masks, dev, torch)
+        if not args.no_other_configs:
+            res["other_configs"] = other_configs(args, dev, torch, ops)
     cpu = parity = None
     if world == 1 and not args.no_cpu_baseline:
         cpu, parity = cpu_baseline(model, alp_sd, vol, svol, slab, args, dev)
@@ -317,6 +332,102 @@ def extras(args, model, step, ops, psmod, B, torch, dev):
         finally:
             alp.cache_support = True
     return out
+
+
+def rank_of_8(args, model, vol_d, sup_imgs, sup_masks, dev, torch):
+    """What ONE rank of an 8-rank strong-scaling job over the 64-slice volume runs per step (z = 0 mod 8: eight slices, batched per
+    z-part as the volume runner does), measured here on one GPU: the per-rank compute efficiency at N = 8 before hardware is."""
+    from protosam_amd.runner import run_slices
+    zs = strong_slices(args.slices, 8, 0)
+    run_slices(model, vol_d, sup_imgs, sup_masks, zs, dev, batch=len(zs))
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    n = 3
+    for _ in range(n):
+        run_slices(model, vol_d, sup_imgs, sup_masks, zs, dev, batch=len(zs))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / n
+    return {"slices_per_step": len(zs), "ms_per_step": round(dt * 1e3, 2), "slices_per_s_per_rank": round(len(zs) / dt, 2),
+            "note": "a rank's slices span the three z-parts (different support sets), so its micro-batches are 2-3 slices; x8 ranks = the "
+                    "compute-side ceiling of the 8-GPU strong-scaling number (the all-gather of 2 MiB of masks per rank is not in it)"}
+
+
+def other_configs(args, dev, torch, ops):
+    """BASELINE.json configs 2 / 3 / 5 as short legs (config 4 is the headline): slices/s and the GEMM rate of each."""
+    from protosam_amd.runner import build_protosam, part_assign, run_slices, support_set
+    from protosam_amd.synth import synth_volume
+    out = {}
+
+    def leg(name, fn, n_units, reps, unit="slices/s", note=""):
+        fn()
+        torch.cuda.synchronize()
+        timer = ops.KernelTimer()
+        ops.GEMM_TIMER = timer
+        t = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        ops.GEMM_TIMER = None
+        nl, tg, fl = timer.summary()
+        out[name] = {"value": round(reps * n_units / dt, 2), "unit": unit, "ms_per_call": round(dt / reps * 1e3, 2),
+                     "gemm_tflops": round(fl / tg / 1e12, 1) if tg > 0 else None,
+                     "gemm_frac_of_mfma_peak": round(fl / tg / 1e12 / PEAK_F16_TFLOPS, 4) if tg > 0 else None,
+                     "gemm_time_share": round(tg / dt, 3), "note": note}
+    # config 2: DINOv2 ViT-B/14 + ALP cosine-similarity map, 512x512, batch 1 (coarse prediction only)
+    m2, _ = build_protosam(dev, sam_type="vit_b", image_size=512, seed=1234, sam_depth=1, coarse_pred_only=True)
+    vol, _ = synth_volume(32, 512, seed=0, kind="mri")
+    svol, slab = synth_volume(32, 512, seed=1, kind="mri")
+    vol_d = vol.to(dev)
+    sup_imgs, sup_masks = support_set(svol.to(dev), slab.to(dev))
+    zs_part = [z for z in range(32) if part_assign(z, 32) == 1]
+    leg("config2", lambda: run_slices(m2, vol_d, sup_imgs, sup_masks, zs_part[:8], dev, batch=1), 8, 3,
+        note="DINOv2 ViT-B/14 + ALP prototype match only (coarse_pred_only), one ProtoSAM.forward per 512x512 slice, support cached")
+    leg("config2_batched", lambda: run_slices(m2, vol_d, sup_imgs, sup_masks, zs_part[:8], dev, batch=8), 8, 3,
+        note="the same through forward_batch, 8 slices together")
+    del m2
+    # config 3: + SAM ViT-B mask decoder, 512x512 MRI-like volume of 32 slices
+    m3, _ = build_protosam(dev, sam_type="vit_b", image_size=512, seed=1234)
+    zs = list(range(32))
+    leg("config3", lambda: run_slices(m3, vol_d, sup_imgs, sup_masks, zs, dev, batch=16), 32, 2,
+        note="full ProtoSAM with SAM ViT-B on the 32-slice MRI-like volume, 16-slice batches per z-part")
+    leg("config3_per_slice", lambda: run_slices(m3, vol_d, sup_imgs, sup_masks, zs[:16], dev, batch=1), 16, 2,
+        note="one ProtoSAM.forward per slice")
+    del m3
+    torch.cuda.empty_cache()
+    try:
+        out.update(config5_leg(dev, torch, ops, leg))
+    except Exception as e:   # (kept out of the headline's way)
+        out["config5"] = {"error": repr(e)}
+    return out
+
+
+def config5_leg(dev, torch, ops, leg):
+    """config 5: MedSAM ViT-B + a 4-class prototype bank on 1024x1024 slices: the query is encoded ONCE by DINOv2 at 1022^2 and matched
+    against the four banks (validation.py:207: four 1-way passes sharing one encoder forward), then MedSAM per class."""
+    from oracle.make_fullsize_goldens import cfg5_inputs   # (input generator only: seeded synthetic 4-organ slice)
+    from protosam_amd.grid_proto_fewshot import FewShotSeg
+    from protosam_amd.protomedsam import ProtoMedSAM
+    from protosam_amd.protosam import ALPNetWrapper
+    from protosam_amd.runner import ALP_CFG
+    from protosam_amd.synth import synth_state_dict
+    S = 1024
+    alp = FewShotSeg(S, None, dict(ALP_CFG))
+    alp.load_state_dict(synth_state_dict(alp, 1234))
+    alp = alp.to(dev).eval()
+    model = ProtoMedSAM((1024, 1024), ALPNetWrapper(alp), "random:vit_b:1234", use_cca=True).to(dev).eval()
+    s_img, s_masks, q_img = cfg5_inputs()
+    s_img, q_img = s_img.to(dev), q_img.to(dev)
+    s_masks = [m.to(dev) for m in s_masks]
+    res = {}
+    holder = {}
+
+    def run():
+        holder["out"] = model.forward_classes(q_img, s_img, s_masks)
+    leg("config5", run, 1, 3, unit="slices/s",
+        note="one 1024x1024 slice, 4 classes: one DINOv2 forward of the query at 1022^2 shared by the four prototype banks, MedSAM "
+             "ViT-B image encoder once, box-prompted decoder per class (ProtoMedSAM.forward_classes)")
+    return res
 
 
 def cpu_baseline(model, alp_sd, vol, svol, slab, args, dev):

@@ -1,6 +1,6 @@
 """Full-depth oracle taps for BASELINE.json configs 3 / 4 / 5 (test infrastructure; see oracle/__init__.py).
 
-  python oracle/make_fullsize_goldens.py [3] [4] [5]        # writes tests/golden/fullsize_cfg{3,4,5}.npz
+  python oracle/make_fullsize_goldens.py [3] [4] [5] [44]   # writes tests/golden/fullsize_cfg{3,4,5}.npz (44: cfg4_heavytail)
 
 The CPU oracle (pinned against the reference by oracle/validate_against_reference.py) is run ONCE, here in the build
 container, at the configurations' full model depth on seeded synthetic slices; `tests/test_fullsize_gpu.py` runs the HIP
@@ -40,7 +40,7 @@ CFG4_SLICES = (8, 32, 56)
 CFG5_SEED = 2
 
 
-def _weights(sam_type, image_size):
+def _weights(sam_type, image_size, heavy_tail=False):
     from protosam_amd.grid_proto_fewshot import FewShotSeg
     from protosam_amd.runner import ALP_CFG
     from protosam_amd.segment_anything import sam_model_registry
@@ -48,6 +48,9 @@ def _weights(sam_type, image_size):
     alp_sd = synth_state_dict(FewShotSeg(image_size, None, dict(ALP_CFG)), 1234)
     enc_sd = {k[len("encoder."):]: v for k, v in alp_sd.items() if k.startswith("encoder.")}
     sam_sd = synth_state_dict(sam_model_registry[sam_type](), 1234)
+    if heavy_tail:
+        from protosam_amd.synth import heavy_tail_sam_
+        heavy_tail_sam_(sam_sd, 1234)
     return enc_sd, sam_sd
 
 
@@ -55,6 +58,8 @@ def volume_config(cfg):
     """-> (sam_type, n_slices, kind, slices, flag sets) of configs 3 / 4."""
     if cfg == 3:
         return "vit_b", 32, "mri", CFG3_SLICES, {"default": dict(use_cca=False), "cca": dict(use_cca=True)}
+    if cfg == 44:   # config 4 with the heavy-tailed SAM weights of synth.heavy_tail_sam_ (stress case of the fp16 operand path)
+        return "vit_h", 64, "ct", (32,), {"default": dict(use_cca=False)}
     return "vit_h", 64, "ct", CFG4_SLICES, {"default": dict(use_cca=False)}
 
 
@@ -63,7 +68,7 @@ def make_volume_config(cfg):
     from protosam_amd.runner import part_assign, support_set
     from protosam_amd.synth import synth_volume
     sam_type, n, kind, slices, flagsets = volume_config(cfg)
-    enc_sd, sam_sd = _weights(sam_type, 512)
+    enc_sd, sam_sd = _weights(sam_type, 512, heavy_tail=(cfg == 44))
     vol, lab = synth_volume(n, 512, seed=0, kind=kind)
     svol, slab = synth_volume(n, 512, seed=1, kind=kind)
     sup_imgs, sup_masks = support_set(svol, slab)
@@ -87,7 +92,7 @@ def make_volume_config(cfg):
                 out[k + "_prob"] = prob16(torch.stack([l[0] for l in taps["low_res"]]))
         out[f"z{z}_coarse_p"] = torch.round(logits.double().softmax(1)[0, 1, ::4, ::4] * 65535.0).numpy().astype(np.uint16)
         print(f"config {cfg} z={z}: {len(scores)} component(s), fg {int(pred.sum())} px, {time.time() - t0:.0f}s", flush=True)
-    path = os.path.join(GOLD, f"fullsize_cfg{cfg}.npz")
+    path = os.path.join(GOLD, f"fullsize_cfg{cfg}.npz" if cfg != 44 else "fullsize_cfg4_heavytail.npz")
     np.savez_compressed(path, **out)
     print(f"wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
 

@@ -577,7 +577,7 @@ def check_orchestration(gold, tmpdir):
             d = int((m_o.numpy() != m_r).sum())
             print(f"  [{'ok' if d <= 4 else 'FAIL'}] predictor {name}: {d} differing mask pixels of {m_r.size}")
             assert d <= 4
-        gold[f"pred_{name}_low"] = low_r[..., ::2, ::2].astype(np.float16)
+        gold[f"pred_{name}_low"] = low_r[..., ::2, ::2].astype(np.float32)     # fp32: the 1e-3 bound is asserted without slack
         gold[f"pred_{name}_iou"] = s_r.astype(np.float32)
     with torch.no_grad():
         predictor.reset_image()
@@ -627,7 +627,7 @@ def _protosam_flag_cases(gold, ref_ps, gi, glue, q, S, D, logits, sam_sd, ckpt, 
         gold[f"orch_{name}_mask"] = _pack(pred_r.numpy())
         gold[f"orch_{name}_scores"] = np.array([float(v) for v in scores_r], dtype=np.float32)
         # the oracle's low-res logits (bit-equal to the reference's by the mask / score checks above), every 4th pixel
-        gold[f"orch_{name}_low"] = torch.stack([torch.as_tensor(l) for l in taps["low_res"]])[..., ::4, ::4].numpy().astype(np.float16)
+        gold[f"orch_{name}_low"] = torch.stack([torch.as_tensor(l) for l in taps["low_res"]])[..., ::4, ::4].numpy().astype(np.float32)
 
 
 def _orchestration_rest(gold, tmpdir, ref_ps, ref_pm, gi, glue, oalp, odino, q, S, D, logits, sam_sd, ckpt, feats, inp):

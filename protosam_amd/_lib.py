@@ -23,6 +23,7 @@ SIGNATURES = {
     "psam_ln_finalize": [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p],
     "psam_gemm_set_tile": [c_int],
     "psam_gemm_asm_variant": [c_int],
+    "psam_gemm_set_option": [ctypes.c_char_p, c_int],
     "psam_gemm_set_workspace": [c_void_p, c_size_t],
     "psam_layernorm": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                        c_int, c_int, c_void_p],

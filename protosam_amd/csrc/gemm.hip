@@ -21,6 +21,7 @@
 #include "common.h"
 #include "gemm_asm_meta.h"   // generated: PSAM_ASM2_E_* (gemm_asm_gen.py --meta)
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 #include <map>
 #include <string>
@@ -1027,12 +1028,25 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   *reinterpret_cast<float4*>(out + (size_t)m * ldo + n) = v;
 }
 
-static float* g_ks_ws = nullptr;
-static size_t g_ks_ws_bytes = 0;
+// The workspace is registered per DEVICE (the device current at registration), and users on different streams are ordered through an
+// event: a split-K GEMM on stream B first waits for the previous user's reduce pass on stream A (ProtoSAM.overlap_streams runs the two
+// encoders on two streams; both may take this path).
+struct KsWorkspace { float* ptr = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; hipStream_t last = nullptr; bool used = false; };
+static std::map<int, KsWorkspace> g_ks;
+static KsWorkspace* ks_workspace() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  auto it = g_ks.find(dev);
+  return it == g_ks.end() || !it->second.ptr ? nullptr : &it->second;
+}
 extern "C" int psam_gemm_set_workspace(void* ptr, size_t bytes) {   // device scratch for the split-K partial sums (null: no split-K)
   if (ptr && (reinterpret_cast<uintptr_t>(ptr) & 15)) return PSAM_ERR_ARG;
-  g_ks_ws = (float*)ptr;
-  g_ks_ws_bytes = ptr ? bytes : 0;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  KsWorkspace& w = g_ks[dev];
+  w.ptr = (float*)ptr;
+  w.bytes = ptr ? bytes : 0;
+  w.used = false;
   return PSAM_OK;
 }
 
@@ -1046,12 +1060,18 @@ static void launch8kp_splitk(const GemmArgs& p, hipStream_t s) {
   const int ntm = (p.M + 255) / 256, ntn = p.N / 256;
   GemmArgs q = p;
   q.map_mode = 1;   // identity map: the items of one tile are neighbours
-  q.ks_ws = g_ks_ws;
+  KsWorkspace* w = ks_workspace();
+  q.ks_ws = w->ptr;
+  if (w->used && w->last != s) (void)hipStreamWaitEvent(s, w->done, 0);   // another stream's partial sums may still be in the planes
   const int total = ntm * ntn * q.ksplit;
   hipLaunchKernelGGL((gemm8kp_f16_kernel<EPI_F32, false, true>), dim3(total < num_cus() ? total : num_cus()), dim3(512), LDS, s, q, total);
   const size_t n4 = (size_t)p.M * (p.N / 4);
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, g_ks_ws, q.ksplit, p.bias, p.gamma,
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, w->ptr, q.ksplit, p.bias, p.gamma,
                      p.resid, p.ldr, p.resid_mod, reinterpret_cast<float*>(p.out), p.ldo, p.M, p.N);
+  if (!w->done) (void)hipEventCreateWithFlags(&w->done, hipEventDisableTiming);
+  (void)hipEventRecord(w->done, s);
+  w->last = s;
+  w->used = true;
 }
 
 
@@ -1201,6 +1221,20 @@ static int launch_asm(const GemmArgs& p, int epilogue, hipStream_t s, int family
 // waves, the default large tile); 16 = the half-tile ping-pong assembly kernels of gemm_asm2_gen.py (experimental). The other
 // HIP schedules of rounds 1 / 2 (tiles 2 ... 10, 13, 14) lost to these and are gone (history: DESIGN.md).
 // (PSAM_GEMM_TILE env var or psam_gemm_set_tile)
+// dispatch switches (A/B and tests): initial values from the environment, psam_gemm_set_option overrides at run time
+enum { OPT_ASM = 0, OPT_HALF, OPT_SPLITK, OPT_NSPLIT, OPT_COUNT };
+static const char* const g_opt_names[OPT_COUNT] = {"asm", "half_tiles", "splitk", "nsplit"};
+static const char* const g_opt_env[OPT_COUNT] = {"PSAM_GEMM_ASM", "PSAM_GEMM_HALF", "PSAM_GEMM_SPLITK", "PSAM_GEMM_NSPLIT"};
+static int g_opt[OPT_COUNT] = {-1, -1, -1, -1};
+static int gemm_option(int i) {
+  if (g_opt[i] < 0) { const char* e = getenv(g_opt_env[i]); g_opt[i] = e ? (atoi(e) != 0) : 1; }
+  return g_opt[i];
+}
+extern "C" int psam_gemm_set_option(const char* name, int value) {
+  for (int i = 0; i < OPT_COUNT; ++i)
+    if (name && strcmp(name, g_opt_names[i]) == 0) { g_opt[i] = value != 0; return PSAM_OK; }
+  return PSAM_ERR_ARG;
+}
 static int g_tile_override = -1;
 extern "C" int psam_gemm_set_tile(int t) {
   g_tile_override = t;
@@ -1225,17 +1259,15 @@ static int pick_tile(int M, int N, int K, int epilogue) {
     // 128-tile one (tools/gemm_tiles.py 1,11: qkv 790-820 vs 750, proj 730-760 vs 500-620, fc1 870 vs 740 TFLOP/s; fp32 epilogue
     // 557 vs 497); per-slice calls (M = 1297) fail the fill test and stay on the 128-tile kernel (350 vs 200)
     if (K >= 768 && t256 * 100 >= rounds * ncu * (short_f32 ? 95 : 80)) {
-      static int asm_on = -1;   // the assembly kernels (tile 15) take every shape the persistent HIP kernel took, when eligible (gemm_dispatch)
-      if (asm_on < 0) { const char* e = getenv("PSAM_GEMM_ASM"); asm_on = e ? atoi(e) : 1; }
-      return asm_on ? 15 : 11;
+      // the assembly kernels (tile 15) take every shape the persistent HIP kernel took, when eligible (gemm_dispatch)
+      return gemm_option(OPT_ASM) ? 15 : 11;
     }
   }
   // too few 256x256 tiles for the CUs (one slice through proj / fc1 / fc2: 80 ... 320 tiles): the half-tile assembly kernels have
   // twice the work items (4096x1280x5120: 852 vs 576 TFLOP/s on tile 15, 671 split-K; 4096x5120x1280: 832 vs 734; gemm_dispatch
   // falls back to the 128x128 kernel when their layout rules or minimum K are not met)
   if (N % 128 == 0 && K >= 768) {
-    static int half_on = -1;
-    if (half_on < 0) { const char* e = getenv("PSAM_GEMM_HALF"); half_on = e ? atoi(e) : 1; }
+    const int half_on = gemm_option(OPT_HALF);
     const long th = (long)((M + 255) / 256) * (N / 128), ncu = num_cus();
     if (half_on && th * 2 >= ncu) return 16;
   }
@@ -1310,10 +1342,10 @@ static int gemm_dispatch(const void* A, const void* W, const float* bias, void* 
   // exist, every K range keeps >= 16 K-tiles (the partial stores + the reduce pass cost about as much as 12) and the
   // registered workspace holds the partial sums
   {
-    static int ks_on = -1;
-    if (ks_on < 0) { const char* e = getenv("PSAM_GEMM_SPLITK"); ks_on = e ? atoi(e) : 1; }
+    const int ks_on = gemm_option(OPT_SPLITK);
     const bool auto_sel = g_tile_override <= 0;
-    if (ks_on && auto_sel && g_ks_ws && tsel == 1 && epilogue == EPI_F32 && !ln_prod && !ln_cons && !head_hd && N % 256 == 0 &&
+    const KsWorkspace* ksw = ks_workspace();
+    if (ks_on && auto_sel && ksw && tsel == 1 && epilogue == EPI_F32 && !ln_prod && !ln_cons && !head_hd && N % 256 == 0 &&
         out_seg == 0 && (ldo % 4) == 0) {
       const int t256 = ((M + 255) / 256) * (N / 256), nkt = K / 64;
       // measured (tools/gemm_splitk_bench.py, us split / 128-tile): 4096x1280x5120 (3 ranges of 26-27 K-tiles, 240 items) 80 / 108;
@@ -1322,7 +1354,7 @@ static int gemm_dispatch(const void* A, const void* W, const float* bias, void* 
       int ks = num_cus() / t256;
       if (ks > nkt / 24) ks = nkt / 24;
       if (ks > 8) ks = 8;
-      while (ks >= 2 && (size_t)ks * M * N * sizeof(float) > g_ks_ws_bytes) --ks;
+      while (ks >= 2 && (size_t)ks * M * N * sizeof(float) > ksw->bytes) --ks;
       if (ks >= 2 && t256 * ks * 4 >= num_cus() * 3) {
         p.ksplit = ks;
         launch8kp_splitk(p, s);
@@ -1369,8 +1401,7 @@ extern "C" int psam_gemm_f16(const void* A, const void* W, const float* bias, vo
   // the columns that fill the CUs exactly once go to the persistent kernel, the rest to whatever the picker chooses for
   // them (every kernel accumulates an element's K-tiles in the same order, so the results do not depend on the split).
   {
-    static int ns_on = -1;
-    if (ns_on < 0) { const char* e = getenv("PSAM_GEMM_NSPLIT"); ns_on = e ? atoi(e) : 1; }
+    const int ns_on = gemm_option(OPT_NSPLIT);
     const int ncu = num_cus();
     const int ntm = (M + 255) / 256;
     if (ns_on && g_tile_override <= 0 && (epilogue == EPI_F16 || epilogue == EPI_GELU_F16) && out_seg == 0 && N % 256 == 0 &&

@@ -191,6 +191,38 @@ class FewShotSeg(nn.Module):
         qry_view = qry_tok.unflatten(1, (g, g)).unsqueeze(0).permute(0, 1, 4, 2, 3)   # zero-copy [1,B,C,g,g]
         return output, 0.0, [None, None], None, None, supp_view, qry_view
 
+    @torch.no_grad()
+    def forward_classes(self, supp_img, fore_masks, qry_img, isval=True, val_wsize=None):
+        """Several 1-way episodes on the SAME support / query image pair (the multi-class loop of /root/reference/validation.py:207,
+        BASELINE config 5: one prototype bank per class): the support and the query image are each encoded ONCE and the query
+        tokens are matched against every class's bank. fore_masks: list of [1,H,W] masks. Returns a list of logits [1,2,H,W],
+        each identical to `forward(...)` of that class alone."""
+        S, g = self._grid()
+        C = self.encoder.embed_dim
+        img_size = supp_img.shape[-2:]
+        pool_w = val_wsize if (isval and val_wsize is not None) else self.cls_unit.kernel_size[0]
+        key = (supp_img, supp_img._version, tuple((m, m._version) for m in fore_masks), pool_w, getattr(self.encoder, "_weights_epoch", 0))
+        hit = getattr(self, "_cls_cache", None)
+        if (self.cache_support and hit is not None and hit[0][0] is supp_img and hit[0][1] == key[1] and hit[0][3:] == key[3:]
+                and len(hit[0][2]) == len(key[2]) and all(a[0] is b[0] and a[1] == b[1] for a, b in zip(hit[0][2], key[2]))):
+            banks = hit[1]
+        else:
+            t, _, _ = self._patch_tokens(supp_img)
+            tok = t[0].clone()
+            banks = []
+            for fg in fore_masks:
+                fg2 = fg.reshape(fg.shape[-2], fg.shape[-1]).float().contiguous()
+                banks.append(self.cls_unit.build_bank(tok, C, g, g, fg2, pool_w, FG_THRESH, force_mode=-1, bank=None, bg_mask=None))
+            self._cls_cache = (key, banks)
+        qry_tok, q_bstride, q_ld = self._patch_tokens(qry_img)
+        B = qry_tok.shape[0]
+        outs = []
+        for bank in banks:
+            pred = self.cls_unit.scores_token_major(qry_tok, q_bstride, q_ld, B, g * g, bank)
+            self._check_bank(bank)
+            outs.append(ops.bilinear_nchw(pred.view(B, 2, g, g), img_size[0], img_size[1]))
+        return outs
+
     def _check_bank(self, bank):
         """The reference raises inside F.conv2d when a bank is empty (alpmodule.py:193-196). One 8-int D2H read."""
         if self.config.get("skip_bank_check", False):

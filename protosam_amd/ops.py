@@ -107,7 +107,7 @@ def gemm(a, w, bias=None, out=None, epilogue=EPI_F16, resid=None, gamma=None, re
     if fold:
         _req(out16, torch.float16, "out16"); _req(stats, torch.float32, "stats")
         _req(ln_mr, torch.float32, "ln_mr"); _req(ln_s, torch.float32, "ln_s")
-    if epilogue == EPI_F32 and _GEMM_WS is None:
+    if epilogue == EPI_F32 and a.device.index not in _GEMM_WS:
         _ensure_gemm_workspace(a.device)
     t0 = GEMM_TIMER.start() if GEMM_TIMER is not None else None
     if fold:
@@ -168,23 +168,32 @@ def gemm_heads(a, w, bias, hd, out=None, M=None):
     return out
 
 
-_GEMM_WS = None
+_GEMM_WS = {}     # device index -> scratch buffer registered with the library for that device
 GEMM_WORKSPACE_MB = int(_os.environ.get("PSAM_GEMM_WORKSPACE_MB", "64"))
 
 
 def _ensure_gemm_workspace(device):
     """Scratch for the split-K form of the fp32-residual GEMM (csrc/gemm.hip launch8kp_splitk): partial sums of one slice through
-    fc2 are 63 MB. Allocated once per process from torch's allocator and registered with the library; 0 MB = no split-K."""
-    global _GEMM_WS
-    if _GEMM_WS is None:
+    fc2 are 63 MB. Allocated once per DEVICE from torch's allocator and registered with the library for that device (the library
+    orders users on different streams through an event); 0 MB = no split-K."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _GEMM_WS:
         n = GEMM_WORKSPACE_MB << 20
-        _GEMM_WS = torch.empty(max(n, 16), dtype=torch.uint8, device=device)
-        _lib.check(_lib.lib().psam_gemm_set_workspace(_GEMM_WS.data_ptr() if n else 0, n), "psam_gemm_set_workspace")
+        with torch.cuda.device(idx):
+            buf = torch.empty(max(n, 16), dtype=torch.uint8, device=torch.device("cuda", idx))
+            _lib.check(_lib.lib().psam_gemm_set_workspace(buf.data_ptr() if n else 0, n), "psam_gemm_set_workspace")
+        _GEMM_WS[idx] = buf
+        _GEMM_WS[None] = buf
 
 
 def gemm_set_tile(tile):
     """0 auto, 1 = 128x128, 2 = 256x128, 3 = 256x256 (see csrc/gemm.hip)."""
     _lib.check(_lib.lib().psam_gemm_set_tile(int(tile)), "psam_gemm_set_tile")
+
+
+def gemm_set_option(name, value):
+    """Dispatch switches of the GEMM: "asm", "half_tiles", "splitk", "nsplit" (see include/protosam_hip.h)."""
+    _lib.check(_lib.lib().psam_gemm_set_option(name.encode(), int(bool(value))), "psam_gemm_set_option")
 
 
 def gemm_asm_variant(v):

@@ -126,3 +126,71 @@ class ProtoMedSAM(nn.Module):
         seg = ops.mask_union(masks, 0, S, original_size, 3, 0.5)                           # sigmoid -> bilinear -> > 0.5
         self.last_stats.update(low_res=masks, iou=iou)
         return seg.to(torch.uint8), [iou[:, 0:1].cpu().numpy()]
+
+    @torch.no_grad()
+    def forward_classes(self, query_image, support_image, support_masks, val_wsize=2):
+        """Throughput path of the multi-class loop (BASELINE config 5; /root/reference/validation.py:207 runs one 1-way episode per
+        class on the same slice): ONE DINOv2 forward of the query (and of the support) shared by all classes' prototype banks, ONE
+        MedSAM image-encoder forward of the query, one batched box-prompt decoder call for all classes. Returns a list of
+        (uint8 mask [H,W], [conf]) per class, equal to `forward()` of each class alone (same arithmetic; the decoder batches).
+        Only `use_cca=True` (one component per class), as `forward()`."""
+        if not self.use_cca or self.coarse_pred_only:
+            raise NotImplementedError("forward_classes: use_cca=True, coarse_pred_only=False")
+        original_size = query_image.shape[-2]
+        dev = query_image.device
+        alp = self.coarse_segmentation_model.model
+        logits = alp.forward_classes(support_image, support_masks, query_image, isval=True, val_wsize=val_wsize)
+        bufs = self._work(dev)
+        sam = self.medsam
+        S = sam.image_encoder.img_size
+        nc = len(logits)
+        if len(getattr(self, "_cls_ws", [])) < nc:
+            self._cls_ws = [dict(ccl=ops.CclWorkspace(1024, 1024, MAX_COMPONENTS, dev), fg=torch.zeros(1, dtype=torch.int32, device=dev),
+                                 prob=torch.empty((1, 2, 1024, 1024), dtype=torch.float32, device=dev),
+                                 pred=torch.empty((1, 1024, 1024), dtype=torch.uint8, device=dev)) for _ in range(nc)]
+        cws = []
+        for c, lg in enumerate(logits):
+            w = self._cls_ws[c]
+            w["fg"].zero_()
+            output_p, pred = ops.prob_argmax(lg.float().contiguous(), S, S, prob=w["prob"], pred=w["pred"], fg_sum=w["fg"])
+            p2, _ = ops.prob_argmax(output_p, S, S, prob=bufs["prob2"], pred=bufs["pred2"])
+            cw = ops.ccl(pred[0], p2[0, 1], w["ccl"], fg_sum=w["fg"])
+            cw.tab_host.copy_(cw.tab, non_blocking=True)
+            cws.append(cw)
+        bufs["event"].record()
+        q = query_image.float().contiguous()
+        if tuple(q.shape[-2:]) != (S, S):
+            q = ops.bilinear_nchw(q, S, S, out=bufs["q1024"])
+        ops.minmax(q, 1, mm=bufs["mm"])
+        ops.sam_patchify(q, bufs["mm"], S, sam.image_encoder.patch_size, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), False, out=bufs["patches"])
+        feat_tok = sam.image_encoder.encode_patches(bufs["patches"], 1)[0]
+        bufs["event"].synchronize()
+        results = [None] * nc
+        boxes, owners = [], []
+        for c, cw in enumerate(cws):
+            tab = cw.tab_host.numpy()
+            if int(tab[0]) > int(tab[1]):
+                raise RuntimeError(f"class {c}: {int(tab[0])} connected components exceed the fast table; use forward() for this slice")
+            n = int(tab[1])
+            if n == 0:
+                results[c] = (torch.zeros((original_size, original_size), dtype=torch.int64, device=dev), [0])
+                continue
+            rows = tab[ops.CC_HDR:ops.CC_HDR + ops.CC_STRIDE * n].reshape(n, ops.CC_STRIDE)
+            row = rows[int(tab[3])]
+            boxes.append(row[3:7] / np.array([S, S, S, S]) * max(self.image_size))
+            owners.append(c)
+        self.last_stats = dict(n_classes=nc, n_prompted=len(owners))
+        if owners:
+            coords = np.stack(boxes).reshape(-1, 2, 2).astype(np.float32)
+            labels = np.tile(np.array([[2, 3]], dtype=np.int32), (coords.shape[0], 1))
+            pe = sam.prompt_encoder._packed()
+            dpk = sam.mask_decoder._packed()
+            tokens = ops.prompt_tokens(torch.from_numpy(coords).to(dev), torch.from_numpy(labels).to(dev), pe["G"], pe["type_emb"],
+                                       dpk["out_tok"], coords.shape[0], 2, float(S))
+            masks, iou, _ = sam.mask_decoder.predict_masks_tokens(feat_tok, pe["pe_tok"], tokens, pe["no_mask"])
+            iou_h = iou[:, 0:1].cpu().numpy()
+            for k, c in enumerate(owners):
+                seg = ops.mask_union(masks[k:k + 1], 0, S, original_size, 3, 0.5)
+                results[c] = (seg.to(torch.uint8).clone(), [iou_h[k:k + 1]])
+            self.last_stats.update(low_res=masks, iou=iou)
+        return results

@@ -268,18 +268,21 @@ class ProtoSAM(nn.Module):
 
     def get_sam(self, checkpoint_path, use_sam_trans):
         """ProtoSAM.py:205-220. `random:<vit_b|vit_l|vit_h>[:seed[:depth]]` builds seeded synthetic weights instead of reading a
-        checkpoint (none exist offline)."""
+        checkpoint (none exist offline); `random-heavy:...` the same with the heavy-tailed residual stream of synth.heavy_tail_sam_."""
         model_type = "vit_b"
         if checkpoint_path is not None and "vit_h" in checkpoint_path:
             model_type = "vit_h"
-        if checkpoint_path is not None and checkpoint_path.startswith("random:"):
-            from .synth import synth_state_dict
+        if checkpoint_path is not None and checkpoint_path.startswith(("random:", "random-heavy:")):
+            from .synth import heavy_tail_sam_, synth_state_dict
             parts = checkpoint_path.split(":")
             model_type = parts[1]
             seed = int(parts[2]) if len(parts) > 2 else 1234
             depth = int(parts[3]) if len(parts) > 3 else None   # test hook: truncated block stack
             self.sam = sam_model_registry[model_type](encoder_depth=depth)
-            self.sam.load_state_dict(synth_state_dict(self.sam, seed))
+            sd = synth_state_dict(self.sam, seed)
+            if parts[0] == "random-heavy":
+                heavy_tail_sam_(sd, seed)
+            self.sam.load_state_dict(sd)
             self.sam.eval()
         else:
             self.sam = sam_model_registry[model_type](checkpoint=checkpoint_path).eval()

@@ -18,7 +18,7 @@ ALP_CFG = {"which_model": "dinov2_b14", "cls_name": "grid_proto", "proto_grid_si
 
 
 def build_protosam(device, sam_type="vit_h", image_size=512, seed=1234, dino_depth=None, sam_depth=None,
-                   cache_support=True, **protosam_kw):
+                   cache_support=True, heavy_tail=False, **protosam_kw):
     """Seeded synthetic-weight ProtoSAM as validation_protosam.get_model builds it (:188-232)."""
     cfg = dict(ALP_CFG)
     if dino_depth is not None:
@@ -27,7 +27,7 @@ def build_protosam(device, sam_type="vit_h", image_size=512, seed=1234, dino_dep
     alp_sd = synth_state_dict(alp, seed)
     alp.load_state_dict(alp_sd)
     alp = alp.to(device).eval()
-    spec = f"random:{sam_type}:{seed}" + (f":{sam_depth}" if sam_depth is not None else "")
+    spec = ("random-heavy" if heavy_tail else "random") + f":{sam_type}:{seed}" + (f":{sam_depth}" if sam_depth is not None else "")
     kw = dict(use_bbox=True, use_points=True, point_mode="both", use_cca=False, num_points_for_sam=1,
               use_sam_trans=True)
     kw.update(protosam_kw)

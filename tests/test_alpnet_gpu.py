@@ -235,7 +235,7 @@ def test_resnet101_encoder_and_config1_fewshot(dev):
     assert out.shape == (1, 2, 256, 256)
     perr = (out.cpu().softmax(1) - logits_ref.softmax(1)).abs().max().item()
     print(f"config 1 coarse probability map: max abs err {perr:.3e}")
-    assert perr < 5e-3
+    assert perr < 1e-3          # north-star tolerance (measured 4.4e-4)
     with pytest.raises(NotImplementedError):                                    # get_features has no 'default' branch
         bad = FewShotSeg(256, None, dict(cfg, which_model="default", resnet_layers=(1, 1, 1, 1))).to(dev).eval()
         bad.get_features(imgs.to(dev))

@@ -3,7 +3,7 @@
 pinned to the reference by oracle/validate_against_reference.py).
 
   config 3: DINOv2 ViT-B/14 x12 + ALP + SAM ViT-B x12 on the 32-slice MRI-like volume (default flags and use_cca)
-  config 4: ... + SAM ViT-H x32 on the 64-slice CT-like volume (the benchmark's workload)
+  config 4: ... + SAM ViT-H x32 on the 64-slice CT-like volume (the benchmark's workload); also with heavy-tailed SAM weights
   config 5: DINOv2 ViT-B/14 x12 at 1022^2 + MedSAM ViT-B x12, 1024x1024 slice, four classes
 
 The north-star tolerance is asserted as written: |sigmoid(low_res_masks) - reference| <= 1e-3 and the coarse probability map
@@ -31,18 +31,21 @@ def _volume_setup(dev, cfg):
     from protosam_amd.runner import build_protosam, support_set
     from protosam_amd.synth import synth_volume
     sam_type, n, kind, slices, flagsets = volume_config(cfg)
-    model, _ = build_protosam(dev, sam_type=sam_type, image_size=512, seed=1234)
+    model, _ = build_protosam(dev, sam_type=sam_type, image_size=512, seed=1234, heavy_tail=(cfg == 44))
     vol, _ = synth_volume(n, 512, seed=0, kind=kind)
     svol, slab = synth_volume(n, 512, seed=1, kind=kind)
     sup_imgs, sup_masks = support_set(svol.to(dev), slab.to(dev))
     return model, vol.to(dev), sup_imgs, sup_masks, n, slices, flagsets
 
 
-@pytest.mark.parametrize("cfg", [3, 4])
+@pytest.mark.parametrize("cfg", [3, 4, 44])
 def test_config_full_depth_vs_oracle_record(dev, cfg):
+    """cfg 44 = config 4 with heavy-tailed SAM ViT-H weights (synth.heavy_tail_sam_: channel scales over 1.5 decades, 'massive
+    activation' channels in the hundreds, Student-t output projections): the fp16-operand path is held to the same 1e-3 where
+    the residual stream looks like a trained checkpoint's, not only on well-conditioned Gaussian weights."""
     from protosam_amd.metrics import dice
     from protosam_amd.runner import run_slices
-    gold = np.load(os.path.join(GOLD, f"fullsize_cfg{cfg}.npz"))
+    gold = np.load(os.path.join(GOLD, f"fullsize_cfg{cfg}.npz" if cfg != 44 else "fullsize_cfg4_heavytail.npz"))
     model, vol_d, sup_imgs, sup_masks, n, slices, flagsets = _volume_setup(dev, cfg)
     worst = 0.0
     for fname, fl in flagsets.items():
@@ -129,3 +132,48 @@ def test_config5_full_depth_vs_oracle_record(dev):
         # (the smallest organ is ~900 px: a handful of threshold flips on its border is already 0.002 of Dice)
         assert cerr <= TOL and perr <= TOL and ce <= TOL and (d >= 0.998 or flips <= 8)
     assert ran == 4
+
+
+def test_config5_forward_classes_equals_per_class_forward(dev):
+    """`ProtoMedSAM.forward_classes` (one DINOv2 forward of the query shared by the four prototype banks, one MedSAM encoder
+    forward, one batched decoder call) against the four separate `forward()` calls the reference's multi-class loop makes
+    (validation.py:207), and against the oracle record."""
+    from oracle.make_fullsize_goldens import cfg5_inputs
+    from protosam_amd.grid_proto_fewshot import FewShotSeg
+    from protosam_amd.metrics import dice
+    from protosam_amd.protomedsam import ProtoMedSAM
+    from protosam_amd.protosam import ALPNetWrapper, InputFactory, TYPE_ALPNET
+    from protosam_amd.runner import ALP_CFG
+    from protosam_amd.synth import synth_state_dict
+    gold = np.load(os.path.join(GOLD, "fullsize_cfg5.npz"))
+    S = 1024
+    alp = FewShotSeg(S, None, dict(ALP_CFG))
+    alp.load_state_dict(synth_state_dict(alp, 1234))
+    alp = alp.to(dev).eval()
+    model = ProtoMedSAM((1024, 1024), ALPNetWrapper(alp), "random:vit_b:1234", use_cca=True).to(dev).eval()
+    s_img, s_masks, q_img = cfg5_inputs()
+    s_d, q_d, m_d = s_img.to(dev), q_img.to(dev), [m.to(dev) for m in s_masks]
+    res = model.forward_classes(q_d, s_d, m_d)
+    low_all = model.last_stats["low_res"].cpu()
+    assert len(res) == 4
+    k = 0
+    for ci, m in enumerate(s_masks):
+        inp = InputFactory.create_input(TYPE_ALPNET, q_img, support_images=[s_img], support_labels=[m], isval=True, val_wsize=2)
+        inp.to(dev)
+        seg1, conf1 = model(q_d, inp)
+        seg, conf = res[ci]
+        assert seg.shape == seg1.shape
+        flips = int((seg.cpu() != seg1.cpu()).sum())
+        ref_mask = _unpack(gold[f"class{ci}_mask"], S)
+        d = dice(seg.cpu().float(), ref_mask)
+        if f"class{ci}_prob" in gold.files:
+            perr = (torch.sigmoid(low_all[k, 0]) - torch.from_numpy(gold[f"class{ci}_prob"].astype(np.float32) / 65535.0)).abs().max().item()
+            cerr = float(np.abs(np.asarray(conf[0]) - np.asarray(conf1[0])).max())
+            k += 1
+            print(f"class {ci}: {flips} px differ from the per-class forward, conf diff {cerr:.2e}; vs oracle record: max |dprob| {perr:.2e}, Dice {d:.5f}")
+            assert flips <= 4 and cerr <= 1e-4 and perr <= TOL
+        else:
+            assert int(seg.sum()) == 0
+    # the second call (same support objects) reuses the cached banks and gives the same result
+    res2 = model.forward_classes(q_d, s_d, m_d)
+    assert all(torch.equal(a[0], b[0]) for a, b in zip(res, res2))

@@ -160,7 +160,7 @@ def test_gemm_inplace_residual(dev):
 
 @pytest.mark.parametrize("M,N,K,ks", [(4096, 1280, 5120, 3), (4000, 1280, 5120, 3), (2048, 2048, 6144, 4), (8192, 256, 16384, 8),
                                       (1297, 768, 3072, 1), (4096, 1280, 1280, 1)])
-def test_gemm_splitk_residual(dev, M, N, K, ks):
+def test_gemm_splitk_residual(dev, request, M, N, K, ks):
     """The residual update of few 256-tiles over a long K (one slice through fc2) takes the split-K form of the persistent
     kernel: several workgroups per tile write partial sums, a reduce pass applies bias, LayerScale and the residual in a fixed
     order. Against a float64 product and against the single-pass 128x128 kernel (forced tile 1: no split).
@@ -172,6 +172,8 @@ def test_gemm_splitk_residual(dev, M, N, K, ks):
     gamma = _rand((N,), dev, 1.0, 5)
     x0 = _rand((M, N), dev, 1.0, 3)
     ref = (x0.double() + gamma.double() * (a.double() @ w.double().t() + bias.double())).float()
+    ops.gemm_set_option("half_tiles", 0)     # (the half-tile assembly kernels would take these shapes first)
+    request.addfinalizer(lambda: ops.gemm_set_option("half_tiles", 1))
     x = x0.clone()
     ops.gemm(a, w, bias, out=x, epilogue=ops.EPI_F32, resid=x, gamma=gamma)
     y = x0.clone()
@@ -198,7 +200,33 @@ def test_gemm_splitk_residual(dev, M, N, K, ks):
     assert (zp - refp).abs().max().item() < tol
 
 
-def test_gemm_splitk_needs_a_registered_workspace(dev):
+def test_gemm_splitk_two_streams_share_the_workspace(dev, request):
+    """Two streams taking the split-K path at the same time (ProtoSAM.overlap_streams runs the two encoders on two streams): the
+    library orders the users of the per-device workspace through an event, so both results equal the single-stream ones."""
+    from protosam_amd import ops
+    ops.gemm_set_option("half_tiles", 0)
+    request.addfinalizer(lambda: ops.gemm_set_option("half_tiles", 1))
+    M, N, K = 4096, 1280, 5120
+    a1, a2 = _rand((M, K), dev, 1.0, 71).half(), _rand((M, K), dev, 1.0, 72).half()
+    w = _rand((N, K), dev, 0.05, 73).half()
+    x0 = _rand((M, N), dev, 1.0, 74)
+    r1, r2 = x0.clone(), x0.clone()
+    ops.gemm(a1, w, None, out=r1, epilogue=ops.EPI_F32, resid=r1)
+    ops.gemm(a2, w, None, out=r2, epilogue=ops.EPI_F32, resid=r2)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(5):
+        y1, y2 = x0.clone(), x0.clone()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s1):
+            ops.gemm(a1, w, None, out=y1, epilogue=ops.EPI_F32, resid=y1)
+        with torch.cuda.stream(s2):
+            ops.gemm(a2, w, None, out=y2, epilogue=ops.EPI_F32, resid=y2)
+        torch.cuda.synchronize()
+        assert torch.equal(y1, r1) and torch.equal(y2, r2)
+
+
+def test_gemm_splitk_needs_a_registered_workspace(dev, request):
     """Without a workspace (psam_gemm_set_workspace(NULL)) the fc2-per-slice shape stays on the single-pass kernel: the result is
     bit-identical to the forced 128-tile kernel; registering a workspace again switches the split-K path back on."""
     from protosam_amd import _lib, ops
@@ -206,6 +234,8 @@ def test_gemm_splitk_needs_a_registered_workspace(dev):
     a = _rand((M, K), dev, 1.0, 1).half()
     w = _rand((N, K), dev, 0.05, 2).half()
     x0 = _rand((M, N), dev, 1.0, 3)
+    ops.gemm_set_option("half_tiles", 0)
+    request.addfinalizer(lambda: ops.gemm_set_option("half_tiles", 1))
     ops.gemm(a, w, None, out=x0.clone(), epilogue=ops.EPI_F32, resid=x0.clone())       # (registers the default workspace)
     y = x0.clone()
     ops.gemm_set_tile(1)
@@ -213,7 +243,7 @@ def test_gemm_splitk_needs_a_registered_workspace(dev):
         ops.gemm(a, w, None, out=y, epilogue=ops.EPI_F32, resid=y)
     finally:
         ops.gemm_set_tile(0)
-    ws = ops._GEMM_WS
+    ws = ops._GEMM_WS[x0.device.index]
     try:
         _lib.check(_lib.lib().psam_gemm_set_workspace(0, 0), "psam_gemm_set_workspace")
         x = x0.clone()
