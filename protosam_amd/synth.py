@@ -62,7 +62,7 @@ def synth_state_dict(module, seed=1234):
     return sd
 
 
-def heavy_tail_sam_(sd, seed=1234):
+def heavy_tail_sam_(sd, seed=1234, parts=("scale", "massive", "student")):
     """In place: give a synthetic SAM state dict the residual-stream statistics of trained ViT checkpoints (stress fixture for
     the fp16 operand path; tests/test_fullsize_gpu.py): per-channel scales spread over ~1.5 decades on what enters the stream
     (patch embedding, position embedding), a few 'massive activation' channels (tens everywhere, hundreds at a handful of token
@@ -70,21 +70,23 @@ def heavy_tail_sam_(sd, seed=1234):
     g = _gen(seed, "heavy_tail")
     D = sd["image_encoder.pos_embed"].shape[-1]
     scale = torch.exp(torch.randn(D, generator=g)).clamp(0.25, 8.0)
-    sd["image_encoder.patch_embed.proj.weight"] *= scale[:, None, None, None]
-    sd["image_encoder.patch_embed.proj.bias"] *= scale
-    sd["image_encoder.pos_embed"] *= scale
+    if "scale" in parts:
+        sd["image_encoder.patch_embed.proj.weight"] *= scale[:, None, None, None]
+        sd["image_encoder.patch_embed.proj.bias"] *= scale
+        sd["image_encoder.pos_embed"] *= scale
     chans = torch.randperm(D, generator=g)[:3]
     gh, gw = sd["image_encoder.pos_embed"].shape[1:3]
-    for c in chans.tolist():
+    for c in (chans.tolist() if "massive" in parts else []):
         sign = 1.0 if c % 2 == 0 else -1.0
         sd["image_encoder.pos_embed"][..., c] += sign * 30.0
         for _ in range(6):
             y, x = int(torch.randint(0, gh, (1,), generator=g)), int(torch.randint(0, gw, (1,), generator=g))
             sd["image_encoder.pos_embed"][0, y, x, c] += sign * 250.0
-    for k in sd:
+    for k in (sd if "student" in parts else []):
         if k.startswith("image_encoder.blocks.") and (k.endswith("attn.proj.weight") or k.endswith("mlp.lin2.weight")):
             w = sd[k]
-            t = torch.randn(w.shape, generator=g) / torch.sqrt(torch.distributions.Chi2(3.0).sample(w.shape[:1])[:, None] / 3.0)
+            chi2 = (torch.randn((3, w.shape[0]), generator=g) ** 2).sum(0)      # (seeded: 3 degrees of freedom per output channel)
+            t = torch.randn(w.shape, generator=g) / torch.sqrt(chi2[:, None] / 3.0)
             sd[k] = (t / math.sqrt(w.shape[1]) * 0.7).to(torch.float32)
     return sd
 
