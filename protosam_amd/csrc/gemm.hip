@@ -1121,15 +1121,15 @@ static std::map<unsigned long long, AsmTable> g_asm_tabs;
 // work list of workgroup b: entry i at tab[i * G + b] = tm | tn << 16, terminated (and padded two rows deep) by -1
 // halves > 0 (tile 16): every 256x256 tile of the map becomes its 256x128 halves (tm, 2 tn), (tm, 2 tn + 1) back to back - they share
 // the A panel - and `halves` is the number of 128-column blocks of the matrix (the last tile column may have one)
-static const AsmTable* asm_table(int ntm, int ntn, int mode, int halves = 0) {
+static const AsmTable* asm_table(int ntm, int ntn, int mode, int halves = 0, int wg_per_cu = 1) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   const unsigned long long key = ((unsigned long long)ntm << 40) | ((unsigned long long)ntn << 20) | ((unsigned long long)(halves ? 1 : 0) << 19) |
-                                 ((unsigned long long)(halves & 1) << 18) | ((unsigned long long)mode << 8) | (unsigned)dev;
+                                 ((unsigned long long)(halves & 1) << 18) | ((unsigned long long)(wg_per_cu - 1) << 16) | ((unsigned long long)mode << 8) | (unsigned)dev;
   auto it = g_asm_tabs.find(key);
   if (it != g_asm_tabs.end()) return &it->second;
   const int total = tile_map_grid(ntm, ntn, mode);
-  const int G = total < num_cus() ? total : num_cus();
+  const int G = total < num_cus() * wg_per_cu ? total : num_cus() * wg_per_cu;
   std::vector<std::vector<int>> lists(G);
   for (int b = 0; b < G; ++b)
     for (int idx = b; idx < total; idx += G) {
@@ -1184,7 +1184,7 @@ static int launch_asm(const GemmArgs& p, int epilogue, hipStream_t s, int family
   if (!fns) return PSAM_ERR_LAUNCH;
   // family 2 walks 256x128 half-tiles in the same XCD-aware order: the workgroups of an XCD that run side by side then share A panels
   // (one workgroup doing both halves of a 256x256 tile back to back re-read its A panel from beyond the L2: measured 20 % slower on fc2)
-  const int ntm = (p.M + 255) / 256, ntn = family == 2 ? p.N / 128 : p.N / 256;
+  const int ntm = (p.M + 255) / 256, ntn = family >= 2 ? p.N / 128 : p.N / 256;
   const AsmTable* t = asm_table(ntm, ntn, pick_map_mode(ntm, ntn));
   if (!t) return PSAM_ERR_LAUNCH;
   AsmGemmArgs a;

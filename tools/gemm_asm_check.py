@@ -35,7 +35,7 @@ def timeit(fn, n=6, w=2):
 cases = [(256, 256, 128), (256, 256, 192), (512, 512, 256), (300, 256, 640), (1297, 768, 768), (4096, 1280, 1280)]
 if mode == "full":
     cases += [(20000, 1536, 128), (33000, 2304, 192), (4096, 5120, 1280), (4096, 1280, 5120), (70001, 768, 128), (65536, 1280, 1280)]
-if TILE == 16:
+if TILE >= 16:
     cases = [(256, 128, 1280), (256, 256, 1280), (512, 384, 1280), (300, 256, 1344), (1297, 768, 768), (4096, 1280, 1280)]
     if mode == "full":
         cases += [(20000, 1536, 1152), (4096, 5120, 1280), (4096, 1280, 5120), (70001, 640, 1088), (65536, 1280, 1280)]
