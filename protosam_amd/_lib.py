@@ -73,6 +73,7 @@ SIGNATURES = {
     "psam_normalize_chw": [c_void_p, c_int, c_int, c_longlong, ctypes.POINTER(c_float), ctypes.POINTER(c_float),
                            c_void_p, c_void_p],
     "psam_ccl": [c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 9 + [c_void_p],
+    "psam_ccl_batch": [c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_int] + [c_void_p] * 9 + [c_void_p],
     "psam_sam_patchify": [c_void_p, c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_float), ctypes.POINTER(c_float),
                           c_int, c_void_p, c_void_p, c_void_p],
 }

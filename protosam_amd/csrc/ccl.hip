@@ -46,10 +46,15 @@ __device__ __forceinline__ void uf_union(int* parent, int a, int b) {
   }
 }
 
+// Batched form (psam_ccl_batch): blockIdx.z = image of the batch, every array moves by its per-image stride (elements); the
+// single-image entry launches with grid.z = 1 and zero strides.
+struct CclStride { long long pred, pfg, labels, parent, counters, roots, acc_i, acc_u, acc_d, fg_sum, tab; };
+
 // init: every foreground pixel points at the start of its horizontal run inside its 64-pixel wave segment (found with
 // one ballot, no atomics), so horizontal connectivity inside a segment costs nothing and find() paths stay short.
 __global__ __launch_bounds__(256) void ccl_init_kernel(const uint8_t* __restrict__ pred, int H, int W,
-                                                       int* __restrict__ parent, int* counters) {
+                                                       int* __restrict__ parent, int* counters, CclStride st) {
+  pred += blockIdx.z * st.pred; parent += blockIdx.z * st.parent; counters += blockIdx.z * st.counters;
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
   if (x == 0 && y == 0) {
     counters[0] = 0;
@@ -74,7 +79,8 @@ __global__ __launch_bounds__(256) void ccl_init_kernel(const uint8_t* __restrict
 //   NW : only if N and W are background
 //   NE : only if N is background
 __global__ __launch_bounds__(256) void ccl_merge_kernel(const uint8_t* __restrict__ pred, int H, int W,
-                                                        int* __restrict__ parent) {
+                                                        int* __restrict__ parent, CclStride st) {
+  pred += blockIdx.z * st.pred; parent += blockIdx.z * st.parent;
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
   if (x >= W) return;
   const int p = y * W + x;
@@ -94,7 +100,8 @@ __global__ __launch_bounds__(256) void ccl_merge_kernel(const uint8_t* __restric
   }
 }
 
-__global__ void ccl_flatten_kernel(int n, int* __restrict__ parent, int* __restrict__ roots, int cap, int* counters) {
+__global__ void ccl_flatten_kernel(int n, int* __restrict__ parent, int* __restrict__ roots, int cap, int* counters, CclStride st) {
+  parent += blockIdx.z * st.parent; roots += blockIdx.z * st.roots; counters += blockIdx.z * st.counters;
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   if (parent[i] < 0) return;
@@ -105,7 +112,8 @@ __global__ void ccl_flatten_kernel(int n, int* __restrict__ parent, int* __restr
   }
 }
 // second flatten pass (after all roots are final) so that parent[i] is the root itself
-__global__ void ccl_compress_kernel(int n, int* __restrict__ parent) {
+__global__ void ccl_compress_kernel(int n, int* __restrict__ parent, CclStride st) {
+  parent += blockIdx.z * st.parent;
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || parent[i] < 0) return;
   parent[i] = uf_find(parent, i);
@@ -114,7 +122,9 @@ __global__ void ccl_compress_kernel(int n, int* __restrict__ parent) {
 // one block: rank the (<= cap) collected roots ascending, label them 1..n, clear the accumulators
 __global__ __launch_bounds__(256) void ccl_rank_kernel(int* __restrict__ roots, int cap, const int* counters,
                                                        int* __restrict__ labels, int* __restrict__ acc_i,
-                                                       unsigned long long* __restrict__ acc_u, double* __restrict__ acc_d) {
+                                                       unsigned long long* __restrict__ acc_u, double* __restrict__ acc_d, CclStride st) {
+  roots += blockIdx.z * st.roots; counters += blockIdx.z * st.counters; labels += blockIdx.z * st.labels;
+  acc_i += blockIdx.z * st.acc_i; acc_u += blockIdx.z * st.acc_u; acc_d += blockIdx.z * st.acc_d;
   extern __shared__ int sroots[];
   const int nall = counters[0];
   const int n = nall < cap ? nall : cap;
@@ -157,7 +167,9 @@ __device__ __forceinline__ float ord2f32(uint32_t u) {
 __global__ __launch_bounds__(256) void ccl_stats_kernel(const int* __restrict__ parent, int H, int W,
                                                         const float* __restrict__ pfg, int* __restrict__ labels,
                                                         int* __restrict__ acc_i, unsigned long long* __restrict__ acc_u,
-                                                        double* __restrict__ acc_d) {
+                                                        double* __restrict__ acc_d, CclStride st) {
+  parent += blockIdx.z * st.parent; pfg += blockIdx.z * st.pfg; labels += blockIdx.z * st.labels;
+  acc_i += blockIdx.z * st.acc_i; acc_u += blockIdx.z * st.acc_u; acc_d += blockIdx.z * st.acc_d;
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const int y0 = blockIdx.y * STAT_ROWS, y1 = min(y0 + STAT_ROWS, H);
@@ -230,7 +242,10 @@ __global__ __launch_bounds__(256) void ccl_stats_kernel(const int* __restrict__ 
 
 __global__ void ccl_finalize_kernel(const int* counters, int cap, int W, const int* __restrict__ acc_i,
                                     const unsigned long long* __restrict__ acc_u, const double* __restrict__ acc_d,
-                                    const int* __restrict__ fg_sum, double* __restrict__ tab) {
+                                    const int* __restrict__ fg_sum, double* __restrict__ tab, CclStride st) {
+  counters += blockIdx.z * st.counters; acc_i += blockIdx.z * st.acc_i; acc_u += blockIdx.z * st.acc_u; acc_d += blockIdx.z * st.acc_d;
+  tab += blockIdx.z * st.tab;
+  if (fg_sum) fg_sum += blockIdx.z * st.fg_sum;
   const int nall = counters[0];
   const int n = nall < cap ? nall : cap;
   __shared__ double total_s;
@@ -284,24 +299,47 @@ __global__ void ccl_finalize_kernel(const int* counters, int cap, int W, const i
 
 // pred u8 [H,W]; pfg fp32 [H,W]; labels int32 [H,W] (out); parent int32 [H*W] scratch; scratch: int32 area of
 // 2 + cap + 5*cap ints, then 8-byte aligned 3*cap u64 + cap doubles (see protosam_amd/ops.py: CclWorkspace).
+static int ccl_launch(const void* pred, const float* pfg, int H, int W, int cap, int* labels, int* parent, int* counters, int* roots,
+                      int* acc_i, void* acc_u, double* acc_d, const int* fg_sum, double* tab, int B, const CclStride& st, hipStream_t s) {
+  const int n = H * W;
+  const uint8_t* pr = (const uint8_t*)pred;
+  if (B == 1 || st.labels == (long long)n) {
+    (void)hipMemsetAsync(labels, 0, (size_t)n * B * sizeof(int), s);
+  } else {
+    for (int b = 0; b < B; ++b) (void)hipMemsetAsync(labels + (size_t)b * st.labels, 0, (size_t)n * sizeof(int), s);
+  }
+  const unsigned Z = (unsigned)B;
+  hipLaunchKernelGGL(ccl_init_kernel, dim3((W + 255) / 256, H, Z), dim3(256), 0, s, pr, H, W, parent, counters, st);
+  hipLaunchKernelGGL(ccl_merge_kernel, dim3((W + 255) / 256, H, Z), dim3(256), 0, s, pr, H, W, parent, st);
+  hipLaunchKernelGGL(ccl_flatten_kernel, dim3((n + 255) / 256, 1, Z), dim3(256), 0, s, n, parent, roots, cap, counters, st);
+  hipLaunchKernelGGL(ccl_compress_kernel, dim3((n + 255) / 256, 1, Z), dim3(256), 0, s, n, parent, st);
+  hipLaunchKernelGGL(ccl_rank_kernel, dim3(1, 1, Z), dim3(256), cap * sizeof(int), s, roots, cap, counters, labels, acc_i,
+                     (unsigned long long*)acc_u, acc_d, st);
+  hipLaunchKernelGGL(ccl_stats_kernel, dim3((W + 255) / 256, (H + STAT_ROWS - 1) / STAT_ROWS, Z), dim3(256), 0, s, parent, H, W, pfg, labels,
+                     acc_i, (unsigned long long*)acc_u, acc_d, st);
+  hipLaunchKernelGGL(ccl_finalize_kernel, dim3(1, 1, Z), dim3(256), 0, s, counters, cap, W, acc_i,
+                     (const unsigned long long*)acc_u, acc_d, fg_sum, tab, st);
+  return psam_launch_status();
+}
+
 extern "C" int psam_ccl(const void* pred, const float* pfg, int H, int W, int cap, int* labels, int* parent, int* counters,
                         int* roots, int* acc_i, void* acc_u, double* acc_d, const int* fg_sum, double* tab, void* stream) {
   if (H <= 0 || W <= 0 || cap <= 0 || cap > 4096) return PSAM_ERR_ARG;
-  hipStream_t s = (hipStream_t)stream;
-  const int n = H * W;
-  const uint8_t* pr = (const uint8_t*)pred;
-  (void)hipMemsetAsync(labels, 0, (size_t)n * sizeof(int), s);
-  hipLaunchKernelGGL(ccl_init_kernel, dim3((W + 255) / 256, H), dim3(256), 0, s, pr, H, W, parent, counters);
-  hipLaunchKernelGGL(ccl_merge_kernel, dim3((W + 255) / 256, H), dim3(256), 0, s, pr, H, W, parent);
-  hipLaunchKernelGGL(ccl_flatten_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, parent, roots, cap, counters);
-  hipLaunchKernelGGL(ccl_compress_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, parent);
-  hipLaunchKernelGGL(ccl_rank_kernel, dim3(1), dim3(256), cap * sizeof(int), s, roots, cap, counters, labels, acc_i,
-                     (unsigned long long*)acc_u, acc_d);
-  hipLaunchKernelGGL(ccl_stats_kernel, dim3((W + 255) / 256, (H + STAT_ROWS - 1) / STAT_ROWS), dim3(256), 0, s, parent, H, W, pfg, labels, acc_i,
-                     (unsigned long long*)acc_u, acc_d);
-  hipLaunchKernelGGL(ccl_finalize_kernel, dim3(1), dim3(256), 0, s, counters, cap, W, acc_i,
-                     (const unsigned long long*)acc_u, acc_d, fg_sum, tab);
-  return psam_launch_status();
+  CclStride st = {};
+  return ccl_launch(pred, pfg, H, W, cap, labels, parent, counters, roots, acc_i, acc_u, acc_d, fg_sum, tab, 1, st, (hipStream_t)stream);
+}
+
+// B images in one launch chain (seven launches for the whole batch instead of seven per image; validation_protosam.py walks slices,
+// ProtoSAM.forward_batch batches them): pred u8 [B,H,W] contiguous, pfg fp32 with `pfg_stride` floats between images (channel 1 of a
+// [B,2,H,W] probability map: 2*H*W), every scratch array B times the single-image size, contiguous per image; fg_sum int32 [B] or
+// NULL; tab fp64 [B][8 + 12*cap].
+extern "C" int psam_ccl_batch(const void* pred, const float* pfg, long long pfg_stride, int B, int H, int W, int cap, int* labels,
+                              int* parent, int* counters, int* roots, int* acc_i, void* acc_u, double* acc_d, const int* fg_sum,
+                              double* tab, void* stream) {
+  if (H <= 0 || W <= 0 || cap <= 0 || cap > 4096 || B <= 0 || B > 65535) return PSAM_ERR_ARG;
+  const long long n = (long long)H * W;
+  CclStride st = {n, pfg_stride, n, n, 2, cap, 5LL * cap, 3LL * cap, cap, 1, CC_HDR + (long long)CC_STRIDE * cap};
+  return ccl_launch(pred, pfg, H, W, cap, labels, parent, counters, roots, acc_i, acc_u, acc_d, fg_sum, tab, B, st, (hipStream_t)stream);
 }
 
 // ---- negative point prompts (models/ProtoSAM.py:361-372 global, :395-419 per component) ---------------------------------

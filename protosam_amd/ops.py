@@ -726,9 +726,13 @@ class CclWorkspace:
         n = H * W
         self.H, self.W, self.cap, self.slots = H, W, cap, slots
         i32 = lambda k: torch.empty(k, dtype=torch.int32, device=device)  # noqa: E731
-        self.parent, self.labels, self.counters, self.roots, self.acc_i = i32(n), i32(n), i32(2), i32(cap), i32(5 * cap)
-        self.acc_u = torch.empty(3 * cap, dtype=torch.int64, device=device)
-        self.acc_d = torch.empty(cap, dtype=torch.float64, device=device)
+        # every scratch array `slots` times (ccl_batch works on all images of a batch at once; ccl on image 0's part)
+        self.parent_b, self.labels_b = i32(slots * n).view(slots, n), i32(slots * n).view(slots, n)
+        self.counters_b, self.roots_b, self.acc_i_b = i32(slots * 2), i32(slots * cap), i32(slots * 5 * cap)
+        self.acc_u_b = torch.empty(slots * 3 * cap, dtype=torch.int64, device=device)
+        self.acc_d_b = torch.empty(slots * cap, dtype=torch.float64, device=device)
+        self.parent, self.labels, self.counters, self.roots = self.parent_b[0], self.labels_b[0], self.counters_b[:2], self.roots_b[:cap]
+        self.acc_i, self.acc_u, self.acc_d = self.acc_i_b[:5 * cap], self.acc_u_b[:3 * cap], self.acc_d_b[:cap]
         self.tabs = torch.zeros((slots, CC_HDR + CC_STRIDE * cap), dtype=torch.float64, device=device)
         self.tabs_host = torch.empty((slots, CC_HDR + CC_STRIDE * cap), dtype=torch.float64).pin_memory()
 
@@ -754,14 +758,30 @@ def ccl(pred_u8, pfg, ws, fg_sum=None, slot=0):
     return ws
 
 
-def neg_points(ws, pbg, tab, max_comp, r=10, thr=0.95, keys=None):
+def ccl_batch(pred_u8, prob, ws, fg_sum=None):
+    """pred uint8 [B,H,W], prob fp32 [B,2,H,W] (foreground = channel 1) -> ws.labels_b[b], ws.tabs[b] for every image in ONE chain of
+    seven launches (psam_ccl_batch)."""
+    B = pred_u8.shape[0]
+    assert pred_u8.dtype == torch.uint8 and pred_u8.is_cuda and pred_u8.is_contiguous() and B <= ws.slots
+    _req(prob, torch.float32, "prob")
+    assert prob.is_contiguous() and prob.shape[1] == 2
+    h = _tstart("ccl")
+    st = _lib.lib().psam_ccl_batch(_ptr(pred_u8), _ptr(prob[0, 1]), 2 * ws.H * ws.W, B, ws.H, ws.W, ws.cap, _ptr(ws.labels_b),
+                                  _ptr(ws.parent_b), _ptr(ws.counters_b), _ptr(ws.roots_b), _ptr(ws.acc_i_b), _ptr(ws.acc_u_b),
+                                  _ptr(ws.acc_d_b), _ptr(fg_sum), _ptr(ws.tabs), _stream())
+    _tstop(h, B * ws.H * ws.W * (1 + 4 + 4))
+    _lib.check(st, "psam_ccl_batch")
+    return ws
+
+
+def neg_points(ws, pbg, tab, max_comp, r=10, thr=0.95, keys=None, labels=None):
     """int64 keys [max_comp+1] (see psam_neg_points) from ws.labels (the CCL of the SAME image) and p_bg fp32 [H,W]."""
     _req(pbg, torch.float32, "pbg")
     assert pbg.is_contiguous() and tab.dtype == torch.float64
     if keys is None:
         keys = torch.empty(max_comp + 1, dtype=torch.int64, device=pbg.device)
-    st = _lib.lib().psam_neg_points(_ptr(ws.labels), _ptr(pbg), _ptr(tab), ws.H, ws.W, max_comp, r, float(thr), _ptr(keys),
-                                   _stream())
+    st = _lib.lib().psam_neg_points(_ptr(ws.labels if labels is None else labels), _ptr(pbg), _ptr(tab), ws.H, ws.W, max_comp, r,
+                                   float(thr), _ptr(keys), _stream())
     _lib.check(st, "psam_neg_points")
     return keys
 

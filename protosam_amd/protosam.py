@@ -448,14 +448,14 @@ class ProtoSAM(nn.Module):
         bufs["fg_event"].record()
         # 2. connected components + per-component statistics; the tables go to pinned host memory asynchronously
         cw = self._ccl
+        ops.ccl_batch(pred[:B], output_p[:B], cw, fg_sum=bufs["fg_sum"])        # one chain of seven launches for the batch
         for b in range(B):
-            ops.ccl(pred[b], output_p[b, 1], cw, fg_sum=bufs["fg_sum"][b:b + 1], slot=b)
-            if self.use_neg_points:   # labels are per-call scratch: reduce them now
+            if self.use_neg_points:
                 nk = bufs.setdefault("neg_keys", torch.empty((B, MAX_NEG_COMPONENTS + 1), dtype=torch.int64, device=dev))
-                ops.neg_points(cw, output_p[b, 0], cw.tabs[b], MAX_NEG_COMPONENTS, keys=nk[b])
-            if self._mask_only:   # cv2.resize(mask, (256, 256), INTER_NEAREST) samples pixel (4y, 4x); labels are scratch
+                ops.neg_points(cw, output_p[b, 0], cw.tabs[b], MAX_NEG_COMPONENTS, keys=nk[b], labels=cw.labels_b[b])
+            if self._mask_only:   # cv2.resize(mask, (256, 256), INTER_NEAREST) samples pixel (4y, 4x)
                 bufs.setdefault("lab256", torch.empty((B, S // 4, S // 4), dtype=torch.int32, device=dev))[b].copy_(
-                    cw.labels.view(S, S)[::4, ::4])
+                    cw.labels_b[b].view(S, S)[::4, ::4])
         cw.tabs_host[:B].copy_(cw.tabs[:B], non_blocking=True)
         if self.use_neg_points:
             nkh = bufs.setdefault("neg_keys_host", torch.empty((B, MAX_NEG_COMPONENTS + 1), dtype=torch.int64).pin_memory())
