@@ -124,3 +124,35 @@ def test_bench_launches_its_own_ranks(monkeypatch, capsys):
     assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     assert capsys.readouterr().out.strip() == '{"metric": "m", "n_gpus": 4}'
     assert "torch.cuda" not in str(getattr(bench, "__dict__", {}).get("torch", ""))   # parent path imports no torch at module level
+
+
+def _strong_worker(rank, world, port, n_slices, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    from protosam_amd.runner import gather_masks, interleave_rank_major
+    zs = bench.strong_slices(n_slices, world, rank)                       # one pass over the whole volume per step
+    local = torch.stack([_fake_mask(z) for z in zs])
+    full = gather_masks(local, world)
+    vol = interleave_rank_major(full, n_slices, world)
+    ok = all(torch.equal(vol[z], _fake_mask(z)) for z in range(n_slices)) and len(zs) == n_slices // world
+    q.put((rank, bool(ok), zs))
+    dist.destroy_process_group()
+
+
+def test_bench_strong_scaling_indexing_world2():
+    """`bench.py --scaling strong`: the 64-slice volume split z = r (mod W), one all-gather per step reassembles it in z order."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_strong_worker, args=(r, 2, port, 64, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    assert sorted(z for r in res for z in r[2]) == list(range(64))
+    import bench
+    assert bench.strong_slices(64, 8, 3) == [3, 11, 19, 27, 35, 43, 51, 59]
