@@ -52,20 +52,20 @@ __device__ __forceinline__ float wave_min(float v) {
 }
 
 // erf-form GELU (torch.nn.GELU() default). erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the fp16
-// rounding of every consumer) on the hardware exp2 / rcp: ~14 VALU ops instead of libm erff's ~40 with branches.
-__device__ __forceinline__ float fast_erf(float x) {
+// rounding of every consumer) on the hardware exp2 / rcp, with the 1 / sqrt(2) of erf(x / sqrt(2)) folded into the constants:
+// 14 VALU operations per element (the assembly GEMM epilogues of csrc/gemm_asm*_gen.py issue exactly this sequence, so every
+// GEMM kernel produces the same bits; the epilogue of the 256x256 assembly tile is VALU-issue bound on it).
+__device__ __forceinline__ float gelu_erf(float x) {
   const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(ax, 0.23164189f, 1.0f));               // 1 / (1 + p |x| / sqrt(2))
   float poly = fmaf(1.061405429f, t, -1.453152027f);
   poly = fmaf(poly, t, 1.421413741f);
   poly = fmaf(poly, t, -0.284496736f);
   poly = fmaf(poly, t, 0.254829592f);
-  const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f);
-  const float y = fmaf(-poly * t, e, 1.0f);
-  return copysignf(y, x);
-}
-__device__ __forceinline__ float gelu_erf(float x) {
-  return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f));
+  const float e = __builtin_amdgcn_exp2f((x * x) * -0.72134752044448170f);          // exp(-x^2 / 2)
+  const float y = fmaf(-poly * t, e, 1.0f);                                         // |erf(x / sqrt(2))|
+  const float h = 0.5f * x;
+  return fmaf(h, copysignf(y, x), h);
 }
 
 // XCD-aware bijective block remap (8 XCDs; block b runs on XCD b % 8): gives each XCD a
