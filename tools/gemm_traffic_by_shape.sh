@@ -14,3 +14,4 @@ for sh in "65536 3840 1280 0" "65536 1280 1280 2" "65536 5120 1280 1" "65536 128
   done
 done
 python3 tools/gemm_traffic_collect.py $OUT gpurun_out/gemm_traffic_by_shape.json $TILE
+rm -rf $OUT     # the raw counter databases are tens of MiB; gpurun_out/ only travels back when it is under 64 MiB
