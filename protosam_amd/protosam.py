@@ -312,8 +312,8 @@ class ProtoSAM(nn.Module):
         if self.use_neg_points:
             if not self.use_points:
                 raise TypeError("'NoneType' object is not iterable")   # ProtoSAM.py:509 iterates sam_neg_input_points[i] = None
-            if n > MAX_NEG_COMPONENTS:
-                raise NotImplementedError(f"use_neg_points with more than {MAX_NEG_COMPONENTS} components")
+            if len(neg_keys) < n + 1:
+                raise RuntimeError("negative-point keys of fewer components than the table holds")
             glob = ops.decode_point_key(int(neg_keys[0]), 1024)
         coords, labels = [], []
         for k, r in enumerate(rows):
@@ -368,9 +368,6 @@ class ProtoSAM(nn.Module):
             self._ccl_big = ops.CclWorkspace(S, S, MAX_COMPONENTS_LARGE, dev, slots=1)
         big = self._ccl_big
         ops.ccl(pred[b], output_p[b, 1], big, fg_sum=bufs["fg_sum"][b:b + 1], slot=0)
-        if self.use_neg_points:
-            ops.neg_points(big, output_p[b, 0], big.tabs[0], MAX_NEG_COMPONENTS, keys=bufs["neg_keys"][b])
-            bufs["neg_keys_host"][b].copy_(bufs["neg_keys"][b])
         if self._mask_only:
             bufs["lab256"][b].copy_(big.labels.view(S, S)[::4, ::4])
         tab = big.tabs[0].cpu().numpy()
@@ -508,7 +505,18 @@ class ProtoSAM(nn.Module):
                 slice_idx += [b] * len(ids)
                 stats[b].update(n_prompts=len(ids))
                 continue
-            c, l, rows = self._prompts_from_table(tab, bufs["neg_keys_host"][b].numpy() if self.use_neg_points else None)
+            neg_keys = None
+            if self.use_neg_points:
+                neg_keys = bufs["neg_keys_host"][b].numpy()
+                if n > MAX_NEG_COMPONENTS or n_found > MAX_COMPONENTS:
+                    # the fast path asked for the rings of the first MAX_NEG_COMPONENTS components of the fast table only (one
+                    # tile grid per component): ask again for all of them, on the labelling the table in hand belongs to
+                    # (the reference walks every component, ProtoSAM.py:395-419)
+                    big = n_found > MAX_COMPONENTS
+                    ws = self._ccl_big if big else cw
+                    neg_keys = ops.neg_points(ws, output_p[b, 0], ws.tabs[0] if big else cw.tabs[b], n,
+                                              labels=None if big else cw.labels_b[b]).cpu().numpy()
+            c, l, rows = self._prompts_from_table(tab, neg_keys)
             spans.append((b, len(img_idx), len(l)))
             coords += c
             labels += l
@@ -525,19 +533,23 @@ class ProtoSAM(nn.Module):
             ids = torch.tensor(labels, dtype=torch.int32).to(dev, non_blocking=True)
             fg, bg = self._mask_vals
             sop = torch.tensor(slice_idx, dtype=torch.int64).to(dev, non_blocking=True)
-            prompt = torch.where(bufs["lab256"][sop] == ids[:, None, None], fg, bg).to(torch.float32)
-            dense = sam.prompt_encoder.embed_masks_tokens(prompt[:, None])               # [P, 4096, 256]
-            src = (feat_tok[iop] + dense).contiguous()                                    # mask_decoder.py:126-127
-            tokens = dpk["out_tok"].unsqueeze(0).expand(P, -1, -1).contiguous()
             masks = torch.empty((P, 4, 256, 256), dtype=torch.float32, device=dev)
             iou = torch.empty((P, 4), dtype=torch.float32, device=dev)
             zero_dense = torch.zeros(256, dtype=torch.float32, device=dev)
             for c0 in range(0, P, DECODER_CHUNK):
+                # the dense prompt embedding and the decoder's image operand are [chunk, 4096, 256] fp32 (4 MiB per prompt set
+                # each): built per chunk, so that memory stays bounded however many components a slice has
                 c1 = min(c0 + DECODER_CHUNK, P)
+                prompt = torch.where(bufs["lab256"][sop[c0:c1]] == ids[c0:c1, None, None], fg, bg).to(torch.float32)
+                dense = sam.prompt_encoder.embed_masks_tokens(prompt[:, None])           # [chunk, 4096, 256]
+                src = (feat_tok[iop[c0:c1]] + dense).contiguous()                         # mask_decoder.py:126-127
+                del dense
+                tokens = dpk["out_tok"].unsqueeze(0).expand(c1 - c0, -1, -1).contiguous()
                 sam.mask_decoder.predict_masks_tokens(
-                    src[c0:c1], pe["pe_tok"], tokens[c0:c1].contiguous(), zero_dense,
+                    src, pe["pe_tok"], tokens, zero_dense,
                     img_of_prompt=torch.arange(c1 - c0, dtype=torch.int32, device=dev), masks_out=masks[c0:c1],
                     iou_out=iou[c0:c1])
+                del src
             best = iou[:, 1:].argmax(dim=1)                                               # score.argmax(), :494
             chosen = masks[torch.arange(P, device=dev), best + 1].unsqueeze(1).contiguous()   # [P,1,256,256]
             iou_host = iou[:, 1:].max(dim=1).values.cpu().numpy()

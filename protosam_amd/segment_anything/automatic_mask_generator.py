@@ -227,16 +227,43 @@ class SamAutomaticMaskGenerator:
                     area=area[order], points=pts[kept[order] // 3] + np.array([[x0, y0]], dtype=np.float64),
                     crop_boxes=np.tile(np.array([crop_box], dtype=np.int64), (len(order), 1)), masks=full_masks)
 
+    def _zero_plane(self, H, W, dev):
+        z = getattr(self, "_zero_planes", None)
+        if z is None:
+            z = self._zero_planes = {}
+        key = (H, W, str(dev))
+        if key not in z:
+            z.clear()
+            z[key] = torch.zeros((H, W), dtype=torch.float32, device=dev)
+        return z[key]
+
     def _remove_small_regions(self, mask_u8, area_thresh, mode, cw):
         """utils/amg.py:267-291 on the device: connected components of the mask (islands) or of its complement (holes) with
         `psam_ccl`, areas from its table, relabelling through a small lookup table. -> (uint8 mask [H,W], changed)."""
         H, W = mask_u8.shape
         holes = mode == "holes"
         working = (1 - mask_u8) if holes else mask_u8
-        ops.ccl(working.contiguous(), self._zero_p, cw)
+        ops.ccl(working.contiguous(), self._zero_plane(H, W, mask_u8.device), cw)
         tab = cw.tab.cpu().numpy()
         if int(tab[0]) > int(tab[1]):
-            raise RuntimeError(f"{int(tab[0])} regions in one mask exceed the connected-components table ({cw.cap})")
+            # more regions than the table has rows (speckled crop-resolution logits; cv2.connectedComponentsWithStats has no
+            # limit): the union-find forest of the same labelling is complete - every foreground pixel of `working` holds its
+            # region's root pixel - so the areas come from it; roots ascend like the table's rows, so ties break alike
+            par = cw.parent.view(H, W)
+            fgm = par >= 0
+            _, inv, counts = torch.unique(par[fgm], return_inverse=True, return_counts=True)
+            small_t = counts < area_thresh
+            if not bool(small_t.any()):
+                return mask_u8, False
+            sel = torch.zeros((H, W), dtype=torch.uint8, device=mask_u8.device)
+            if holes:
+                sel[fgm] = small_t[inv].to(torch.uint8)
+                return mask_u8 | sel, True
+            keep = ~small_t
+            if not bool(keep.any()):
+                keep[int(counts.argmax())] = True
+            sel[fgm] = keep[inv].to(torch.uint8)
+            return sel, True
         n = int(tab[1])
         sizes = tab[ops.CC_HDR:ops.CC_HDR + ops.CC_STRIDE * n].reshape(n, ops.CC_STRIDE)[:, 0]
         small = [i + 1 for i, sz in enumerate(sizes) if sz < area_thresh]
@@ -269,7 +296,6 @@ class SamAutomaticMaskGenerator:
             masks = masks[torch.from_numpy(keep).to(dev)]
         if self.min_mask_region_area > 0 and len(masks):                        # :332-380
             cw = ops.CclWorkspace(H, W, 4096, dev)
-            self._zero_p = torch.zeros((H, W), dtype=torch.float32, device=dev)
             new_masks, scores = [], []
             for i in range(len(masks)):
                 m, c1 = self._remove_small_regions(masks[i], self.min_mask_region_area, "holes", cw)

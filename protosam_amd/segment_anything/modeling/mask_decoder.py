@@ -104,6 +104,8 @@ class MaskDecoder(nn.Module):
         h = self.image_side_fp16
         key = (B, T, h)
         if key not in self._ws:
+            while len(self._ws) >= 4:          # every distinct number of prompt sets has its own ~13 MB-per-set workspace:
+                self._ws.pop(next(iter(self._ws)))   # keep the four most recently created ones
             e = lambda shape, dt=torch.float32: torch.empty(shape, dtype=dt, device=dev)  # noqa: E731
             M = B * Nk
             pdt = torch.float16 if h else torch.float32

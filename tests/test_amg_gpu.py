@@ -232,14 +232,14 @@ def test_remove_small_regions_on_device(dev):
         if 0 < p < 1:
             mask[10:30, 5:15] = True
             mask[12, 7] = False                                               # a one-pixel hole
-        cw = ops.CclWorkspace(H, W, 4096, dev)
-        g._zero_p = torch.zeros((H, W), dtype=torch.float32, device=dev)
-        for mode in ("holes", "islands"):
-            for thr in (1, 6, 50):
-                ref, ch_ref = oamg.remove_small_regions(mask, thr, mode)
-                got, ch = g._remove_small_regions(torch.from_numpy(mask.astype(np.uint8)).to(dev), thr, mode, cw)
-                assert ch == ch_ref, (H, W, mode, thr)
-                assert np.array_equal(got.cpu().numpy().astype(bool), ref), (H, W, mode, thr)
+        # the second workspace has fewer table rows than the mask has regions: the overflow path must give the same masks
+        for cw in (ops.CclWorkspace(H, W, 4096, dev), ops.CclWorkspace(H, W, 4, dev)):
+            for mode in ("holes", "islands"):
+                for thr in (1, 6, 50, 10 ** 6):
+                    ref, ch_ref = oamg.remove_small_regions(mask, thr, mode)
+                    got, ch = g._remove_small_regions(torch.from_numpy(mask.astype(np.uint8)).to(dev), thr, mode, cw)
+                    assert ch == ch_ref, (H, W, mode, thr, cw.cap)
+                    assert np.array_equal(got.cpu().numpy().astype(bool), ref), (H, W, mode, thr, cw.cap)
 
 
 @pytest.fixture(scope="module")
