@@ -1107,13 +1107,16 @@ static const hipFunction_t* asm_load(int family = 1) {
   const int key = family * 1000 + g_asm_variant;
   auto it = g_asm_fns.find(key);
   if (it != g_asm_fns.end()) return it->second.data();
+  // [0..2]: f16 / gelu / f32; [3..5] (family 1, shipped schedule): the same with the default cache policy in the epilogue (_l2)
   const char* names[3] = {"f16", "gelu", "f32"};
-  std::vector<hipFunction_t> f(3, nullptr);
-  for (int i = 0; i < 3; ++i) {
-    std::string n = std::string(family == 2 ? "psam_gemm_asm2_" : "psam_gemm_asm_") + names[i] +
+  const int nf = (family == 1 && g_asm_variant == 0) ? 6 : 3;
+  std::vector<hipFunction_t> f(6, nullptr);
+  for (int i = 0; i < nf; ++i) {
+    std::string n = std::string(family == 2 ? "psam_gemm_asm2_" : "psam_gemm_asm_") + names[i % 3] + (i >= 3 ? "_l2" : "") +
                     (g_asm_variant > 0 ? "_v" + std::to_string(g_asm_variant) : std::string());
     if (hipModuleGetFunction(&f[i], g_asm_mod, n.c_str()) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   }
+  for (int i = nf; i < 6; ++i) f[i] = f[i - 3];
   return (g_asm_fns[key] = f).data();
 }
 struct AsmTable { int grid; int* dev; };
@@ -1198,7 +1201,11 @@ static int launch_asm(const GemmArgs& p, int epilogue, hipStream_t s, int family
   if (trace) { (void)hipMalloc(&a.trace, (size_t)t->grid * 16); (void)hipMemsetAsync(a.trace, 0, (size_t)t->grid * 16, s); }
   size_t sz = sizeof(a);
   void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  if (hipModuleLaunchKernel(fns[epilogue], t->grid, 1, 1, 256, 1, 1, 0, s, nullptr, extra) != hipSuccess) {
+  // streaming epilogue (nt loads / stores) when the output is far beyond the 32 MB of L2 and only the next launch reads it; the
+  // default policy when it may still be there (gemm_asm_gen.py variants())
+  const size_t out_bytes = (size_t)p.M * p.N * (epilogue == EPI_F32 ? 4 : 2);
+  const int fsel = epilogue + ((family == 1 && out_bytes <= ((size_t)48 << 20)) ? 3 : 0);
+  if (hipModuleLaunchKernel(fns[fsel], t->grid, 1, 1, 256, 1, 1, 0, s, nullptr, extra) != hipSuccess) {
     (void)hipGetLastError();
     return PSAM_ERR_LAUNCH;
   }
