@@ -44,10 +44,7 @@ struct GemmArgs {
   int out_seg_off;
   int map_mode;  // 0: XCD-region tile map (default); 1: identity; 2: contiguous chunk per XCD
   int head_hd;   // > 0: head-major output, out[(n / head_hd), m, n % head_hd] (planes of [M, head_hd]); EPI_F16 only
-  unsigned long long* trace;  // PSAM_GEMM_TRACE: per-workgroup timestamps (tile 10, debugging)
   int wide16;    // fp16 output rows may be stored with 16-byte instructions (ldo % 8 == 0, 16-byte aligned base)
-  int stagger;   // start-time spread of the first round of workgroups, in units of s_sleep(8) (tile 10)
-  int dbg;       // ablation switches for tools/gemm_ablate.py (PSAM_GEMM_DBG; only the DBG instantiation reads it)
   // ---- LayerNorm folded into the GEMMs either side of it (psam_gemm_f16_ln; tiles 1 / 11 / 14 only) ----
   // producer (EPI_F32, the residual-stream update x = resid + gamma * (acc + bias)): besides x it writes
   //   out16[m, n]                 = fp16(x)   - the NEXT GEMM's A operand (no LayerNorm pass, no cast pass)
@@ -612,7 +609,7 @@ __device__ __forceinline__ int lds_off64(int row, int chunk) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Tile 11: the 8-phase kernel above made PERSISTENT for the fp16-output epilogues. One workgroup per CU walks tiles
-// bid, bid + grid, ... of the same XCD-aware map. What it buys (per-workgroup timeline, tools/gemm_trace.py, 65536x3840x1280:
+// bid, bid + grid, ... of the same XCD-aware map. What it buys (per-workgroup timeline of a round-2 trace build, 65536x3840x1280:
 // prologue 2.3 us + k-loop 35.8 us + epilogue 4.2 us + 0.9 us until the CU's next workgroup starts): the next tile's first
 // five half-tile DMAs are issued BEFORE the epilogue of the finished tile and land while its stores drain, and there is no
 // workgroup turn-around. The epilogue therefore cannot park its slabs in the ring: each wave owns 4 KiB of the 32 KiB that
@@ -870,10 +867,6 @@ __global__ __launch_bounds__(512) void gemm8kp_f16_kernel(GemmArgs p, int total)
     if (k1 - k0 > 1) stage(0, k0 + 1);
   };
 
-  if (p.stagger > 0) {
-    const int n = (int)(((blockIdx.x * 167u) & 255u) * (unsigned)p.stagger) >> 8;
-    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(8);
-  }
   offsets(tm * 256, tn * 256);
   prologue(k_lo, k_hi);
 
@@ -1316,9 +1309,6 @@ static int gemm_dispatch(const void* A, const void* W, const float* bias, void* 
   p.out_seg_stride = out_seg_stride;
   p.out_seg_off = out_seg_off;
   { static int mm = -2; if (mm == -2) { const char* e = getenv("PSAM_GEMM_MAP"); mm = e ? atoi(e) : (xcd_maps_apply() ? 0 : 1); } p.map_mode = mm; }
-  { const char* e = getenv("PSAM_GEMM_DBG"); p.dbg = e ? atoi(e) : 0; }
-  p.trace = nullptr;
-  { static int st = -1; if (st < 0) { const char* e = getenv("PSAM_GEMM_STAGGER"); st = e ? atoi(e) : 0; } p.stagger = st; }
   p.head_hd = head_hd;
   p.out16 = (half_t*)ln.out16;
   p.ld16 = ln.ld16;
