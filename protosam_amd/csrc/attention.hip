@@ -972,25 +972,25 @@ __global__ __launch_bounds__(896, 4) void wattn_p_kernel(AttnArgs p, int nitems)
   const int it0 = (int)((long long)sx * cnt_x / nwg_x), it1 = (int)((long long)(sx + 1) * cnt_x / nwg_x);
   if (it0 >= it1) return;
 
-  // Per DMA piece the key's position inside the window, its 16-byte chunk and whether the slot exists, packed as
-  // kx | ky << 4 | chunk << 8 | zero-row << 12 | active << 13: a function of the lane and the piece only (constant divisors).
-  // It is RECOMPUTED per piece (~15 VALU) rather than hoisted out of the item loop: hoisted, the six values were spilled to
-  // scratch at the 128-register budget, and every reload - a VMEM load the compiler waits for with vmcnt(0) - drained the DMA
-  // queue right before the next piece was issued (the ISA showed scratch_load / s_waitcnt vmcnt(0) in front of each
-  // global_load_lds: the pipelining across items was void).
-  auto geo_of = [&](int w2, int i) -> int {
-    int lane_v = lane;
-    asm volatile("" : "+v"(lane_v));      // opaque: keeps the computation inside the item loop (see above)
-    const int S = (wv + i * NW) * 64 + lane_v;
+  // Per DMA piece (one wave instruction = 64 lanes x 16 bytes = 6.4 image rows) the geometry of this lane's chunk is a function of the
+  // lane and the piece only: packed ONCE per workgroup into one register per piece - kx | ky << 4 of the K image's key, the same
+  // << 8 for the V image's key (the two images order their rows differently), chunk << 16, bit 20 / 21: the K / V slot exists and
+  // its key is one of the window's 196 (the rows of the keys 196..207 are zeroed once, below, and never loaded). Round 2 recomputed
+  // all of it per piece and item (53 VALU instructions per piece, a third of the kernel's VALU issue - and the kernel is bound by
+  // exactly that: ~1000 VALU instructions per wave and item on SIMDs that hold four waves); three registers fit the budget.
+  int G[NDMA];
+#pragma unroll
+  for (int i = 0; i < NDMA; ++i) {
+    const int S = (wv + i * NW) * 64 + lane;
     const int R = S / RC, c = S - R * RC;
     const int rho = R & 31, C = R >> 5;
-    int key;
-    if (w2 == 0) key = C * 32 + ((rho >> 2) & 3) * 8 + (rho >> 4) * 4 + (rho & 3);
-    else key = C * 32 + ((rho >> 4) * 2 + ((rho >> 2) & 1)) * 8 + ((rho >> 3) & 1) * 4 + (rho & 3);
-    const int kk = key < NKEY ? key : 0;
-    const int ky = kk / WS, kx = kk - ky * WS;
-    return kx | (ky << 4) | (c << 8) | ((key >= NKEY ? 1 : 0) << 12) | ((R < KROWS && c < CH) ? (1 << 13) : 0);
-  };
+    const int keyK = C * 32 + ((rho >> 2) & 3) * 8 + (rho >> 4) * 4 + (rho & 3);
+    const int keyV = C * 32 + ((rho >> 4) * 2 + ((rho >> 2) & 1)) * 8 + ((rho >> 3) & 1) * 4 + (rho & 3);
+    const int kK = keyK < NKEY ? keyK : 0, kV = keyV < NKEY ? keyV : 0;
+    const int kyK = kK / WS, kxK = kK - kyK * WS, kyV = kV / WS, kxV = kV - kyV * WS;
+    const bool slot = R < KROWS && c < CH;
+    G[i] = kxK | (kyK << 4) | (kxV << 8) | (kyV << 12) | (c << 16) | ((slot && keyK < NKEY) ? (1 << 20) : 0) | ((slot && keyV < NKEY) ? (1 << 21) : 0);
+  }
   const int ndma_w = (wv + 2 * NW < NINS) ? 3 : 2;   // DMA instructions this wave issues per image (33 = 5 x 3 + 9 x 2)
   const int qidx = wv * 16 + li;                     // this lane's query (window-local; >= 196: none)
   const int qy = (qidx * 4682) >> 16, qx = qidx - 14 * qy;
@@ -1014,25 +1014,45 @@ __global__ __launch_bounds__(896, 4) void wattn_p_kernel(AttnArgs p, int nitems)
     }
     return n;
   };
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  const int rs2 = (int)rs * 2;                       // bytes per token row of qkv
   auto dma_image = [&](const Item& im, int which, half_t* img) {
-    const half_t* base = p.qkv + (size_t)im.b * N * rs + (size_t)which * p.ws_ + (size_t)im.h * p.hs;   // wave-uniform
+    // wave-uniform buffer descriptors (raw, no stride): the head's slice of q / k / v for this item's image, and the pad row
+    const half_t* base = p.qkv + (size_t)im.b * N * rs + (size_t)which * p.ws_ + (size_t)im.h * p.hs;
     const half_t* padw = p.pad_row + ((size_t)which * H + im.h) * HD;
+    i32x4 srd, srd_pad;
+    srd.x = __builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)base);
+    srd.y = __builtin_amdgcn_readfirstlane((int)(unsigned)((size_t)base >> 32));
+    srd.z = 0x7fffffff;
+    srd.w = 0x00020000;
+    srd_pad.x = __builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)padw);
+    srd_pad.y = __builtin_amdgcn_readfirstlane((int)(unsigned)((size_t)padw >> 32));
+    srd_pad.z = HD * 2;
+    srd_pad.w = 0x00020000;
 #pragma unroll
     for (int i = 0; i < NDMA; ++i) {
       if (wv + i * NW < NINS) {
-        const int gq = geo_of(which - 1, i);
-        const int y = im.wy14 + ((gq >> 4) & 15), xx = im.wx14 + (gq & 15);
-        const half_t* src = (y < p.gh && xx < p.gw) ? base + (size_t)(unsigned)((y * p.gw + xx) * (int)rs) : padw;
-        src = (gq & (1 << 12)) ? zero_row : src;
-        src += ((gq >> 8) & 15) * 8;
+        int gq = G[i];
+        asm volatile("" : "+v"(gq));   // opaque: the fields are unpacked here, per piece - hoisted out of the item loop they are spilled, and
+                                       // every reload of a spill is a VMEM load the compiler awaits with vmcnt(0): the prefetch would drain
+        const int kk = which == 1 ? gq : (gq >> 8);
+        const int y = im.wy14 + ((kk >> 4) & 15), xx = im.wx14 + (kk & 15);
+        const unsigned c16 = (unsigned)((gq >> 16) & 15) * 16u;
+        const unsigned voff = (unsigned)((y * p.gw + xx) * rs2) + c16;
         // The DMA is issued as inline asm, not through __builtin_amdgcn_global_load_lds: the compiler models the builtin as a
         // pending LDS write and - across the item loop, where it cannot see the hand-placed counted waits - protects every
         // later read of the same array with s_waitcnt vmcnt(0), which drains the NEXT item's prefetch (seen in the ISA in front
         // of the first V read of every item). Unknown to its model, the DMA can only make its own waits more conservative.
-        if (gq & (1 << 13)) {
-          const unsigned ldsb = (unsigned)(size_t)(__attribute__((address_space(3))) half_t*)(img + (wv + i * NW) * 512);
-          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                       :: "v"(src), "s"(__builtin_amdgcn_readfirstlane(ldsb)) : "memory", "m0");
+        const unsigned ldsb = (unsigned)(size_t)(__attribute__((address_space(3))) half_t*)(img + (wv + i * NW) * 512);
+        const int m0v = __builtin_amdgcn_readfirstlane(ldsb);
+        if (gq & (1 << (19 + which))) {
+          if (y < p.gh && xx < p.gw) {
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+                         :: "v"(voff), "s"(srd), "s"(m0v) : "memory", "m0");
+          } else {   // tokens beyond the image edge (the last window row / column): the padded map's value there, fp16(qkv bias)
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+                         :: "v"(c16), "s"(srd_pad), "s"(m0v) : "memory", "m0");
+          }
         }
       }
     }
@@ -1069,6 +1089,17 @@ __global__ __launch_bounds__(896, 4) void wattn_p_kernel(AttnArgs p, int nitems)
   }
   for (int idx = t; idx < 13 * 64; idx += NT)
     *reinterpret_cast<uint4*>(&Oht[idx * 8]) = *reinterpret_cast<const uint4*>(p.rpack + 2 * 2 * 32 * HDP + (size_t)idx * 8);
+  for (int idx = t; idx < KROWS * RC; idx += NT) {                 // image rows of the keys 196..207: zero, once (no DMA piece touches them)
+    const int R = idx / RC, c = idx - R * RC;
+    const int rho = R & 31, C = R >> 5;
+    const int keyK = C * 32 + ((rho >> 2) & 3) * 8 + (rho >> 4) * 4 + (rho & 3);
+    const int keyV = C * 32 + ((rho >> 4) * 2 + ((rho >> 2) & 1)) * 8 + ((rho >> 3) & 1) * 4 + (rho & 3);
+    if (keyK >= NKEY) {
+      *reinterpret_cast<uint4*>(&Kb0[R * RLD + c * 8]) = make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(&Kb1[R * RLD + c * 8]) = make_uint4(0, 0, 0, 0);
+    }
+    if (keyV >= NKEY) *reinterpret_cast<uint4*>(&Vs[R * RLD + c * 8]) = make_uint4(0, 0, 0, 0);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   dma_image(cur, 2, Vs);

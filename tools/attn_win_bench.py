@@ -5,6 +5,7 @@ from protosam_amd import ops
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 H, hd, N = 16, 80, 4096
+torch.manual_seed(0)
 qkv = torch.randn(B, N, 3, H, hd, device=dev).half()
 r = torch.randn(B, H, N, 2, 32, device=dev).half() * 0.1
 pad = torch.randn(3, H, hd, device=dev).half()
@@ -24,3 +25,4 @@ e0.record()
 for _ in range(20): run()
 e1.record(); torch.cuda.synchronize()
 print(f"fused={int(FUSED)} dbg={os.environ.get('PSAM_ATTN_DBG','0')} B={B}: {e0.elapsed_time(e1)/20*1e3:.1f} us")
+print("checksum", out.float().sum().item(), out.float().abs().sum().item(), out[B - 1, 1000, 77].item(), out[0, 4095, 1279].item(), int(torch.isnan(out.float()).sum()))
