@@ -40,14 +40,17 @@ int psam_gemm_f16_heads(const void* A, const void* W, const float* bias, void* o
  *   epilogue 2 (x = resid + gamma*(a w^T + bias)) also writes out16 = half(x) [.., ld16] and stats: per row and 64-column
  *              group (sum, sum of squares) of x, float [M][N/64][2] (either may be null);
  *   epilogue 0 / 1 take A = half(x), W already multiplied by the LayerNorm weight, bias' = bias + W . ln_bias, and
- *              ln_mr float [M][2] = (mean, rstd) from psam_ln_finalize, ln_s float [N] = row sums of the fp16 W':
+ *              ln_mr = the buffer psam_ln_finalize fills: float [M][2] = (mean, rstd), then half [M][8] = {hi, hi, lo, 0 x 5} of
+ *              -mean; ln_s = float [N] row sums of the fp16 W', then half [N][8] = {hi, lo, hi, 0 x 5} of the same sums (the MFMA
+ *              operands of the assembly kernels' rank-1 correction acc -= mean (x) ln_s; ops.fold_layernorm builds ln_s):
  *              out = act(rstd * (acc - mean * ln_s[n]) + bias'[n]).
  * modeling/image_encoder.py:174-193 (norm1 -> attn.qkv, norm2 -> mlp.lin1); DINOv2 Block (norm1 / norm2). */
 int psam_gemm_f16_ln(const void* A, const void* W, const float* bias, void* out, const float* resid, const float* gamma,
                      int M, int N, int K, int lda, int ldw, int ldo, int ldr, int resid_mod, int out_seg,
                      int out_seg_stride, int out_seg_off, int epilogue, void* out16, int ld16, float* stats,
                      const float* ln_mr, const float* ln_s, void* stream);
-/* stats [M][D/64][2] -> mr [M][2] = (mean, 1/sqrt(var + eps)), biased variance (nn.LayerNorm) */
+/* stats [M][D/64][2] -> mr: float [M][2] = (mean, 1/sqrt(var + eps)), biased variance (nn.LayerNorm), followed by half [M][8] =
+ * {hi, hi, lo, 0, 0, 0, 0, 0} of -mean: 6 floats per row in all */
 int psam_ln_finalize(const float* stats, int M, int D, float eps, float* mr, void* stream);
 
 

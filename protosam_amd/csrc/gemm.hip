@@ -1078,8 +1078,10 @@ struct AsmGemmArgs {
   const void* A; const void* W; const void* bias; void* out; const void* resid; const void* gamma; const void* tab;
   int M, N, K, lda, ldw, ldo, ldr, G, flags, pad;
   void* trace;   // experiment variants only (gemm_asm_gen.py --experiments): uint4 per workgroup {k-loop cycles, epilogue cycles, K-tiles, 0}
+  // folded-LayerNorm producer (psam_gemm_asm_f32_ln only; the other kernels' kernarg segment ends at 104)
+  void* out16; float* stats; int ld16, pad2;
 };
-static_assert(sizeof(AsmGemmArgs) == 104, "kernarg layout of gemm_asm_gen.py");
+static_assert(sizeof(AsmGemmArgs) == 128, "kernarg layout of gemm_asm_gen.py");
 static hipModule_t g_asm_mod = nullptr;
 static std::map<int, std::vector<hipFunction_t>> g_asm_fns;   // family * 1000 + variant -> {f16, gelu, f32}
 static int g_asm_variant = 0;   // 0 = the shipped schedule; > 0: experiment builds (kernel names carry the suffix _v<n>)
@@ -1100,14 +1102,20 @@ static const hipFunction_t* asm_load(int family = 1) {
   const int key = family * 1000 + g_asm_variant;
   auto it = g_asm_fns.find(key);
   if (it != g_asm_fns.end()) return it->second.data();
-  // [0..2]: f16 / gelu / f32; [3..5] (family 1, shipped schedule): the same with the default cache policy in the epilogue (_l2)
+  // [0..2]: f16 / gelu / f32; [3..5] (family 1, shipped schedule): the same with the default cache policy in the epilogue (_l2);
+  // [6..8]: the folded-LayerNorm forms (_ln: consumers f16 / gelu, producer f32)
   const char* names[3] = {"f16", "gelu", "f32"};
-  const int nf = (family == 1 && g_asm_variant == 0) ? 6 : 3;
-  std::vector<hipFunction_t> f(6, nullptr);
+  const char* suffix[3] = {"", "_l2", "_ln"};
+  const int nf = (family == 1 && g_asm_variant == 0) ? 9 : 3;
+  std::vector<hipFunction_t> f(9, nullptr);
   for (int i = 0; i < nf; ++i) {
-    std::string n = std::string(family == 2 ? "psam_gemm_asm2_" : "psam_gemm_asm_") + names[i % 3] + (i >= 3 ? "_l2" : "") +
+    std::string n = std::string(family == 2 ? "psam_gemm_asm2_" : "psam_gemm_asm_") + names[i % 3] + suffix[i / 3] +
                     (g_asm_variant > 0 ? "_v" + std::to_string(g_asm_variant) : std::string());
-    if (hipModuleGetFunction(&f[i], g_asm_mod, n.c_str()) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipModuleGetFunction(&f[i], g_asm_mod, n.c_str()) != hipSuccess) {
+      (void)hipGetLastError();
+      if (i < 6) return nullptr;
+      f[i] = nullptr;              // (a _ln form that is not built: the dispatcher keeps those launches on the HIP kernels)
+    }
   }
   for (int i = nf; i < 6; ++i) f[i] = f[i - 3];
   return (g_asm_fns[key] = f).data();
@@ -1148,8 +1156,16 @@ static const AsmTable* asm_table(int ntm, int ntn, int mode, int halves = 0, int
   if (hipMemcpy(t.dev, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
   return &(g_asm_tabs[key] = t);
 }
-static bool asm_eligible(const GemmArgs& p, int epilogue, bool lnf) {
-  if (lnf || p.head_hd || p.out_seg || p.resid_mod || epilogue > EPI_F32) return false;
+// lnf: 0 plain, 1 a folded-LayerNorm launch (tile 15 has _ln forms of its kernels, tile 16 none)
+static bool asm_eligible(const GemmArgs& p, int epilogue, int lnf) {
+  if (lnf) {
+    const hipFunction_t* f = asm_load(1);
+    const bool cons = p.ln_mr || p.ln_s, prod = p.out16 || p.stats;
+    if (!f || g_asm_variant != 0 || (cons && prod)) return false;
+    if (cons && (!f[6 + epilogue] || !p.ln_mr || !p.ln_s || !p.bias || (reinterpret_cast<uintptr_t>(p.ln_mr) & 15) || (reinterpret_cast<uintptr_t>(p.ln_s) & 15))) return false;
+    if (prod && (!f[8] || !p.out16 || !p.stats || p.resid != p.out || p.ldr != p.ldo)) return false;
+  }
+  if (p.head_hd || p.out_seg || p.resid_mod || epilogue > EPI_F32) return false;
   if (p.N % 256 || p.K % 64 || p.K < 128 || p.M < 1) return false;
   if ((p.lda % 8) || (p.ldw % 8) || (reinterpret_cast<uintptr_t>(p.A) & 15) || (reinterpret_cast<uintptr_t>(p.W) & 15)) return false;
   const unsigned long long lim = 0xffffffffull;
@@ -1166,11 +1182,11 @@ static bool asm_eligible(const GemmArgs& p, int epilogue, bool lnf) {
 }
 // tile 16 (half-tile ping-pong, epilogue hidden under the next half-tile): same operand rules, N in blocks of 128, and the K loop
 // must be long enough to carry the previous half-tile's epilogue (E + 1 K-tiles)
-static bool asm2_eligible(const GemmArgs& p, int epilogue, bool lnf) {
+static bool asm2_eligible(const GemmArgs& p, int epilogue, int lnf) {
   if (epilogue > EPI_F32 || (p.N % 128)) return false;
   GemmArgs q = p;
   q.N = 256;   // (the 256-column rule of the first family does not apply)
-  if (!asm_eligible(q, epilogue, lnf)) return false;
+  if (lnf || !asm_eligible(q, epilogue, 0)) return false;
   if ((unsigned long long)p.N * p.ldw * 2 > 0xffffffffull) return false;
   const int e = epilogue == EPI_F16 ? PSAM_ASM2_E_F16 : epilogue == EPI_GELU_F16 ? PSAM_ASM2_E_GELU : PSAM_ASM2_E_F32;
   return p.K / 64 >= e + 1 && p.K / 64 >= 3;
@@ -1189,15 +1205,21 @@ static int launch_asm(const GemmArgs& p, int epilogue, hipStream_t s, int family
   a.flags = p.gamma ? 1 : 0;
   a.pad = 0;
   a.trace = nullptr;
+  const bool ln_cons = family == 1 && p.ln_mr && p.ln_s, ln_prod = family == 1 && (p.out16 || p.stats);
+  if (ln_cons) {   // folded LayerNorm, consumer: (mean, rstd) rows + -mean fragments in `resid`, the s fragments (behind the N floats) in `gamma`
+    a.resid = p.ln_mr;
+    a.gamma = p.ln_s + p.N;
+  }
+  a.out16 = p.out16; a.stats = p.stats; a.ld16 = p.ld16; a.pad2 = 0;
   static const char* tr = getenv("PSAM_GEMM_ASM_TRACE");
   const bool trace = tr && g_asm_variant > 0;
   if (trace) { (void)hipMalloc(&a.trace, (size_t)t->grid * 16); (void)hipMemsetAsync(a.trace, 0, (size_t)t->grid * 16, s); }
-  size_t sz = sizeof(a);
+  size_t sz = ln_prod ? sizeof(a) : 104;     // (the kernarg segment each kernel declares)
   void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
   // streaming epilogue (nt loads / stores) when the output is far beyond the 32 MB of L2 and only the next launch reads it; the
   // default policy when it may still be there (gemm_asm_gen.py variants())
   const size_t out_bytes = (size_t)p.M * p.N * (epilogue == EPI_F32 ? 4 : 2);
-  const int fsel = epilogue + ((family == 1 && out_bytes <= ((size_t)48 << 20)) ? 3 : 0);
+  const int fsel = (ln_cons || ln_prod) ? 6 + epilogue : epilogue + ((family == 1 && out_bytes <= ((size_t)48 << 20)) ? 3 : 0);
   if (hipModuleLaunchKernel(fns[fsel], t->grid, 1, 1, 256, 1, 1, 0, s, nullptr, extra) != hipSuccess) {
     (void)hipGetLastError();
     return PSAM_ERR_LAUNCH;
@@ -1325,7 +1347,7 @@ static int gemm_dispatch(const void* A, const void* W, const float* bias, void* 
   // the slab epilogues store fp16 rows with 16-byte instructions when the layout allows (tiles 7 / 8 / 10 / 11 / 15 require it)
   p.wide16 = (ldo % 8) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (!head_hd || head_hd % 8 == 0);
   // the assembly kernels (tile 15) take plain row-major operands; everything else they were picked for goes to the persistent HIP kernel
-  if (tsel == 16 && !asm2_eligible(p, epilogue, ln_prod || ln_cons)) tsel = g_tile_override > 0 ? 15 : 1;
+  if (tsel == 16 && !asm2_eligible(p, epilogue, ln_prod || ln_cons)) tsel = (g_tile_override > 0 || ln_prod || ln_cons) ? 15 : 1;
   if (tsel == 15 && !asm_eligible(p, epilogue, ln_prod || ln_cons)) tsel = (N % 256 == 0) ? 11 : 1;
   if (tsel != 1 && tsel != 11 && tsel != 15 && tsel != 16) tsel = (N % 256 == 0) ? 11 : 1;   // (tiles 2 ... 14 of rounds 1 / 2 are gone)
   if (tsel == 11 && (N % 256) != 0) tsel = 1;

@@ -126,6 +126,15 @@ __global__ void ln_finalize_kernel(const float* __restrict__ stats, int M, int p
   const float mean = s1 * inv_d;
   const float var = fmaxf(s2 * inv_d - mean * mean, 0.f);
   reinterpret_cast<float2*>(mr)[m] = make_float2(mean, 1.0f / sqrtf(var + eps));
+  // behind the M (mean, rstd) pairs: -mean as the MFMA operand of the assembly GEMM's rank-1 correction, fp16 {hi, hi, lo, 0 x 5}
+  // in the k slots 0..7 (multiplied with the {hi, lo, hi, 0 x 5} fragment of s: hi hi + lo hi + hi lo, fp32-accurate)
+  const half_t hi = (half_t)(-mean);
+  const half_t lo = (half_t)(-mean - (float)hi);
+  half8_t f;
+  f[0] = hi; f[1] = hi; f[2] = lo;
+#pragma unroll
+  for (int e = 3; e < 8; ++e) f[e] = (half_t)0.f;
+  reinterpret_cast<half8_t*>(mr + 2 * (size_t)M)[m] = f;
 }
 
 extern "C" int psam_ln_finalize(const float* stats, int M, int D, float eps, float* mr, void* stream) {

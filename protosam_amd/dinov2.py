@@ -97,12 +97,12 @@ class DinoVisionTransformer(nn.Module):
         self._packed = None
         self._pos_cache = {}
         self._ws = {}
-        # measured on MI355X (bench.py, 16-slice steps, same box, interleaved): 122.2 slices/s folded vs 124.3 with the separate
-        # LayerNorm passes - the passes (7 ms per step) are cheaper than what the extra fp16 copy, row sums and row-scale loads
-        # add to the persistent GEMM's epilogues (+10 ms), which nothing overlaps (profiles/r02_fold*_kernel_trace.md). Off by
-        # default; PSAM_FOLD_LN=1 / `fold_ln = True` selects it (it also lowers the embedding error: sigmoid(low_res) 4.6e-4 vs
-        # 6.2e-4 on config 4).
-        self.fold_ln = os.environ.get("PSAM_FOLD_LN", "0") != "0"
+        # LayerNorm folded into the GEMMs either side of it (ops.gemm ... out16 / stats / ln_mr / ln_s): on by default since the
+        # assembly GEMM has the folded epilogues (round 3: 145.3 vs 142.8 slices/s, same box, interleaved; the LayerNorm passes of a
+        # 16-slice step cost 6 ms, the fp16 copy + row sums in the producers' epilogues and the rank-1 correction MFMAs in the
+        # consumers' 3.8 ms; it also lowers the embedding error). Round 2 measured the opposite on the HIP kernels (122.2 vs 124.3:
+        # +10 ms of epilogue). PSAM_FOLD_LN=0 / `fold_ln = False` selects the separate passes.
+        self.fold_ln = os.environ.get("PSAM_FOLD_LN", "1") != "0"
 
     # -- weight packing (fp16 GEMM operands); rebuilt whenever parameters change -----------------------------
     def _apply(self, fn, *a, **k):
@@ -185,7 +185,7 @@ class DinoVisionTransformer(nn.Module):
                 x=torch.empty((B, N, D), dtype=torch.float32, device=dev),
                 ln=torch.empty((M, D), dtype=torch.float16, device=dev),
                 stats=torch.empty((M, D // 64, 2), dtype=torch.float32, device=dev),
-                mr=torch.empty((M, 2), dtype=torch.float32, device=dev),
+                mr=ops.ln_mr_buffer(M, dev),
                 qkv=torch.empty((M, 3 * D), dtype=torch.float16, device=dev),
                 att=torch.empty((M, D), dtype=torch.float16, device=dev),
                 hid=torch.empty((M, 4 * D), dtype=torch.float16, device=dev),

@@ -126,12 +126,19 @@ def gemm(a, w, bias=None, out=None, epilogue=EPI_F16, resid=None, gamma=None, re
     return out
 
 
+def ln_mr_buffer(M, device):
+    """(mean, rstd) buffer of psam_ln_finalize: fp32 [M][2] followed by the fp16 MFMA fragments of -mean [M][8] (6 floats per row)."""
+    return torch.empty(6 * M, dtype=torch.float32, device=device)
+
+
 def ln_finalize(stats, M, D, eps, mr=None):
-    """stats fp32 [rows, D/64, 2] (partial sums from a folded-LayerNorm producer GEMM) -> mr fp32 [rows, 2] = (mean, rstd)."""
+    """stats fp32 [rows, D/64, 2] (partial sums from a folded-LayerNorm producer GEMM) -> mr (see ln_mr_buffer): fp32 [rows, 2] =
+    (mean, rstd), then fp16 [rows, 8] = {hi, hi, lo, 0 x 5} of -mean (the assembly GEMM's rank-1 correction operand)."""
     _req(stats, torch.float32, "stats")
     if mr is None:
-        mr = torch.empty((M, 2), dtype=torch.float32, device=stats.device)
+        mr = ln_mr_buffer(M, stats.device)
     _req(mr, torch.float32, "mr")
+    assert mr.numel() >= 6 * M and mr.is_contiguous()
     st = _lib.lib().psam_ln_finalize(_ptr(stats), M, D, float(eps), _ptr(mr), _stream())
     _lib.check(st, "psam_ln_finalize")
     return mr
@@ -144,7 +151,13 @@ def fold_layernorm(weight, bias, ln_weight, ln_bias):
     Wp = (W * ln_weight.detach().float()[None, :]).half().contiguous()
     s = Wp.float().sum(1).contiguous()
     b = bias.detach().float() if bias is not None else torch.zeros(W.shape[0], dtype=torch.float32, device=W.device)
-    return Wp, s, (b + W @ ln_bias.detach().float()).contiguous()
+    # ln_s as psam_gemm_f16_ln takes it: fp32 [N], then the fp16 MFMA fragments {hi, lo, hi, 0 x 5} of s [N][8] (the assembly
+    # GEMM subtracts mean_row * s_col with one rank-1 MFMA per block: hi * hi + lo * hi + hi * lo)
+    hi = s.half()
+    frag = torch.zeros((s.numel(), 8), dtype=torch.float16, device=s.device)
+    frag[:, 0], frag[:, 1], frag[:, 2] = hi, (s - hi.float()).half(), hi
+    s_ext = torch.cat([s, frag.reshape(-1).view(torch.float32)]).contiguous()
+    return Wp, s_ext, (b + W @ ln_bias.detach().float()).contiguous()
 
 
 def gemm_heads(a, w, bias, hd, out=None, M=None):

@@ -91,12 +91,12 @@ class ImageEncoderViT(nn.Module):
                                   LayerNorm2d(out_chans))
         self._packed = None
         self._ws = {}
-        # measured on MI355X (bench.py, 16-slice steps, same box, interleaved): 122.2 slices/s folded vs 124.3 with the separate
-        # LayerNorm passes - the passes (7 ms per step) are cheaper than what the extra fp16 copy, row sums and row-scale loads
-        # add to the persistent GEMM's epilogues (+10 ms), which nothing overlaps (profiles/r02_fold*_kernel_trace.md). Off by
-        # default; PSAM_FOLD_LN=1 / `fold_ln = True` selects it (it also lowers the embedding error: sigmoid(low_res) 4.6e-4 vs
-        # 6.2e-4 on config 4).
-        self.fold_ln = os.environ.get("PSAM_FOLD_LN", "0") != "0"
+        # LayerNorm folded into the GEMMs either side of it (ops.gemm ... out16 / stats / ln_mr / ln_s): on by default since the
+        # assembly GEMM has the folded epilogues (round 3: 145.3 vs 142.8 slices/s, same box, interleaved; the LayerNorm passes of a
+        # 16-slice step cost 6 ms, the fp16 copy + row sums in the producers' epilogues and the rank-1 correction MFMAs in the
+        # consumers' 3.8 ms; it also lowers the embedding error). Round 2 measured the opposite on the HIP kernels (122.2 vs 124.3:
+        # +10 ms of epilogue). PSAM_FOLD_LN=0 / `fold_ln = False` selects the separate passes.
+        self.fold_ln = os.environ.get("PSAM_FOLD_LN", "1") != "0"
 
     def _apply(self, fn, *a, **k):
         self._packed, self._ws = None, {}
@@ -142,14 +142,14 @@ class ImageEncoderViT(nn.Module):
             big = max((b for b in self._ws if b > B), default=None)
             if big is not None:   # a sub-batch (e.g. only the slices with a non-empty coarse mask): views of the larger set
                 N = self.grid * self.grid
-                self._ws[B] = {k: (v[:B] if v.shape[0] == big else v[:B * N]) for k, v in self._ws[big].items()}
+                self._ws[B] = {k: (v[:6 * B * N] if k == "mr" else v[:B] if v.shape[0] == big else v[:B * N]) for k, v in self._ws[big].items()}
                 return self._ws[B]
             D, oc, N, H = self.embed_dim, self.out_chans, self.grid * self.grid, self.num_heads
             dev = self.pos_embed.device
             M = B * N
             e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)  # noqa: E731
             self._ws[B] = dict(x=e((M, D), torch.float32), ln=e((M, D), torch.float16), qkv=e((M, 3 * D), torch.float16),
-                               stats=e((M, D // 64, 2), torch.float32), mr=e((M, 2), torch.float32),
+                               stats=e((M, D // 64, 2), torch.float32), mr=ops.ln_mr_buffer(M, dev),
                                att=e((M, D), torch.float16), hid=e((M, 4 * D), torch.float16),
                                relh=e((B, H, N, 64), torch.float32), relw=e((B, H, N, 64), torch.float32),
                                relq=torch.zeros((B, H, N, 2, 32), dtype=torch.float16, device=dev),

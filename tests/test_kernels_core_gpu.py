@@ -500,9 +500,13 @@ def test_gemm_folded_layernorm(dev, tile, M, D, N2, act):
         assert torch.equal(x16, x.half())
         torch.testing.assert_close(stats[..., 0].sum(1), x.sum(1), rtol=1e-4, atol=1e-2)
         torch.testing.assert_close(stats[..., 1].sum(1), (x * x).sum(1), rtol=1e-4, atol=1e-2)
-        mr = ops.ln_finalize(stats, M, D, eps)
-        torch.testing.assert_close(mr[:, 0], x.mean(1), rtol=1e-4, atol=1e-5)
-        torch.testing.assert_close(mr[:, 1], torch.rsqrt(x.var(1, unbiased=False) + eps), rtol=1e-4, atol=1e-5)
+        mr = ops.ln_finalize(stats, M, D, eps)                 # fp32 (mean, rstd) [M][2], then the fp16 fragments of -mean [M][8]
+        mr2 = mr[:2 * M].view(M, 2)
+        torch.testing.assert_close(mr2[:, 0], x.mean(1), rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(mr2[:, 1], torch.rsqrt(x.var(1, unbiased=False) + eps), rtol=1e-4, atol=1e-5)
+        frag = mr[2 * M:].view(torch.float16).view(M, 8).float()
+        assert torch.equal(frag[:, 0], frag[:, 1]) and int(frag[:, 3:].abs().sum()) == 0
+        torch.testing.assert_close(frag[:, 0] + frag[:, 2], -mr2[:, 0], rtol=1e-6, atol=1e-7)
         wf, s_, t_ = ops.fold_layernorm(w2, b2, ln_w, ln_b)
         e = ops.EPI_GELU_F16 if act else ops.EPI_F16
         y = ops.gemm(x16, wf, t_, epilogue=e, ln_mr=mr, ln_s=s_).float()

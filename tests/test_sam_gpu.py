@@ -205,10 +205,11 @@ def test_image_encoder_folded_layernorm_path(dev):
     ref = oenc.image_encoder(x, sd, model_type="vit_b", depth=3)
     xin = sam.preprocess(img.to(dev))
     outs = {}
+    default = sam.image_encoder.fold_ln
     for fold in (False, True):
         sam.image_encoder.fold_ln = fold
         outs[fold] = sam.image_encoder(xin).cpu().clone()
-    sam.image_encoder.fold_ln = False
+    sam.image_encoder.fold_ln = default
     for fold, o in outs.items():
         err = (o - ref).abs()
         print(f"fold_ln={fold}: max abs err {err.max():.3e} mean {err.mean():.3e}")
