@@ -42,6 +42,8 @@ def main(outdir, out_json, tile):
         esz = 4 if epi == 2 else 2
         alg_read = 2 * (M * K + N * K) + (4 * M * N if epi == 2 else 0)
         alg_write = esz * M * N
+        if epi == 2 and kern.endswith("_ln"):       # folded-LayerNorm producer: also the fp16 copy of x and the row sums
+            alg_write += 2 * M * N + M * (N // 64) * 8
         shapes[key] = {"M": M, "N": N, "K": K, "epilogue": epi, "kernel": kern, "launches": f[kern][0],
                        "read_bytes_per_launch": int(read_b), "write_bytes_per_launch": int(write_b),
                        "algorithmic_read_bytes": alg_read, "algorithmic_write_bytes": alg_write,
