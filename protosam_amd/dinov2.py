@@ -103,6 +103,7 @@ class DinoVisionTransformer(nn.Module):
         # consumers' 3.8 ms; it also lowers the embedding error). Round 2 measured the opposite on the HIP kernels (122.2 vs 124.3:
         # +10 ms of epilogue). PSAM_FOLD_LN=0 / `fold_ln = False` selects the separate passes.
         self.fold_ln = os.environ.get("PSAM_FOLD_LN", "1") != "0"
+        self.fold_min_fill = 0.8      # ... where the launches fill the CUs (ops.fold_pays); 0 = always
 
     # -- weight packing (fp16 GEMM operands); rebuilt whenever parameters change -----------------------------
     def _apply(self, fn, *a, **k):
@@ -217,6 +218,8 @@ class DinoVisionTransformer(nn.Module):
         # consuming GEMM applies (mean, rstd) in its epilogue. The first norm1 stays a pass of its own: the cls / register rows
         # come from `broadcast_rows`, not from a GEMM epilogue.
         fold = self.fold_ln and not ops.QKV_HEAD_MAJOR and D % 64 == 0
+        M = B * N
+        fold = fold and ops.fold_pays(M, D, x.device, self.fold_min_fill)   # (small launches: separate passes are faster)
         M = B * N
         x16, stats, mr = ws["ln"], ws["stats"], ws["mr"]
         fk = dict(out16=x16, stats=stats) if fold else {}

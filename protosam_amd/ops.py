@@ -126,6 +126,19 @@ def gemm(a, w, bias=None, out=None, epilogue=EPI_F16, resid=None, gamma=None, re
     return out
 
 
+_CU_COUNT = {}
+
+
+def fold_pays(M, D, device, min_fill=0.8):
+    """Whether the folded LayerNorm is worth it for residual-stream GEMMs of M rows x D columns: its producer / consumer epilogues
+    live in the 256x256-tile assembly kernels (and, slower, in the HIP kernels), so the launches must fill the CUs with 256-tiles -
+    one slice at a time (80 tiles for 256 CUs) the half-tile kernels with separate LayerNorm passes are faster (85 vs 73 slices/s)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _CU_COUNT:
+        _CU_COUNT[idx] = torch.cuda.get_device_properties(idx).multi_processor_count
+    return ((M + 255) // 256) * (D // 256) >= min_fill * _CU_COUNT[idx]
+
+
 def ln_mr_buffer(M, device):
     """(mean, rstd) buffer of psam_ln_finalize: fp32 [M][2] followed by the fp16 MFMA fragments of -mean [M][8] (6 floats per row)."""
     return torch.empty(6 * M, dtype=torch.float32, device=device)

@@ -97,6 +97,7 @@ class ImageEncoderViT(nn.Module):
         # consumers' 3.8 ms; it also lowers the embedding error). Round 2 measured the opposite on the HIP kernels (122.2 vs 124.3:
         # +10 ms of epilogue). PSAM_FOLD_LN=0 / `fold_ln = False` selects the separate passes.
         self.fold_ln = os.environ.get("PSAM_FOLD_LN", "1") != "0"
+        self.fold_min_fill = 0.8      # ... where the launches fill the CUs (ops.fold_pays); 0 = always
 
     def _apply(self, fn, *a, **k):
         self._packed, self._ws = None, {}
@@ -170,6 +171,8 @@ class ImageEncoderViT(nn.Module):
         hd = D // H
         x = ws["x"]
         fold = self.fold_ln and not ops.QKV_HEAD_MAJOR and D % 64 == 0
+        M = B * N
+        fold = fold and ops.fold_pays(M, D, x.device, self.fold_min_fill)   # (small launches: separate passes are faster)
         M = B * N
         x16, stats, mr = ws["ln"], ws["stats"], ws["mr"]
         fk = dict(out16=x16, stats=stats) if fold else {}
