@@ -217,7 +217,8 @@ def main():
     nl, tg, fl = timer.summary()
     achieved = fl / tg / 1e12 if tg > 0 else 0.0
     roofline = {"bound": "mfma", "kernel": "psam_gemm_f16 (fp16 operands, fp32 accumulate; every Linear / conv-as-GEMM of the "
-                                           "two ViT encoders)",
+                                           "two ViT encoders; the launches also carry the blocks' LayerNorms, folded into "
+                                           "their epilogues - no separate LayerNorm pass runs)",
                 "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F16_TFLOPS, 4),
                 # HBM-side bytes per launch come from rocprofv3 PMC passes, which cannot run inside this process: taken from the
