@@ -71,6 +71,40 @@ def test_config_full_depth_vs_oracle_record(dev, cfg):
     print(f"config {cfg}: worst max |dprob(low_res)| {worst:.2e} (bound {TOL:.0e})")
 
 
+@pytest.mark.parametrize("cfg", [4, 44])
+def test_batched_step_vs_oracle_record(dev, cfg):
+    """The benchmark's own path against the same records: 16 slices of one z-part per `forward_batch` call - the launches then fill
+    the CUs and the encoders run with the LayerNorms folded into the assembly GEMM's epilogues (ops.fold_pays), which the
+    one-slice calls above do not reach."""
+    from protosam_amd.metrics import dice
+    from protosam_amd.runner import part_assign, run_slices
+    gold = np.load(os.path.join(GOLD, "fullsize_cfg4.npz" if cfg == 4 else "fullsize_cfg4_heavytail.npz"))
+    model, vol_d, sup_imgs, sup_masks, n, slices, flagsets = _volume_setup(dev, cfg)
+    assert model.sam.image_encoder.fold_ln
+    fname = next(k for k, fl in flagsets.items() if not fl["use_cca"])
+    model.use_cca = False
+    worst = 0.0
+    for z in slices:
+        part = [y for y in range(n) if part_assign(y, n) == part_assign(z, n)]
+        i = part.index(z)
+        zs = part[max(0, min(i - 8, len(part) - 16)):][:16]
+        masks, _ = run_slices(model, vol_d, sup_imgs, sup_masks, zs, dev, batch=16)
+        st = model.last_stats
+        b = zs.index(z)
+        _, start, cnt = next(sp for sp in st["spans"] if sp[0] == b)
+        k = f"z{z}_{fname}"
+        ref_prob = torch.from_numpy(gold[k + "_prob"].astype(np.float32) / 65535.0)
+        assert cnt == ref_prob.shape[0]
+        prob = torch.sigmoid(st["low_res"][start:start + cnt, st["sel"]].cpu())
+        perr = (prob - ref_prob).abs().max().item()
+        serr = float(np.abs(st["iou"][start:start + cnt, st["sel"]].cpu().numpy() - gold[k + "_scores"]).max())
+        d = dice(masks[b].cpu().float(), _unpack(gold[k + "_mask"], 512))
+        print(f"config {cfg} batched z={z} ({len(zs)} slices per call): max |dprob(low_res)| {perr:.2e}, scores {serr:.2e}, Dice {d:.5f}")
+        worst = max(worst, perr)
+        assert perr <= TOL and serr <= TOL and d >= 0.998
+    print(f"config {cfg} batched: worst max |dprob(low_res)| {worst:.2e} (bound {TOL:.0e})")
+
+
 @pytest.mark.parametrize("cfg", [3, 4])
 def test_volume_runner_equals_per_slice_forward(dev, cfg):
     """`run_slices` with 16-slice batches over the whole 32- / 64-slice volume == one `ProtoSAM.forward` per slice."""
