@@ -931,8 +931,9 @@ __global__ __launch_bounds__(448, 4) void wattn_kernel(AttnArgs p) {
 // pointless arithmetic - no measurable change. Both dropped.)
 // LDS: K 2 x 33 280 + V 33 280 + tables 20 480 + one-hot 13 312 + 14 x 2 KiB prologue scratch = 162 304 bytes.
 #ifndef PSAM_WATTN_NTT
-#define PSAM_WATTN_NTT 2   // 64-key chunks (4): 322 vs 314 us - no gain
-#endif
+#define PSAM_WATTN_NTT 4   // key tiles of 16 per chunk. 64-key chunks (4) against 32-key ones (2): 322 vs 314 us in round 2 - no gain; 343 vs 359 us
+#endif                     // in round 3, once the DMA address arithmetic was out of the way (the kernel is bound by its VALU + MFMA issue)
+
 template <int HD>
 __global__ __launch_bounds__(896, 4) void wattn_p_kernel(AttnArgs p, int nitems) {
   constexpr int NW = 14, NT = NW * 64;

@@ -432,7 +432,9 @@ def test_window_attention_fused_relpos(dev):
         b = ops.attention(qkv, B, N, H, hd, scale, mode=2, rpack=rp, pad_row=pad, gh=g, gw=g, ws=ws)
         err = (a.float() - b.float()).abs().max().item()
         print(f"H{H} hd{hd}: fused vs two-kernel max abs diff {err:.2e}")
-        assert err < 2e-3 and torch.isfinite(b.float()).all()
+        # (outputs reach |4|: one fp16 ulp there is 3.9e-3 - the two kernels take their rescale decisions over different key chunks)
+        assert torch.isfinite(b.float()).all()
+        torch.testing.assert_close(b.float(), a.float(), rtol=2e-3, atol=2e-3)
 
 
 @pytest.mark.parametrize("mode,N,H,hd,B", [(0, 1297, 12, 64, 2), (0, 200, 3, 80, 1), (1, 4096, 2, 80, 1), (1, 4096, 2, 64, 1)])
