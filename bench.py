@@ -466,16 +466,22 @@ def cpu_baseline(model, alp_sd, vol, svol, slab, args, dev):
         t0 = time.perf_counter()
         pred_ref, scores_ref = oracle_slice(z, taps)
         t_all += time.perf_counter() - t0
-        masks, _ = run_slices(model, vol_d, sup_d, msk_d, [z], dev)         # GPU result for the same slice
-        g, r = masks[0].cpu().float(), pred_ref.float()
+        # GPU result for the same slice THROUGH THE TIMED PATH: a micro-batch of the slice's z-part, as the steps above run them
+        part_z = [y for y in range(args.slices) if part_assign(y, args.slices) == part_assign(z, args.slices)]
+        i = part_z.index(z)
+        zs_b = part_z[max(0, min(i - args.micro // 2, len(part_z) - args.micro)):][:args.micro]
+        masks, _ = run_slices(model, vol_d, sup_d, msk_d, zs_b, dev, batch=args.micro)
+        b = zs_b.index(z)
+        g, r = masks[b].cpu().float(), pred_ref.float()
         st = model.last_stats
+        span = next((sp for sp in st.get("spans", []) if sp[0] == b), None) if args.micro > 1 else (0, 0, st.get("n_prompts", 0))
         p = {"slice": z, "dice_final_mask": round(dice(g, r), 5), "flipped_pixels": int((g != r).sum()),
-             "components": int(st.get("n_prompts", 0))}
-        if "low_res" in st and len(taps.get("low_res", [])) == st["low_res"].shape[0]:
-            low = st["low_res"][:, st["sel"]].cpu()
+             "components": int(span[2]) if span else 0, "slices_in_call": len(zs_b)}
+        if "low_res" in st and span and len(taps.get("low_res", [])) == span[2]:
+            low = st["low_res"][span[1]:span[1] + span[2], st["sel"]].cpu()
             low_ref = torch.stack([l[0] for l in taps["low_res"]])
             p["max_abs_dprob_low_res"] = float((torch.sigmoid(low) - torch.sigmoid(low_ref)).abs().max())
-            p["max_abs_dscore"] = float(np.abs(st["iou"][:, st["sel"]].cpu().numpy() - np.array(scores_ref)).max())
+            p["max_abs_dscore"] = float(np.abs(st["iou"][span[1]:span[1] + span[2], st["sel"]].cpu().numpy() - np.array(scores_ref)).max())
         parities.append(p)
     log(f"cpu_baseline: {len(zs_all)} slices in {t_all:.1f}s on {cores} threads")
     cpu = {"value": round(len(zs_all) / t_all, 5), "unit": "slices/s", "cores": cores, "kind": "port",
