@@ -159,6 +159,10 @@ def main():
     if rank == 0:
         log(f"built model + volume in {time.time() - t0:.1f}s (world {world})")
 
+    # The headline is measured with the two encoders on ONE stream: `roofline` prices every GEMM launch with its own pair of HIP events
+    # (and must agree with rocprofv3's per-kernel durations), which concurrent kernels of a second stream would blur. The library's
+    # default ("auto": SAM encoder beside DINOv2 + ALP on a second stream once the calls are dense) is reported as a leg of its own.
+    model.overlap_streams = "0"
     strong = args.scaling == "strong"
     if strong and args.slices % world:
         raise SystemExit("--scaling strong needs --slices divisible by the number of ranks")
@@ -295,6 +299,15 @@ def extras(args, model, step, ops, psmod, B, torch, dev):
         hbm.append(e)
     ops.TIMERS.clear()
     out["roofline_hbm"] = hbm
+    # (a2) the library's default stream mode: SAM image encoder on a second stream beside DINOv2 + ALP + connected components
+    model.overlap_streams = "auto"
+    timed(4)                                                     # ("auto" overlaps after four dense batched calls)
+    dt = timed(3)
+    model.overlap_streams = "0"
+    out["overlap_streams_auto"] = {"value": round(3 * B / dt, 2), "unit": "slices/s",
+                                   "note": "headline configuration with PSAM_OVERLAP_STREAMS=auto (the library default): the SAM image "
+                                           "encoder runs on a second HIP stream beside the coarse model; per-kernel event timing is "
+                                           "blurred by the concurrency, so the headline and its roofline are measured without it"}
     # (b) the reference-shaped call pattern: one ProtoSAM.forward per slice (validation_protosam.py:387)
     timed(1, micro=1)
     dt = timed(1, micro=1)

@@ -262,9 +262,15 @@ class ProtoSAM(nn.Module):
         self._ccl = None
         self._bufs = {}
         self.last_stats = {}
-        # measured on MI355X (tools/ab_env.sh PSAM_OVERLAP_STREAMS "1 0", 16-slice steps): 107.0 / 110.3 vs 108.2 / 107.8 slices/s -
-        # no gain (the encoder's GEMMs already fill the chip), and concurrent kernels blur per-kernel timing: off by default
-        self.overlap_streams = os.environ.get("PSAM_OVERLAP_STREAMS", "0") != "0"
+        # The SAM image encoder does not depend on the coarse model: on a second HIP stream it shares the GPU with DINOv2 + ALP +
+        # connected components, whose small launches and part-filled rounds then cost nothing. Round 2 measured no gain (107.0 / 110.3
+        # vs 108.2 / 107.8 slices/s); with round 3's kernels it is 150.6 / 151.1 vs 148.3 / 148.5 (same box, interleaved). The price:
+        # the encoder runs on EVERY slice of the batch, before anybody knows which coarse masks are empty (the sequential order skips
+        # those, ProtoSAM.py:612-613: on the sparse test volume that is 195 vs 163 slices/s). PSAM_OVERLAP_STREAMS: "auto" (default)
+        # overlaps a batched call when the last four batched calls of this model had no empty slice (and no per-kernel timer is
+        # attached: concurrent kernels blur those), "1" always, "0" never. Same results.
+        self.overlap_streams = os.environ.get("PSAM_OVERLAP_STREAMS", "auto")
+        self._dense_run = 0
 
     def get_sam(self, checkpoint_path, use_sam_trans):
         """ProtoSAM.py:205-220. `random:<vit_b|vit_l|vit_h>[:seed[:depth]]` builds seeded synthetic weights instead of reading a
@@ -427,7 +433,10 @@ class ProtoSAM(nn.Module):
         # 0. The SAM image encoder depends on the query image only, not on the coarse model: with `overlap_streams` it is
         #    enqueued on a second HIP stream so the two ViTs share the GPU (optional, see __init__)
         main = torch.cuda.current_stream(dev)
-        side = self._side_stream(dev) if self.overlap_streams else None
+        mode = self.overlap_streams
+        if isinstance(mode, str):
+            mode = True if mode == "1" else False if mode == "0" else (self._dense_run >= 4 and B >= 2 and STAGE_TIMER is None and not ops.TIMERS)
+        side = self._side_stream(dev) if mode else None
         feat_tok = None
         if side is not None:
             side.wait_stream(main)                                              # inputs / earlier work on `main` are visible
@@ -482,6 +491,8 @@ class ProtoSAM(nn.Module):
             main.wait_event(bufs["sam_done"])                                   # the decoder below consumes feat_tok on `main`
             feat_tok.record_stream(main)
         tabs = cw.tabs_host[:B].numpy()
+        if B >= 2:                                                              # (what "auto" overlap looks at next time)
+            self._dense_run = self._dense_run + 1 if all(int(tabs[b][0]) > 0 for b in range(B)) else 0
         results = [None] * B
         coords, labels, img_idx, slice_idx, spans = [], [], [], [], []   # img_idx: row of feat_tok, slice_idx: slice
         stats = []

@@ -177,6 +177,28 @@ def test_forward_batch_equals_per_slice(dev):
         assert len(sb) == len(s1) and np.allclose(np.array(sb, dtype=np.float64), np.array(s1, dtype=np.float64), atol=2e-3)
 
 
+def test_forward_batch_overlapped_streams_same_result(dev):
+    """`overlap_streams`: the SAM encoder on a second stream next to DINOv2 + ALP + connected components gives the same masks and
+    scores as the sequential order; "auto" turns it on only after a call without empty slices."""
+    from protosam_amd.protosam import InputFactory, TYPE_ALPNET
+    from protosam_amd.synth import synth_pair
+    model, _ = _build(dev, "random:vit_b:1234:2", 2, use_bbox=True, use_points=True, point_mode="both")
+    s_img, s_m, q0, _ = synth_pair(512, seed=0)
+    _, _, q1, _ = synth_pair(512, seed=3)
+    qs = torch.cat([q0, q1, q0], 0).to(dev)
+    inp = InputFactory.create_input(TYPE_ALPNET, qs, support_images=[s_img], support_labels=[s_m], isval=True, val_wsize=2)
+    inp.to(dev)
+    outs = {}
+    for mode in ("0", "1", "auto", "auto", "auto"):
+        model.overlap_streams = mode
+        outs.setdefault(mode, []).append(model.forward_batch(qs, inp))
+    assert model._dense_run == 5                               # the last "auto" call ran overlapped (four dense calls before it)
+    ref = outs["0"][0]
+    for got in (outs["1"][0], outs["auto"][0], outs["auto"][2]):
+        for (pa, sa), (pb, sb) in zip(ref, got):
+            assert torch.equal(pa, pb) and sa == sb
+
+
 @pytest.mark.parametrize("mask_only", [False, True])
 def test_forward_batch_skips_sam_for_empty_slices(dev, mask_only):
     """A slice whose coarse mask is empty never reaches SAM (ProtoSAM.py:612-613 returns before set_image): in a batch only
