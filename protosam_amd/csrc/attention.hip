@@ -1611,6 +1611,43 @@ extern "C" int psam_attention_set_variant(int v) {   // bit 0: V2 softmax in the
   return PSAM_OK;
 }
 
+// ---- the hand-scheduled global kernel of csrc/gattn_asm_gen.py (hd = 80, rel-pos, N a multiple of 256): PSAM_GATTN=3 -------------
+hipFunction_t psam_asm_function(const char* name);     // csrc/gemm.hip: the assembly code object
+struct GattnAsmArgs {
+  const void* qkv; void* out; const float* rel_h; const float* rel_w;
+  int N, H, lg_nqb, lg_H; float sl2; int rs2, hs2, ws2, NT, orow;
+};
+static_assert(sizeof(GattnAsmArgs) == 72, "kernarg layout of gattn_asm_gen.py");
+static int ilog2_exact(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return (1 << l) == v ? l : -1;
+}
+static bool gattn_asm_eligible(const AttnArgs& p, int mode, int hd) {
+  if (mode != 1 || hd != 80 || (p.N % 256) != 0 || p.N < 256 || ((p.B * p.H) % 8) != 0) return false;
+  if (ilog2_exact(p.N / 256) < 0 || ilog2_exact(p.H) < 0) return false;
+  const long long lim = 0x7fffffffLL;
+  return (long long)p.N * p.ts * 2 < lim && p.hs * 2 < lim && p.ws_ * 2 < lim && (long long)p.N * p.H * hd * 2 < lim;
+}
+static int launch_gattn_asm(const AttnArgs& p, hipStream_t s) {
+  hipFunction_t f = psam_asm_function("psam_gattn_asm_80_rel");
+  if (!f) return PSAM_ERR_LAUNCH;
+  GattnAsmArgs a;
+  a.qkv = p.qkv; a.out = p.out; a.rel_h = p.rel_h; a.rel_w = p.rel_w;
+  a.N = p.N; a.H = p.H; a.lg_nqb = ilog2_exact(p.N / 256); a.lg_H = ilog2_exact(p.H);
+  a.sl2 = p.scale * 1.4426950408889634f;
+  a.rs2 = (int)(p.ts * 2); a.hs2 = (int)(p.hs * 2); a.ws2 = (int)(p.ws_ * 2);
+  a.NT = p.N / 64; a.orow = p.H * 80 * 2;
+  size_t sz = sizeof(a);
+  void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  const int grid = (p.B * p.H) * (p.N / 256);
+  if (hipModuleLaunchKernel(f, grid, 1, 1, 256, 1, 1, 0, s, nullptr, extra) != hipSuccess) {
+    (void)hipGetLastError();
+    return PSAM_ERR_LAUNCH;
+  }
+  return PSAM_OK;
+}
+
 template <int HD, bool V2>
 static int launch_attn(AttnArgs p, int mode, hipStream_t s) {
   if (mode == 2) {
@@ -1638,6 +1675,7 @@ static int launch_attn(AttnArgs p, int mode, hipStream_t s) {
     dim3 grid(groups8 * 8 * p.nqb), block(NW * 64);
     const bool full = (p.N % 64) == 0;
     if (g_gattn < 0) { const char* e = getenv("PSAM_GATTN"); g_gattn = e ? atoi(e) : 1; }
+    if (g_gattn == 3 && gattn_asm_eligible(p, mode, HD)) return launch_gattn_asm(p, s);
     if (g_gattn && V2) {
       if (mode == 1) {
         if (full) hipLaunchKernelGGL((gattn_kernel<HD, 1, true>), grid, block, 0, s, p);

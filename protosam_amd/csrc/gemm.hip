@@ -1120,6 +1120,16 @@ static const hipFunction_t* asm_load(int family = 1) {
   for (int i = nf; i < 6; ++i) f[i] = f[i - 3];
   return (g_asm_fns[key] = f).data();
 }
+// other kernels of the same code object (csrc/gattn_asm_gen.py): looked up by name from attention.hip
+hipFunction_t psam_asm_function(const char* name) {
+  if (!asm_load(1)) return nullptr;
+  static std::map<std::string, hipFunction_t> cache;
+  auto it = cache.find(name);
+  if (it != cache.end()) return it->second;
+  hipFunction_t f = nullptr;
+  if (hipModuleGetFunction(&f, g_asm_mod, name) != hipSuccess) { (void)hipGetLastError(); f = nullptr; }
+  return cache[name] = f;
+}
 struct AsmTable { int grid; int* dev; };
 static std::map<unsigned long long, AsmTable> g_asm_tabs;
 // work list of workgroup b: entry i at tab[i * G + b] = tm | tn << 16, terminated (and padded two rows deep) by -1
