@@ -1615,9 +1615,9 @@ extern "C" int psam_attention_set_variant(int v) {   // bit 0: V2 softmax in the
 hipFunction_t psam_asm_function(const char* name);     // csrc/gemm.hip: the assembly code object
 struct GattnAsmArgs {
   const void* qkv; void* out; const float* rel_h; const float* rel_w;
-  int N, H, lg_nqb, lg_H; float sl2; int rs2, hs2, ws2, NT, orow;
+  int N, H, lg_nqb, lg_H; float sl2; int rs2, hs2, ws2, NT, orow; float rwmul; int pad;
 };
-static_assert(sizeof(GattnAsmArgs) == 72, "kernarg layout of gattn_asm_gen.py");
+static_assert(sizeof(GattnAsmArgs) == 80, "kernarg layout of gattn_asm_gen.py");
 static int ilog2_exact(int v) {
   int l = 0;
   while ((1 << l) < v) ++l;
@@ -1638,6 +1638,8 @@ static int launch_gattn_asm(const AttnArgs& p, hipStream_t s) {
   a.sl2 = p.scale * 1.4426950408889634f;
   a.rs2 = (int)(p.ts * 2); a.hs2 = (int)(p.hs * 2); a.ws2 = (int)(p.ws_ * 2);
   a.NT = p.N / 64; a.orow = p.H * 80 * 2;
+  a.rwmul = 1.0f / p.scale;      // rel_w is staged as rel_w / scale: it enters the score MFMAs as their accumulator input
+  a.pad = 0;
   size_t sz = sizeof(a);
   void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
   const int grid = (p.B * p.H) * (p.N / 256);
