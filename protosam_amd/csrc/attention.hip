@@ -1606,7 +1606,8 @@ static int g_gattn = -1;   // 1: gattn_kernel for modes 0 / 1
 static int g_wattn = -1;   // 1: wattn_kernel for mode 2 (needs rpack with the appended tables), 0: attn_kernel<HD, 2, 7>
 extern "C" int psam_attention_set_variant(int v) {   // bit 0: V2 softmax in the global kernels (0 = round 1's serial chains); bit 1: wattn_kernel
   g_attn_v2 = (v & 1) ? 1 : 0;                        // for the windows. Default 5; A/B and tests
-  g_gattn = (v & 8) ? 0 : 1;                          // bit 3: 1 = the register-staged global kernel (attn_kernel), 0 = gattn_kernel
+  g_gattn = (v & 8) ? 0 : (v & 16) ? 1 : 3;            // bit 3: the register-staged global kernel (attn_kernel); bit 4: gattn_kernel (HIP, DMA-fed)
+                                                      // everywhere; neither: the assembly kernel (gattn_asm_gen.py) where it applies
   g_wattn = (v >> 1) & 3;                             // bits 1-2: 0 attn_kernel<HD, 2, 7>, 1 wattn_kernel, 2 wattn_p_kernel
   return PSAM_OK;
 }
@@ -1676,7 +1677,7 @@ static int launch_attn(AttnArgs p, int mode, hipStream_t s) {
     const int groups8 = (p.B * p.H + 7) / 8;
     dim3 grid(groups8 * 8 * p.nqb), block(NW * 64);
     const bool full = (p.N % 64) == 0;
-    if (g_gattn < 0) { const char* e = getenv("PSAM_GATTN"); g_gattn = e ? atoi(e) : 1; }
+    if (g_gattn < 0) { const char* e = getenv("PSAM_GATTN"); g_gattn = e ? atoi(e) : 3; }   // 3: the assembly kernel where it applies, else gattn_kernel
     if (g_gattn == 3 && gattn_asm_eligible(p, mode, HD)) return launch_gattn_asm(p, s);
     if (g_gattn && V2) {
       if (mode == 1) {

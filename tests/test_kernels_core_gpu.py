@@ -437,7 +437,8 @@ def test_window_attention_fused_relpos(dev):
         torch.testing.assert_close(b.float(), a.float(), rtol=2e-3, atol=2e-3)
 
 
-@pytest.mark.parametrize("mode,N,H,hd,B", [(0, 1297, 12, 64, 2), (0, 200, 3, 80, 1), (1, 4096, 2, 80, 1), (1, 4096, 2, 64, 1)])
+@pytest.mark.parametrize("mode,N,H,hd,B", [(0, 1297, 12, 64, 2), (0, 200, 3, 80, 1), (1, 4096, 2, 80, 1), (1, 4096, 2, 64, 1), (1, 4096, 8, 80, 1),
+                                           (1, 4096, 16, 80, 1)])
 def test_attention_softmax_variants_agree(dev, mode, N, H, hd, B):
     """V2 (tree reductions, one rescale decision for both query tiles, row sums on the matrix pipe) against the round-1 serial
     form and the fp32 reference, including rows whose maximum jumps late in the key sequence (the lazy-rescale branch: a key
@@ -457,7 +458,9 @@ def test_attention_softmax_variants_agree(dev, mode, N, H, hd, B):
         kw = dict(mode=1, rel_h=rel_h, rel_w=rel_w, gh=g, gw=g)
         rel = (rel_h.view(B, H, N, g, 1) + rel_w.view(B, H, N, 1, g)).reshape(B, H, N, N)
     outs = []
-    for v in (0, 9, 1):   # round-1 serial softmax, V2 on the register-staged kernel, V2 on the DMA-fed kernel (gattn_kernel)
+    # round-1 serial softmax, V2 on the register-staged kernel, V2 on the DMA-fed HIP kernel (gattn_kernel), the default: the assembly
+    # kernel of csrc/gattn_asm_gen.py where it applies (rel-pos, hd = 80, B * H a multiple of 8, N a multiple of 256: the last two cases)
+    for v in (0, 9, 17, 1):
         ops.attention_set_variant(v)
         try:
             outs.append(ops.attention(qkv, B, N, H, hd, scale, **kw).float())
