@@ -438,7 +438,7 @@ def test_window_attention_fused_relpos(dev):
 
 
 @pytest.mark.parametrize("mode,N,H,hd,B", [(0, 1297, 12, 64, 2), (0, 200, 3, 80, 1), (1, 4096, 2, 80, 1), (1, 4096, 2, 64, 1), (1, 4096, 8, 80, 1),
-                                           (1, 4096, 16, 80, 1)])
+                                           (1, 4096, 16, 80, 1), (1, 1024, 8, 80, 2), (1, 512, 8, 80, 1)])
 def test_attention_softmax_variants_agree(dev, mode, N, H, hd, B):
     """V2 (tree reductions, one rescale decision for both query tiles, row sums on the matrix pipe) against the round-1 serial
     form and the fp32 reference, including rows whose maximum jumps late in the key sequence (the lazy-rescale branch: a key
@@ -451,12 +451,12 @@ def test_attention_softmax_variants_agree(dev, mode, N, H, hd, B):
     scale = hd ** -0.5
     kw, rel = {}, None
     if mode == 1:
-        g = 64
+        g, gh = 64, N // 64                                                                # (gw is 64 in this mode; gh rows of keys)
         rel_h = _rand((B, H, N, g), dev, 0.7, 32)
         rel_w = _rand((B, H, N, g), dev, 0.7, 33)
-        rel_h[0, 0, 100, 50] = 30.0                                                        # a spike in the bias itself
-        kw = dict(mode=1, rel_h=rel_h, rel_w=rel_w, gh=g, gw=g)
-        rel = (rel_h.view(B, H, N, g, 1) + rel_w.view(B, H, N, 1, g)).reshape(B, H, N, N)
+        rel_h[0, 0, 100, min(50, gh - 1)] = 30.0                                           # a spike in the bias itself
+        kw = dict(mode=1, rel_h=rel_h, rel_w=rel_w, gh=gh, gw=g)
+        rel = (rel_h[..., :gh].reshape(B, H, N, gh, 1) + rel_w.view(B, H, N, 1, g)).reshape(B, H, N, N)
     outs = []
     # round-1 serial softmax, V2 on the register-staged kernel, V2 on the DMA-fed HIP kernel (gattn_kernel), the default: the assembly
     # kernel of csrc/gattn_asm_gen.py where it applies (rel-pos, hd = 80, B * H a multiple of 8, N a multiple of 256: the last two cases)
