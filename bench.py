@@ -309,10 +309,13 @@ def extras(args, model, step, ops, psmod, B, torch, dev):
                                            "encoder runs on a second HIP stream beside the coarse model; per-kernel event timing is "
                                            "blurred by the concurrency, so the headline and its roofline are measured without it"}
     # (b) the reference-shaped call pattern: one ProtoSAM.forward per slice (validation_protosam.py:387)
+    model.overlap_streams = "auto"                                # (the library default; no per-kernel timing in this leg)
     timed(1, micro=1)
     dt = timed(1, micro=1)
+    model.overlap_streams = "0"
     out["per_slice_forward"] = {"value": round(B / dt, 2), "unit": "slices/s",
-                                "note": "micro_batch 1: one ProtoSAM.forward call per slice, support cached"}
+                                "note": "micro_batch 1: one ProtoSAM.forward call per slice, support cached, PSAM_OVERLAP_STREAMS=auto "
+                                        "(the SAM encoder on a second stream beside the coarse model)"}
     # (b2) a scan whose organ covers only part of the z range and comes with satellites: empty coarse masks (SAM skipped for
     # the slice) and several prompt sets per slice inside the timed region; every step visits all three z-parts
     from protosam_amd.synth import synth_volume

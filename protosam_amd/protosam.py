@@ -267,8 +267,9 @@ class ProtoSAM(nn.Module):
         # vs 108.2 / 107.8 slices/s); with round 3's kernels it is 150.6 / 151.1 vs 148.3 / 148.5 (same box, interleaved). The price:
         # the encoder runs on EVERY slice of the batch, before anybody knows which coarse masks are empty (the sequential order skips
         # those, ProtoSAM.py:612-613: on the sparse test volume that is 195 vs 163 slices/s). PSAM_OVERLAP_STREAMS: "auto" (default)
-        # overlaps a batched call when the last four batched calls of this model had no empty slice (and no per-kernel timer is
-        # attached: concurrent kernels blur those), "1" always, "0" never. Same results.
+        # overlaps a call when the last four calls of this model had no empty slice (and no per-kernel timer is attached: concurrent
+        # kernels blur those), "1" always, "0" never. Same results. One slice per call (the reference's convention) gains most:
+        # 88.0 -> 100.6 slices/s, the coarse model's ~150 small launches run beside the encoder's GEMMs.
         self.overlap_streams = os.environ.get("PSAM_OVERLAP_STREAMS", "auto")
         self._dense_run = 0
 
@@ -435,7 +436,7 @@ class ProtoSAM(nn.Module):
         main = torch.cuda.current_stream(dev)
         mode = self.overlap_streams
         if isinstance(mode, str):
-            mode = True if mode == "1" else False if mode == "0" else (self._dense_run >= 4 and B >= 2 and STAGE_TIMER is None and not ops.TIMERS)
+            mode = True if mode == "1" else False if mode == "0" else (self._dense_run >= 4 and STAGE_TIMER is None and not ops.TIMERS)
         side = self._side_stream(dev) if mode else None
         feat_tok = None
         if side is not None:
@@ -491,8 +492,8 @@ class ProtoSAM(nn.Module):
             main.wait_event(bufs["sam_done"])                                   # the decoder below consumes feat_tok on `main`
             feat_tok.record_stream(main)
         tabs = cw.tabs_host[:B].numpy()
-        if B >= 2:                                                              # (what "auto" overlap looks at next time)
-            self._dense_run = self._dense_run + 1 if all(int(tabs[b][0]) > 0 for b in range(B)) else 0
+        # (what "auto" overlap looks at next time)
+        self._dense_run = self._dense_run + 1 if all(int(tabs[b][0]) > 0 for b in range(B)) else 0
         results = [None] * B
         coords, labels, img_idx, slice_idx, spans = [], [], [], [], []   # img_idx: row of feat_tok, slice_idx: slice
         stats = []
