@@ -87,7 +87,11 @@ int psam_layernorm(const float* x, const float* w, const float* b, void* y, floa
 int psam_attention_f16(const void* qkv, void* out, const float* rel_h, const float* rel_w, const void* relq,
                        const void* rpack, const void* pad_row, int B, int N, int H, int hd, float scale, int mode, int gh,
                        int gw, int ws, int head_major, void* stream);
-/* softmax code path of psam_attention_f16: 1 = V2 (default), 0 = the serial round-1 form (A/B, tests) */
+/* kernel selection of psam_attention_f16 (A/B, tests; default 5). bit 0: V2 softmax of the HIP global kernels (0 = the serial round-1
+ * form); bits 1-2: window kernel (0 attn_kernel, 1 wattn_kernel, 2 the persistent wattn_p_kernel); bit 3: the register-staged HIP
+ * global kernel; bit 4: the DMA-fed HIP global kernel everywhere; neither bit 3 nor 4: the assembly global kernel
+ * (csrc/gattn_asm_gen.py) where it applies - rel-pos, hd = 80, N a multiple of 256, B * H a multiple of 8, H and N / 256 powers of
+ * two - and the DMA-fed HIP kernel elsewhere. */
 int psam_attention_set_variant(int v);
 
 /* rel_h[b,h,n,k] = q . Rh[qy - k + K-1], rel_w likewise (UNSCALED q), as an MFMA GEMM against the whole table followed by

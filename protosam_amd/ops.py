@@ -332,8 +332,9 @@ def attention(qkv, B, N, H, hd, scale, out=None, mode=0, rel_h=None, rel_w=None,
 
 def attention_set_variant(v):
     """bit 0: V2 softmax in the global kernels (0 = round-1 serial form); bits 1-2: window kernel of the fused rel-pos path
-    (0 attn_kernel, 1 wattn_kernel, 2 the persistent wattn_p_kernel); bit 3: the register-staged global kernel instead of the
-    DMA-fed gattn_kernel. Default 5; for A/B and the equivalence tests."""
+    (0 attn_kernel, 1 wattn_kernel, 2 the persistent wattn_p_kernel); bit 3: the register-staged HIP global kernel; bit 4: the
+    DMA-fed HIP global kernel everywhere (neither: the assembly global kernel where it applies, see include/protosam_hip.h).
+    Default 5; for A/B and the equivalence tests."""
     _lib.check(_lib.lib().psam_attention_set_variant(int(v)), "psam_attention_set_variant")
 
 
