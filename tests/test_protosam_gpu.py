@@ -197,6 +197,12 @@ def test_forward_batch_overlapped_streams_same_result(dev):
     for got in (outs["1"][0], outs["auto"][0], outs["auto"][2]):
         for (pa, sa), (pb, sb) in zip(ref, got):
             assert torch.equal(pa, pb) and sa == sb
+    # one slice per call (the reference's convention) takes the same two-stream path
+    model.overlap_streams = "0"
+    p0, s0 = model(qs[1:2], inp)
+    model.overlap_streams = "1"
+    p1, s1 = model(qs[1:2], inp)
+    assert torch.equal(p0, p1) and s0 == s1
 
 
 @pytest.mark.parametrize("mask_only", [False, True])
