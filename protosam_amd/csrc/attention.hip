@@ -992,7 +992,17 @@ __global__ __launch_bounds__(896, 4) void wattn_p_kernel(AttnArgs p, int nitems)
     const bool slot = R < KROWS && c < CH;
     G[i] = kxK | (kyK << 4) | (kxV << 8) | (kyV << 12) | (c << 16) | ((slot && keyK < NKEY) ? (1 << 20) : 0) | ((slot && keyV < NKEY) ? (1 << 21) : 0);
   }
-  const int ndma_w = (wv + 2 * NW < NINS) ? 3 : 2;   // DMA instructions this wave issues per image (33 = 5 x 3 + 9 x 2)
+  // K-image DMA instructions this wave ACTUALLY issues per item: a piece whose 64 lanes all fall on the rows of the keys
+  // 196..207 is skipped by dma_image (no lane passes its slot test, the compiler branches around the load: pieces 31 / 32, the
+  // third pieces of waves 3 / 4), so it must not be counted by the vmcnt in front of the first V read either - with the
+  // nominal 33 = 5 x 3 + 9 x 2 those two waves waited one request short and could pass the barrier with a piece of their own
+  // V(it) still in flight. (Pieces that straddle the image edge issue TWO loads - image rows and pad row - which only makes
+  // the counted wait stricter.)
+  int ndma_w = 0;
+#pragma unroll
+  for (int i = 0; i < NDMA; ++i)
+    if (wv + i * NW < NINS && __any((G[i] >> 20) & 1)) ++ndma_w;
+  ndma_w = __builtin_amdgcn_readfirstlane(ndma_w);
   const int qidx = wv * 16 + li;                     // this lane's query (window-local; >= 196: none)
   const int qy = (qidx * 4682) >> 16, qx = qidx - 14 * qy;
 
@@ -1258,7 +1268,8 @@ __global__ __launch_bounds__(896, 4) void wattn_p_kernel(AttnArgs p, int nitems)
         // V(it) complete in every wave: the only newer requests of this wave are the next item's K pieces and query loads
         if (has_next) {
           if (ndma_w == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 + KS) : "memory");
-          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + KS) : "memory");
+          else if (ndma_w == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + KS) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KS) : "memory");   // (no geometry has fewer than two pieces; conservative)
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
