@@ -76,6 +76,14 @@ static void device_geometry() {
   (void)hipGetLastError();
 }
 static inline int num_cus() { device_geometry(); return g_num_cus; }
+// Cap on the persistent grids (psam_gemm_set_option("max_wgs", n) / PSAM_GEMM_MAX_WGS; 0 = none): with half the CUs per launch, two
+// streams run their GEMMs side by side on disjoint CUs (one's epilogue traffic beside the other's k-loops)
+static int g_max_wgs = -1;
+static inline int eff_cus() {
+  if (g_max_wgs < 0) { const char* e = getenv("PSAM_GEMM_MAX_WGS"); g_max_wgs = e ? atoi(e) : 0; }
+  const int n = num_cus();
+  return (g_max_wgs > 0 && g_max_wgs < n) ? g_max_wgs : n;
+}
 static inline bool xcd_maps_apply() { device_geometry(); return g_num_xcds == 8 && g_num_cus % 8 == 0; }
 
 // ---- tile -> workgroup mapping ------------------------------------------------------------------------------------
@@ -1138,12 +1146,12 @@ static std::map<unsigned long long, AsmTable> g_asm_tabs;
 static const AsmTable* asm_table(int ntm, int ntn, int mode, int halves = 0, int wg_per_cu = 1) {
   int dev = 0;
   (void)hipGetDevice(&dev);
-  const unsigned long long key = ((unsigned long long)ntm << 40) | ((unsigned long long)ntn << 20) | ((unsigned long long)(halves ? 1 : 0) << 19) |
+  const unsigned long long key = ((unsigned long long)eff_cus() << 52) | ((unsigned long long)ntm << 40) | ((unsigned long long)ntn << 20) | ((unsigned long long)(halves ? 1 : 0) << 19) |
                                  ((unsigned long long)(halves & 1) << 18) | ((unsigned long long)(wg_per_cu - 1) << 16) | ((unsigned long long)mode << 8) | (unsigned)dev;
   auto it = g_asm_tabs.find(key);
   if (it != g_asm_tabs.end()) return &it->second;
   const int total = tile_map_grid(ntm, ntn, mode);
-  const int G = total < num_cus() * wg_per_cu ? total : num_cus() * wg_per_cu;
+  const int G = total < eff_cus() * wg_per_cu ? total : eff_cus() * wg_per_cu;
   std::vector<std::vector<int>> lists(G);
   for (int b = 0; b < G; ++b)
     for (int idx = b; idx < total; idx += G) {
@@ -1263,6 +1271,7 @@ static int gemm_option(int i) {
   return g_opt[i];
 }
 extern "C" int psam_gemm_set_option(const char* name, int value) {
+  if (name && strcmp(name, "max_wgs") == 0) { g_max_wgs = value > 0 ? value : 0; return PSAM_OK; }
   for (int i = 0; i < OPT_COUNT; ++i)
     if (name && strcmp(name, g_opt_names[i]) == 0) { g_opt[i] = value != 0; return PSAM_OK; }
   return PSAM_ERR_ARG;
@@ -1282,7 +1291,7 @@ static int pick_tile(int M, int N, int K, int epilogue) {
   // part-filled round is lost time); otherwise the 128x128 kernel with two workgroups per CU (measured, tools/gemm_asm_check.py bench)
   if (N % 256 == 0) {
     const long t256 = (long)((M + 255) / 256) * (N / 256);
-    const long ncu = num_cus();
+    const long ncu = eff_cus();
     const long rounds = (t256 + ncu - 1) / ncu;
     // the fp32 residual epilogue with a short K (proj: 20 K-tiles) is better served by two workgroups per CU unless the
     // 256-tiles fill their rounds completely (65536x1280x1280: 603 vs 525 TFLOP/s; 32768x1280x1280, 2.5 rounds: 653 vs 689)
@@ -1300,7 +1309,7 @@ static int pick_tile(int M, int N, int K, int epilogue) {
   // falls back to the 128x128 kernel when their layout rules or minimum K are not met)
   if (N % 128 == 0 && K >= 768) {
     const int half_on = gemm_option(OPT_HALF);
-    const long th = (long)((M + 255) / 256) * (N / 128), ncu = num_cus();
+    const long th = (long)((M + 255) / 256) * (N / 128), ncu = eff_cus();
     if (half_on && th * 2 >= ncu) return 16;
   }
   return 1;

@@ -218,8 +218,9 @@ def gemm_set_tile(tile):
 
 
 def gemm_set_option(name, value):
-    """Dispatch switches of the GEMM: "asm", "half_tiles", "splitk", "nsplit" (see include/protosam_hip.h)."""
-    _lib.check(_lib.lib().psam_gemm_set_option(name.encode(), int(bool(value))), "psam_gemm_set_option")
+    """Dispatch switches of the GEMM: "asm", "half_tiles", "splitk", "nsplit" (0 / 1), "max_wgs" (cap on the persistent grids,
+    0 = none) (see include/protosam_hip.h)."""
+    _lib.check(_lib.lib().psam_gemm_set_option(name.encode(), int(value)), "psam_gemm_set_option")
 
 
 def gemm_asm_variant(v):

@@ -436,7 +436,7 @@ class ProtoSAM(nn.Module):
         main = torch.cuda.current_stream(dev)
         mode = self.overlap_streams
         if isinstance(mode, str):
-            mode = True if mode == "1" else False if mode == "0" else (self._dense_run >= 4 and STAGE_TIMER is None and not ops.TIMERS)
+            mode = True if mode == "1" else False if mode == "0" else (self._dense_run >= 4 and STAGE_TIMER is None and not ops.TIMERS and ops.GEMM_TIMER is None)
         side = self._side_stream(dev) if mode else None
         feat_tok = None
         if side is not None:

@@ -523,3 +523,44 @@ def test_gemm_folded_layernorm(dev, tile, M, D, N2, act):
     print(f"tile {tile} M={M} D={D}: folded max err {err:.2e}, separate LayerNorm pass {err_sep:.2e}")
     torch.testing.assert_close(y, y_ref, rtol=3e-3, atol=3e-3)
     assert err < 2.0 * err_sep + 1e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (4096, 1280, 1280), (33000, 1280, 192), (70001, 768, 128), (2000, 1280, 5120)])
+@pytest.mark.parametrize("ln", [0, 1])
+def test_gemm_fp32_residual_without_gamma(dev, M, N, K, ln):
+    """Tile 15's fp32 epilogue as the SAM encoder calls it (no gamma; in place): its residual slabs travel through the VGPR ring AND
+    through accumulator registers freed by the parked slabs (gemm_asm_gen.py epilogue_f32) - every slab position must get its own rows.
+    Bit-identical to the HIP kernel (tile 11: same arithmetic in the same order), out of place, without a residual, and as the
+    folded-LayerNorm producer (fp16 copy + row sums)."""
+    from protosam_amd import ops
+    a = _rand((M, K), dev, 1.0, 71).half()
+    w = _rand((N, K), dev, 0.05, 72).half()
+    bias = _rand((N,), dev, 0.5, 73)
+    resid = (_rand((M, N), dev, 3.0, 74) + 0.5).contiguous()
+    ref = resid + (a.float() @ w.float().t() + bias)
+    outs = []
+    try:
+        for tile in (15, 11):
+            ops.gemm_set_tile(tile)
+            x = resid.clone()
+            kw = {}
+            if ln:
+                kw = dict(out16=torch.empty((M, N), dtype=torch.float16, device=dev), stats=torch.full((M, N // 64, 2), float("nan"), device=dev))
+            ops.gemm(a, w, bias, out=x, epilogue=ops.EPI_F32, resid=x, **kw)
+            outs.append(x)
+            torch.testing.assert_close(x, ref, rtol=1e-5, atol=2e-4)
+            if ln:
+                assert torch.equal(kw["out16"], x.half())
+                torch.testing.assert_close(kw["stats"][..., 0].sum(1), x.sum(1), rtol=1e-4, atol=2e-2)
+                torch.testing.assert_close(kw["stats"][..., 1].sum(1), (x * x).sum(1), rtol=1e-4, atol=2e-2)
+        assert torch.equal(outs[0], outs[1])
+        ops.gemm_set_tile(15)
+        if not ln:
+            y = torch.full((M, N), float("nan"), device=dev)
+            ops.gemm(a, w, bias, out=y, epilogue=ops.EPI_F32, resid=resid)              # out of place
+            assert torch.equal(y, outs[0])
+            z = torch.full((M, N), float("nan"), device=dev)
+            ops.gemm(a, w, bias, out=z, epilogue=ops.EPI_F32)                           # no residual
+            torch.testing.assert_close(z, a.float() @ w.float().t() + bias, rtol=1e-5, atol=2e-4)
+    finally:
+        ops.gemm_set_tile(0)
