@@ -422,7 +422,7 @@ def other_configs(args, dev, torch, ops):
 def config5_leg(dev, torch, ops, leg):
     """config 5: MedSAM ViT-B + a 4-class prototype bank on 1024x1024 slices: the query is encoded ONCE by DINOv2 at 1022^2 and matched
     against the four banks (validation.py:207: four 1-way passes sharing one encoder forward), then MedSAM per class."""
-    from oracle.make_fullsize_goldens import cfg5_inputs   # (input generator only: seeded synthetic 4-organ slice)
+    from protosam_amd.synth_cases import cfg5_inputs   # (input generator only: seeded synthetic 4-organ slice)
     from protosam_amd.grid_proto_fewshot import FewShotSeg
     from protosam_amd.protomedsam import ProtoMedSAM
     from protosam_amd.protosam import ALPNetWrapper

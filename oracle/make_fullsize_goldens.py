@@ -1,6 +1,7 @@
 """Full-depth oracle taps for BASELINE.json configs 3 / 4 / 5 (test infrastructure; see oracle/__init__.py).
 
   python oracle/make_fullsize_goldens.py [3] [4] [5] [44]   # writes tests/golden/fullsize_cfg{3,4,5}.npz (44: cfg4_heavytail)
+  python oracle/make_fullsize_goldens.py 300 400            # every slice of config 3 / 4: tests/golden/fullvolume_cfg{3,4}.npz
 
 The CPU oracle (pinned against the reference by oracle/validate_against_reference.py) is run ONCE, here in the build
 container, at the configurations' full model depth on seeded synthetic slices; `tests/test_fullsize_gpu.py` runs the HIP
@@ -35,9 +36,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 GOLD = os.path.join(ROOT, "tests", "golden")
 
-CFG3_SLICES = (5, 16, 27)
-CFG4_SLICES = (8, 32, 56)
-CFG5_SEED = 2
+from protosam_amd.synth_cases import cfg5_inputs, volume_config  # noqa: E402  (the seeded inputs live with the other generators)
 
 
 def _weights(sam_type, image_size, heavy_tail=False):
@@ -52,15 +51,6 @@ def _weights(sam_type, image_size, heavy_tail=False):
         from protosam_amd.synth import heavy_tail_sam_
         heavy_tail_sam_(sam_sd, 1234)
     return enc_sd, sam_sd
-
-
-def volume_config(cfg):
-    """-> (sam_type, n_slices, kind, slices, flag sets) of configs 3 / 4."""
-    if cfg == 3:
-        return "vit_b", 32, "mri", CFG3_SLICES, {"default": dict(use_cca=False), "cca": dict(use_cca=True)}
-    if cfg == 44:   # config 4 with the heavy-tailed SAM weights of synth.heavy_tail_sam_ (stress case of the fp16 operand path)
-        return "vit_h", 64, "ct", (32,), {"default": dict(use_cca=False)}
-    return "vit_h", 64, "ct", CFG4_SLICES, {"default": dict(use_cca=False)}
 
 
 def make_volume_config(cfg):
@@ -97,12 +87,52 @@ def make_volume_config(cfg):
     print(f"wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
-def cfg5_inputs():
-    """support image, the four classes' support masks, query image (protosam_amd.synth.synth_pair_multi: four organs of
-    different contrast in one 1024 x 1024 slice)."""
-    from protosam_amd.synth import synth_pair_multi
-    s_img, s_masks, q_img, _ = synth_pair_multi(1024, seed=CFG5_SEED)
-    return s_img, s_masks, q_img
+def make_whole_volume(cfg):
+    """EVERY slice of config 3 (32) / config 4 (64), default flags: final mask (packed bits), scores, sigmoid(low_res_masks) of the
+    kept token at every 4th pixel (uint16) -> tests/golden/fullvolume_cfg{3,4}.npz. The GPU tests hold BOTH HIP paths (one
+    ProtoSAM.forward per slice; 16-slice forward_batch with the LayerNorm folded into the GEMMs) to Dice >= 0.999 against these
+    masks, slice by slice (BASELINE.md section 4's gate; validation_protosam.py:169-185)."""
+    from oracle import alp as oalp, dinov2 as odino, glue
+    from protosam_amd.runner import part_assign, support_set
+    from protosam_amd.synth import synth_volume
+    sam_type, n, kind, _, _ = volume_config(cfg)
+    enc_sd, sam_sd = _weights(sam_type, 512)
+    vol, lab = synth_volume(n, 512, seed=0, kind=kind)
+    svol, slab = synth_volume(n, 512, seed=1, kind=kind)
+    sup_imgs, sup_masks = support_set(svol, slab)
+    from collections import OrderedDict
+    memo = OrderedDict()
+
+    def enc(im):        # the support image of a z-part is encoded once (resize_to_patch_multiple makes a fresh tensor per call: LRU by content)
+        key = (float(im.double().sum()), float(im.double().abs().max()), tuple(im.shape))
+        if key in memo:
+            memo.move_to_end(key)
+        else:
+            memo[key] = odino.forward_features(im, enc_sd, "dinov2_b14")["x_norm_patchtokens"]
+            while len(memo) > 3:
+                memo.popitem(last=False)
+        return memo[key]
+    out = {}
+    t_all = time.time()
+    for z in range(n):
+        t0 = time.time()
+        q = vol[z][None, None].repeat(1, 3, 1, 1).contiguous()
+        part = part_assign(z, n)
+        with torch.no_grad():
+            logits = oalp.fewshot_forward(enc, sup_imgs[part], sup_masks[part], q, 512)
+            taps = {}
+            pred, scores = glue.protosam_forward(q, logits, sam_sd, sam_type, use_bbox=True, use_points=True, point_mode="both",
+                                                 use_cca=False, taps=taps)
+        out[f"z{z}_mask"] = np.packbits(pred.numpy().astype(bool))
+        out[f"z{z}_scores"] = np.array(scores, dtype=np.float32)
+        if taps.get("low_res"):
+            out[f"z{z}_prob4"] = prob16(torch.stack([l[0] for l in taps["low_res"]]))[..., ::4, ::4].copy()
+        print(f"config {cfg} z={z}: {len(scores)} component(s), fg {int(pred.sum())} px, {time.time() - t0:.0f}s "
+              f"(total {time.time() - t_all:.0f}s)", flush=True)
+        if z % 8 == 7 or z == n - 1:      # (checkpoint: a long run)
+            np.savez_compressed(os.path.join(GOLD, f"fullvolume_cfg{cfg}.npz"), **out)
+    path = os.path.join(GOLD, f"fullvolume_cfg{cfg}.npz")
+    print(f"wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
 def make_config5():
@@ -142,4 +172,7 @@ if __name__ == "__main__":
     torch.set_num_threads(os.cpu_count() or 1)
     which = [int(a) for a in sys.argv[1:]] or [3, 4, 5]
     for c in which:
-        make_config5() if c == 5 else make_volume_config(c)
+        if c in (300, 400):          # every slice of config 3 / 4 (long: ~10 / ~40 minutes on 8 cores)
+            make_whole_volume(c // 100)
+        else:
+            make_config5() if c == 5 else make_volume_config(c)

@@ -78,7 +78,7 @@ def check_alp(gold):
     from models.alpmodule import MultiProtoAsConv  # reference
     from oracle import alp as oalp
     print("ALP module (models/alpmodule.py)")
-    from oracle import golden_inputs as gi
+    from protosam_amd import synth_cases as gi
     qry, sup, msk = gi.alp_case()
     C, hw = qry.shape[2], qry.shape[-1]
     ref_unit = MultiProtoAsConv(proto_grid=[8, 8], feature_hw=[hw, hw], embed_dim=C)
@@ -103,7 +103,7 @@ class _HubAdapter(torch.nn.Module):
 
 def check_fewshot(gold):
     from oracle import alp as oalp, dinov2 as odino
-    from oracle import golden_inputs as gi
+    from protosam_amd import synth_cases as gi
     print("FewShotSeg.forward (models/grid_proto_fewshot.py) with the hub encoder replaced by oracle/dinov2.py")
     depth = gi.FEWSHOT_DEPTH
     enc_sd = gi.fewshot_encoder_sd()
@@ -198,7 +198,7 @@ def check_dinov2_vs_transformers():
 
 def _small_encoder_kwargs():
     from functools import partial
-    from oracle import golden_inputs as gi
+    from protosam_amd import synth_cases as gi
     c = gi.SMALL_ENCODER
     return dict(depth=c["depth"], embed_dim=c["embed_dim"], img_size=1024, mlp_ratio=4,
                 norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), num_heads=c["num_heads"], patch_size=16,
@@ -212,7 +212,7 @@ def check_sam_encoder(gold):
     from protosam_amd.synth import synth_state_dict
     print("SAM ImageEncoderViT (reduced width: 3 blocks [window, global, window], dim 64, 2 heads)")
     ref = ImageEncoderViT(**_small_encoder_kwargs()).eval()
-    from oracle import golden_inputs as gi
+    from protosam_amd import synth_cases as gi
     sd = synth_state_dict(ref, gi.SMALL_ENCODER_SEED)
     ref.load_state_dict(sd)
     x = gi.small_encoder_input()
@@ -231,7 +231,7 @@ def check_sam_decoder(gold):
     from protosam_amd.synth import synth_state_dict
     print("SAM PromptEncoder + MaskDecoder + postprocess (full-size decoder, vendored reference)")
     sam = sam_model_registry["vit_b"]()  # random init, SamBatched
-    from oracle import golden_inputs as gi
+    from protosam_amd import synth_cases as gi
     sd_full = synth_state_dict(sam, gi.DECODER_SEED)
     sd = {k: v for k, v in sd_full.items() if not k.startswith("image_encoder.")}
     sam.load_state_dict(sd, strict=False)
@@ -312,7 +312,7 @@ def _amg_reference_model():
     from functools import partial
     from segment_anything import sam_model_registry
     from segment_anything.modeling import ImageEncoderViT
-    from oracle import golden_inputs as gi
+    from protosam_amd import synth_cases as gi
     from protosam_amd.synth import synth_state_dict
     sam = sam_model_registry["vit_b"]()
     sam.image_encoder = ImageEncoderViT(depth=gi.AMG_ENCODER_DEPTH, embed_dim=768, img_size=1024, mlp_ratio=4,
@@ -342,7 +342,7 @@ def amg_thresholds(iou_all, stab_all):
 def check_amg(gold):
     from segment_anything import SamAutomaticMaskGenerator  # vendored
     from oracle import amg as oamg
-    from oracle import golden_inputs as gi
+    from protosam_amd import synth_cases as gi
     print("SamAutomaticMaskGenerator.generate + SamWrapper.forward (vendored reference; NMS = injected restatement)")
     sam, sd = _amg_reference_model()
     img, label = gi.amg_case()
@@ -532,7 +532,8 @@ def check_orchestration(gold, tmpdir):
     import matplotlib
     matplotlib.use("Agg")
     _install_cv2_restatements()
-    from oracle import alp as oalp, dinov2 as odino, glue, golden_inputs as gi
+    from oracle import alp as oalp, dinov2 as odino, glue
+    from protosam_amd import synth_cases as gi
     from oracle import sam_image_encoder as oenc, sam_prompt_decoder as odec
     from protosam_amd.synth import synth_state_dict
     _truncate_vendored_registry(gi.ORCH_SAM_DEPTH)

@@ -157,3 +157,26 @@ def amg_small_case():
     _, _, q_img, _ = synth_pair(64, seed=9)
     q = q_img[0, :, 8:56, 10:54].permute(1, 2, 0).numpy()
     return ((q - q.min()) / (q.max() - q.min()) * 255).astype("uint8")
+
+
+# ---- full-depth cases (tests/golden/fullsize_cfg*.npz, fullvolume_cfg*.npz; BASELINE.json configs 3 / 4 / 5)
+CFG3_SLICES = (5, 16, 27)
+CFG4_SLICES = (8, 32, 56)
+CFG5_SEED = 2
+
+
+def volume_config(cfg):
+    """-> (sam_type, n_slices, kind, slices, flag sets) of configs 3 / 4."""
+    if cfg == 3:
+        return "vit_b", 32, "mri", CFG3_SLICES, {"default": dict(use_cca=False), "cca": dict(use_cca=True)}
+    if cfg == 44:   # config 4 with the heavy-tailed SAM weights of synth.heavy_tail_sam_ (stress case of the fp16 operand path)
+        return "vit_h", 64, "ct", (32,), {"default": dict(use_cca=False)}
+    return "vit_h", 64, "ct", CFG4_SLICES, {"default": dict(use_cca=False)}
+
+
+def cfg5_inputs():
+    """support image, the four classes' support masks, query image (protosam_amd.synth.synth_pair_multi: four organs of
+    different contrast in one 1024 x 1024 slice)."""
+    from protosam_amd.synth import synth_pair_multi
+    s_img, s_masks, q_img, _ = synth_pair_multi(1024, seed=CFG5_SEED)
+    return s_img, s_masks, q_img

@@ -155,7 +155,7 @@ def test_fewshot_forward_small_image_upsamples_features(dev):
     reference's recorded output for exactly this case (tests/golden, written from /root/reference)."""
     import os
     import numpy as np
-    from oracle import golden_inputs as gi
+    from protosam_amd import synth_cases as gi
     from protosam_amd.grid_proto_fewshot import FewShotSeg
     gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_outputs.npz"))
     for size in gi.FEWSHOT_SIZES:

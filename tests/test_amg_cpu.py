@@ -106,7 +106,8 @@ def test_custom_points_label_rule():
 
 
 def test_oracle_generator_reproduces_reference_records():
-    from oracle import amg as oamg, golden_inputs as gi
+    from oracle import amg as oamg
+    from protosam_amd import synth_cases as gi
     from protosam_amd.segment_anything import sam_model_registry
     from protosam_amd.synth import synth_state_dict
     gold = np.load(GOLD)
@@ -131,7 +132,8 @@ def test_oracle_generator_reproduces_reference_records():
 def test_oracle_crops_and_small_regions_reproduce_reference_records(tag, extra):
     """crop_n_layers = 1 + min_mask_region_area (automatic_mask_generator.py:194-380) on the 48 x 44 image: the oracle against
     the records the REFERENCE's generator produced (oracle/validate_against_reference.py check_amg)."""
-    from oracle import amg as oamg, golden_inputs as gi
+    from oracle import amg as oamg
+    from protosam_amd import synth_cases as gi
     from protosam_amd.segment_anything import sam_model_registry
     from protosam_amd.synth import synth_state_dict
     gold = np.load(GOLD)

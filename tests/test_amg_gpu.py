@@ -59,7 +59,8 @@ def test_mask_stats_and_binarize_kernels(dev, variant, H, W):
 @pytest.fixture(scope="module")
 def amg_setup(dev):
     """SAM vit_b (2 encoder blocks, synthetic weights) + the oracle's view of every candidate of the 8x8 grid."""
-    from oracle import amg as oamg, golden_inputs as gi
+    from oracle import amg as oamg
+    from protosam_amd import synth_cases as gi
     from protosam_amd.sam_wrapper import SamWrapper
     torch.set_num_threads(min(32, os.cpu_count() or 8))
     gold = np.load(GOLD)
@@ -244,7 +245,7 @@ def test_remove_small_regions_on_device(dev):
 
 @pytest.fixture(scope="module")
 def amg_crop_setup(dev):
-    from oracle import golden_inputs as gi
+    from protosam_amd import synth_cases as gi
     from protosam_amd.sam_wrapper import SamWrapper
     torch.set_num_threads(min(32, os.cpu_count() or 8))
     w = SamWrapper({"model_type": "vit_b", "sam_checkpoint": f"random:{gi.AMG_SEED}:{gi.AMG_ENCODER_DEPTH}",
@@ -260,7 +261,7 @@ def _record_key(pt, crop, piou):
 def test_generate_crops_and_small_regions_vs_reference(dev, amg_crop_setup):
     """crop_n_layers = 1 + min_mask_region_area on the 48 x 44 image, no suppression: one record per candidate of every crop
     (64 * 3 from the image, 4 * 16 * 3 from the layer-1 crops), against the REFERENCE's recorded run (amgc_all_*)."""
-    from oracle import golden_inputs as gi
+    from protosam_amd import synth_cases as gi
     from protosam_amd.segment_anything import SamAutomaticMaskGenerator
     s, gold = amg_crop_setup, amg_crop_setup["gold"]
     H, W = s["img"].shape[:2]
@@ -300,7 +301,7 @@ def test_generate_crops_and_small_regions_vs_reference(dev, amg_crop_setup):
 
 def test_generate_crops_default_suppression(dev, amg_crop_setup):
     """Default crop_nms_thresh: cross-crop NMS prefers the masks of smaller crops (scores = 1 / crop area, :208-218)."""
-    from oracle import golden_inputs as gi
+    from protosam_amd import synth_cases as gi
     from protosam_amd.segment_anything import SamAutomaticMaskGenerator
     s, gold = amg_crop_setup, amg_crop_setup["gold"]
     g = SamAutomaticMaskGenerator(s["w"].sam, **gi.AMG_CROP_ARGS)
@@ -313,7 +314,8 @@ def test_generate_crops_default_suppression(dev, amg_crop_setup):
 def test_generate_any_image_size_vs_oracle(dev, amg_crop_setup):
     """crop_n_layers = 0 on an image that is NOT at the model's input size (set_image resizes it, masks come back at the
     image's size) against the oracle run live."""
-    from oracle import amg as oamg, golden_inputs as gi
+    from oracle import amg as oamg
+    from protosam_amd import synth_cases as gi
     from protosam_amd.segment_anything import SamAutomaticMaskGenerator
     s = amg_crop_setup
     kw = dict(points_per_side=4, points_per_batch=16, box_nms_thresh=1.0, pred_iou_thresh=0.0, stability_score_thresh=0.0)

@@ -27,7 +27,7 @@ def _unpack(bits, S):
 
 
 def _volume_setup(dev, cfg):
-    from oracle.make_fullsize_goldens import volume_config
+    from protosam_amd.synth_cases import volume_config
     from protosam_amd.runner import build_protosam, support_set
     from protosam_amd.synth import synth_volume
     sam_type, n, kind, slices, flagsets = volume_config(cfg)
@@ -129,7 +129,7 @@ def test_volume_runner_equals_per_slice_forward(dev, cfg):
 
 
 def test_config5_full_depth_vs_oracle_record(dev):
-    from oracle.make_fullsize_goldens import cfg5_inputs
+    from protosam_amd.synth_cases import cfg5_inputs
     from protosam_amd.grid_proto_fewshot import FewShotSeg
     from protosam_amd.metrics import dice
     from protosam_amd.protomedsam import ProtoMedSAM
@@ -175,7 +175,7 @@ def test_config5_forward_classes_equals_per_class_forward(dev):
     """`ProtoMedSAM.forward_classes` (one DINOv2 forward of the query shared by the four prototype banks, one MedSAM encoder
     forward, one batched decoder call) against the four separate `forward()` calls the reference's multi-class loop makes
     (validation.py:207), and against the oracle record."""
-    from oracle.make_fullsize_goldens import cfg5_inputs
+    from protosam_amd.synth_cases import cfg5_inputs
     from protosam_amd.grid_proto_fewshot import FewShotSeg
     from protosam_amd.metrics import dice
     from protosam_amd.protomedsam import ProtoMedSAM

@@ -20,7 +20,8 @@ def _close(a, b, tol):
 
 
 def test_alp_modes(gold):
-    from oracle import alp as oalp, golden_inputs as gi
+    from oracle import alp as oalp
+    from protosam_amd import synth_cases as gi
     qry, sup, msk = gi.alp_case()
     for mode in ("mask", "gridconv", "gridconv+"):
         out, _ = oalp.cls_unit(qry[0], sup[0, 0], msk[0], mode, 0.95, 2)
@@ -48,7 +49,8 @@ def test_alp_edge_cases():
 
 @pytest.mark.parametrize("size", [252, 448])
 def test_fewshot_forward(gold, size):
-    from oracle import alp as oalp, dinov2 as odino, golden_inputs as gi
+    from oracle import alp as oalp, dinov2 as odino
+    from protosam_amd import synth_cases as gi
     sd = gi.fewshot_encoder_sd()
     s_img, s_m, q_img, _ = gi.fewshot_pair(size)
     enc = lambda im: odino.forward_features(im, sd, "dinov2_b14", depth=gi.FEWSHOT_DEPTH)["x_norm_patchtokens"]  # noqa
@@ -57,7 +59,8 @@ def test_fewshot_forward(gold, size):
 
 
 def test_sam_image_encoder_small(gold):
-    from oracle import golden_inputs as gi, sam_image_encoder as oenc
+    from oracle import sam_image_encoder as oenc
+    from protosam_amd import synth_cases as gi
     from protosam_amd.synth import synth_tensor
     c = gi.SMALL_ENCODER
     oenc.VIT_CFGS["tiny_test"] = {k: v for k, v in c.items() if k != "out_chans"}
@@ -80,7 +83,8 @@ def test_sam_image_encoder_small(gold):
 
 
 def test_sam_prompt_encoder_and_mask_decoder(gold):
-    from oracle import golden_inputs as gi, sam_prompt_decoder as odec
+    from oracle import sam_prompt_decoder as odec
+    from protosam_amd import synth_cases as gi
     from protosam_amd.segment_anything import sam_model_registry
     from protosam_amd.synth import synth_state_dict
     sam = sam_model_registry["vit_b"](encoder_depth=0)
@@ -123,7 +127,8 @@ def test_connected_components_properties():
 
 def test_mask_prompt_path(gold):
     """PromptEncoder.mask_downscaling + decoder with per-prompt dense maps vs the vendored reference's outputs."""
-    from oracle import golden_inputs as gi, sam_prompt_decoder as odec
+    from oracle import sam_prompt_decoder as odec
+    from protosam_amd import synth_cases as gi
     from protosam_amd.segment_anything import sam_model_registry
     from protosam_amd.synth import synth_state_dict
     sd = synth_state_dict(sam_model_registry["vit_b"](encoder_depth=1), gi.DECODER_SEED)
@@ -170,7 +175,8 @@ def test_rotation_helpers(gold):
 @pytest.fixture(scope="module")
 def orch():
     """Shared state of the orchestration replays: SAM state dict, query, the oracle's image embedding (computed once)."""
-    from oracle import glue, golden_inputs as gi, sam_image_encoder as oenc
+    from oracle import glue, sam_image_encoder as oenc
+    from protosam_amd import synth_cases as gi
     from protosam_amd.segment_anything import sam_model_registry
     from protosam_amd.synth import synth_state_dict
     torch.set_num_threads(8)
@@ -191,7 +197,8 @@ def _unpack(bits, shape):
 def test_protosam_forward_vs_reference_record(gold, orch, name):
     """oracle/glue.protosam_forward == the reference's ProtoSAM.forward (models/ProtoSAM.py:536-678) run on CPU in the build
     container for every flag set: final mask bit for bit, scores to 1e-5."""
-    from oracle import glue, golden_inputs as gi
+    from oracle import glue
+    from protosam_amd import synth_cases as gi
     kw = gi.ORCH_FLAGS[name]
     with torch.no_grad():
         pred, scores = glue.protosam_forward(orch["q"], gi.orch_coarse_logits(), orch["sd"], "vit_b", postprocess="batched",
@@ -202,7 +209,8 @@ def test_protosam_forward_vs_reference_record(gold, orch, name):
 
 
 def test_protosam_edge_cases_vs_reference_record(gold, orch):
-    from oracle import glue, golden_inputs as gi
+    from oracle import glue
+    from protosam_amd import synth_cases as gi
     pred, scores = glue.protosam_forward(orch["q"], gi.orch_empty_logits(), orch["sd"], "vit_b", features=orch["feats"])
     assert tuple(pred.shape) == (1024, 1024) and int(pred.sum()) == 0 and scores == [0]      # ProtoSAM.py:612-613
     for use_cca in (False, True):                                                              # ProtoSAM.py:580-590
@@ -212,7 +220,8 @@ def test_protosam_edge_cases_vs_reference_record(gold, orch):
 
 
 def test_protomedsam_forward_vs_reference_record(gold, orch):
-    from oracle import glue, golden_inputs as gi
+    from oracle import glue
+    from protosam_amd import synth_cases as gi
     with torch.no_grad():
         seg, conf = glue.protomedsam_forward(orch["q"], gi.orch_coarse_logits(), orch["sd"], "vit_b", use_cca=True,
                                              encoder_depth=gi.ORCH_SAM_DEPTH)
@@ -227,7 +236,8 @@ def test_protomedsam_forward_vs_reference_record(gold, orch):
 def test_predictor_vs_reference_record(gold, orch):
     """oracle `predict` == the vendored SamPredictor.predict (predictor.py:92-241) on square / non-square images, with
     points, boxes and mask inputs."""
-    from oracle import glue, golden_inputs as gi, sam_image_encoder as oenc, sam_prompt_decoder as odec
+    from oracle import glue, sam_image_encoder as oenc, sam_prompt_decoder as odec
+    from protosam_amd import synth_cases as gi
     cache = {}
     for name, hw, pc, pl, box, with_mask, mm, rl in gi.predictor_cases():
         if hw not in cache:

@@ -2,7 +2,7 @@
 oracle/validate_against_reference.py running /root/reference's ProtoSAM.forward, ProtoMedSAM.forward and SamPredictor on
 CPU in the build container). No oracle in between: final masks, scores and low-res logits of the reference are the target.
 The recorded runs use the vendored registry (`SamBatched`: bilinear align_corners=True post-processing), ViT-B truncated to
-two blocks, and given coarse logits (oracle/golden_inputs.py)."""
+two blocks, and given coarse logits (protosam_amd/synth_cases.py)."""
 import os
 
 import numpy as np
@@ -35,7 +35,7 @@ def _unpack(bits, shape):
 
 
 def _model(dev, cls, **kw):
-    from oracle import golden_inputs as gi
+    from protosam_amd import synth_cases as gi
     spec = f"random:vit_b:{gi.ORCH_SAM_SEED}:{gi.ORCH_SAM_DEPTH}"
     m = cls((1024, 1024), FixedCoarse(gi.orch_coarse_logits().to(dev)), spec, **kw).to(dev).eval()
     sam = getattr(m, "sam", None) or m.medsam
@@ -45,7 +45,7 @@ def _model(dev, cls, **kw):
 
 @pytest.mark.parametrize("name", ["default", "cca", "conf_pts", "centroid_box", "box_only", "mask", "mask_cca", "neg"])
 def test_protosam_forward_vs_reference(dev, gold, name):
-    from oracle import golden_inputs as gi
+    from protosam_amd import synth_cases as gi
     from protosam_amd.metrics import dice
     from protosam_amd.protosam import InputFactory, ProtoSAM, TYPE_ALPNET
     kw = gi.ORCH_FLAGS[name]
@@ -72,7 +72,7 @@ def test_protosam_forward_vs_reference(dev, gold, name):
 
 
 def test_protosam_edge_cases_vs_reference(dev, gold):
-    from oracle import golden_inputs as gi
+    from protosam_amd import synth_cases as gi
     from protosam_amd.protosam import InputFactory, ProtoSAM, TYPE_ALPNET
     q = gi.orch_query().to(dev)
     inp = InputFactory.create_input(TYPE_ALPNET, q, support_images=[q], support_labels=[torch.zeros(1, 512, 512)],
@@ -89,7 +89,7 @@ def test_protosam_edge_cases_vs_reference(dev, gold):
 
 
 def test_protomedsam_forward_vs_reference(dev, gold):
-    from oracle import golden_inputs as gi
+    from protosam_amd import synth_cases as gi
     from protosam_amd.metrics import dice
     from protosam_amd.protomedsam import ProtoMedSAM
     from protosam_amd.protosam import InputFactory, TYPE_ALPNET
@@ -111,7 +111,7 @@ def test_protomedsam_forward_vs_reference(dev, gold):
 def test_predictor_vs_reference(dev, gold):
     """SamPredictor.set_image / predict (predictor.py:34-241) on square and non-square images against the vendored
     predictor's recorded low-res logits and IoU predictions."""
-    from oracle import golden_inputs as gi
+    from protosam_amd import synth_cases as gi
     from protosam_amd.segment_anything import SamPredictor, sam_model_registry
     from protosam_amd.synth import synth_state_dict
     sam = sam_model_registry["vit_b"](encoder_depth=gi.ORCH_SAM_DEPTH)

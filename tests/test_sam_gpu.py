@@ -41,13 +41,14 @@ def test_image_encoder(dev, model_type, depth):
 
 
 def _cases():
-    from oracle import golden_inputs as gi
+    from protosam_amd import synth_cases as gi
     return gi.decoder_cases()
 
 
 @pytest.mark.parametrize("name", ["pts_box", "pts_only", "box_only"])
 def test_prompt_encoder_and_mask_decoder(dev, name):
-    from oracle import golden_inputs as gi, sam_prompt_decoder as odec
+    from oracle import sam_prompt_decoder as odec
+    from protosam_amd import synth_cases as gi
     sam, sd = _sam(dev, "vit_b", 0)
     feats = gi.decoder_features()
     pc, pl, bx = _cases()[name]
@@ -117,7 +118,8 @@ def test_mask_prompt_embedding_and_predict(dev):
     """PromptEncoder.mask_downscaling (one HIP kernel) and the decoder fed with per-prompt dense maps, against the
     REFERENCE's recorded outputs (dec_mask_* in tests/golden/reference_outputs.npz) and the oracle."""
     import os
-    from oracle import golden_inputs as gi, sam_prompt_decoder as odec
+    from oracle import sam_prompt_decoder as odec
+    from protosam_amd import synth_cases as gi
     gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_outputs.npz"))
     sam, sd = _sam(dev, "vit_b", 1, seed=gi.DECODER_SEED)
     mk = gi.mask_prompt_case()
