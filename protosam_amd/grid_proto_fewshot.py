@@ -192,6 +192,34 @@ class FewShotSeg(nn.Module):
         return output, 0.0, [None, None], None, None, supp_view, qry_view
 
     @torch.no_grad()
+    def forward_groups(self, qry_imgs, groups):
+        """MI355X extension: ONE encoder forward for a batch of query slices that belong to DIFFERENT support sets (a rank of a
+        multi-GPU job, or a batch that straddles two z-parts of a scan: validation_protosam.py:352-388 changes the support with the
+        part). qry_imgs [B,3,H,W]; groups: list of (supp_imgs, fore_mask, back_mask, isval, val_wsize, n) in batch order, the
+        first n slices matched against the first support set and so on (sum n == B). Only the prototype match depends on the
+        support: every group's logits equal `forward(...)` of that group alone. Returns logits [B,2,H,W]."""
+        S, g = self._grid()
+        B = qry_imgs.shape[0]
+        assert sum(gr[-1] for gr in groups) == B
+        img_size = groups[0][0][0][0].shape[-2:]
+        qry_tok, q_bstride, q_ld = self._patch_tokens(qry_imgs)
+        out = torch.empty((B, 2, img_size[0], img_size[1]), dtype=torch.float32, device=qry_imgs.device)
+        i0 = 0
+        for supp_imgs, fore_mask, back_mask, isval, val_wsize, n in groups:
+            assert len(supp_imgs) == 1, "Multi-shot has not been implemented yet"
+            if len(supp_imgs[0]) != 1 or supp_imgs[0][0].shape[0] != 1:
+                raise NotImplementedError("one support shot per call (validation_protosam.py:346-362)")
+            supp, fg, bg = supp_imgs[0][0], fore_mask[0][0], back_mask[0][0]
+            assert tuple(supp.shape[-2:]) == tuple(img_size)
+            pool_w = val_wsize if (isval and val_wsize is not None) else self.cls_unit.kernel_size[0]
+            bank, _ = self._support_bank(supp, fg, bg, pool_w)
+            pred = self.cls_unit.scores_token_major(qry_tok[i0:i0 + n], q_bstride, q_ld, n, g * g, bank)   # [n, 2, g*g]
+            self._check_bank(bank)
+            ops.bilinear_nchw(pred.view(n, 2, g, g), img_size[0], img_size[1], out=out[i0:i0 + n])
+            i0 += n
+        return out
+
+    @torch.no_grad()
     def forward_classes(self, supp_img, fore_masks, qry_img, isval=True, val_wsize=None):
         """Several 1-way episodes on the SAME support / query image pair (the multi-class loop of /root/reference/validation.py:207,
         BASELINE config 5: one prototype bank per class): the support and the query image are each encoded ONCE and the query

@@ -412,6 +412,16 @@ class ProtoSAM(nn.Module):
     def _coarse_logits(self, query_images, coarse_model_input, degrees_rotate=0):
         """ProtoSAM.py:544-556: the coarse model sees the query rotated by `degrees_rotate` (expanded canvas resized back to
         H x W), its logits are rotated back and centre-cropped (protosam_amd/rotate.py); identity at 0 degrees."""
+        if isinstance(coarse_model_input, (list, tuple)):
+            # mixed-support batch (forward_batch): [(ALPNetInput, n), ...] in batch order - one encoder forward for all slices, the
+            # prototype match per support set (FewShotSeg.forward_groups)
+            if degrees_rotate != 0:
+                raise NotImplementedError("rotation TTA with a mixed-support batch")
+            alp = getattr(self.coarse_segmentation_model, "model", None)
+            if not hasattr(alp, "forward_groups"):
+                raise TypeError("a list of (input, count) pairs needs a coarse model with forward_groups (ALPNetWrapper(FewShotSeg))")
+            return alp.forward_groups(query_images, [(i.supp_imgs, i.fore_mask, i.back_mask, i.isval, i.val_wsize, n)
+                                                     for i, n in coarse_model_input])
         if degrees_rotate == 0:
             coarse_model_input.set_query_images(query_images)
             return self.coarse_segmentation_model(coarse_model_input)
@@ -422,9 +432,11 @@ class ProtoSAM(nn.Module):
 
     @torch.no_grad()
     def forward_batch(self, query_images, coarse_model_input, degrees_rotate=0):
-        """MI355X extension: B independent query slices [B,3,H,W] sharing one support set go through every stage as
-        one batch (the ViT GEMMs see M = B*tokens rows, the mask decoder sees all components of all slices at once).
-        Slices never interact, so each result equals the per-slice `forward`. Returns a list of (pred, scores)."""
+        """MI355X extension: B independent query slices [B,3,H,W] go through every stage as one batch (the ViT GEMMs see
+        M = B*tokens rows, the mask decoder sees all components of all slices at once). `coarse_model_input`: one input (all
+        slices share its support set) or a list of (input, n) pairs in batch order (the first n slices belong to the first support
+        set, ...: both encoders, the connected components, SAM and the decoder do not depend on the support; only the prototype
+        match does). Slices never interact, so each result equals the per-slice `forward`. Returns a list of (pred, scores)."""
         B = query_images.shape[0]
         original_size = query_images.shape[-2]
         dev = query_images.device

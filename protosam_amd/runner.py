@@ -57,30 +57,42 @@ def shard_slices(n_slices, rank, world):
 
 
 @torch.no_grad()
-def run_slices(model, vol, sup_imgs, sup_masks, zs, device, out=None, batch=1):
-    """Runs ProtoSAM on slices `zs` of `vol` [n,S,S] (device tensor), `batch` slices of one z-part at a time through
-    `forward_batch`; returns uint8 masks [len(zs),S,S] and the number of prompts per slice."""
+def run_slices(model, vol, sup_imgs, sup_masks, zs, device, out=None, batch=1, mix_parts=True):
+    """Runs ProtoSAM on slices `zs` of `vol` [n,S,S] (device tensor), `batch` slices at a time through `forward_batch`; returns uint8
+    masks [len(zs),S,S] and the number of prompts per slice. A batch may span z-parts (different support sets: the batch then carries
+    one (input, count) pair per part - only the prototype match is done per part); mix_parts=False cuts batches at part boundaries."""
     n, S = vol.shape[0], vol.shape[-1]
     if out is None:
         out = torch.zeros((len(zs), S, S), dtype=torch.uint8, device=device)
     stats = [0] * len(zs)
     inputs = {}
+
+    def part_input(part, q):
+        if part not in inputs:
+            inputs[part] = InputFactory.create_input(TYPE_ALPNET, q, support_images=[sup_imgs[part]],
+                                                     support_labels=[sup_masks[part]], isval=True, val_wsize=2)
+        return inputs[part]
     i = 0
     while i < len(zs):
         part = part_assign(zs[i], n)
         j = i
-        while j < len(zs) and j - i < batch and part_assign(zs[j], n) == part:
+        while j < len(zs) and j - i < batch and (mix_parts and batch > 1 or part_assign(zs[j], n) == part):
             j += 1
         idx = torch.tensor(zs[i:j], device=device)
         q = vol[idx][:, None].expand(j - i, 3, S, S).contiguous()
-        if part not in inputs:
-            inputs[part] = InputFactory.create_input(TYPE_ALPNET, q, support_images=[sup_imgs[part]],
-                                                     support_labels=[sup_masks[part]], isval=True, val_wsize=2)
         if batch == 1:
-            res = [model(q, inputs[part], degrees_rotate=0)]
+            res = [model(q, part_input(part, q), degrees_rotate=0)]
             st = [model.last_stats]
         else:
-            res = model.forward_batch(q, inputs[part])
+            runs = []                                   # consecutive slices of one part
+            for z in zs[i:j]:
+                pz = part_assign(z, n)
+                if runs and runs[-1][0] == pz:
+                    runs[-1][1] += 1
+                else:
+                    runs.append([pz, 1])
+            cin = part_input(part, q) if len(runs) == 1 else [(part_input(pz, q), cnt) for pz, cnt in runs]
+            res = model.forward_batch(q, cin)
             st = model.last_stats.get("per_slice", [model.last_stats])
         for k, (pred, scores) in enumerate(res):
             if pred.shape[-1] == S:

@@ -128,6 +128,68 @@ def test_volume_runner_equals_per_slice_forward(dev, cfg):
     assert int(diff.max()) <= 256 and all(int(diff[z]) <= 32 or ds[z] >= 0.995 for z in zs)
 
 
+@pytest.mark.parametrize("cfg", [3, 4])
+def test_whole_volume_vs_oracle_masks(dev, cfg):
+    """EVERY slice of config 3 (32) / config 4 (64) against the oracle's final masks (tests/golden/fullvolume_cfg{3,4}.npz), for BOTH
+    HIP paths - one ProtoSAM.forward per slice, and 16-slice forward_batch calls (LayerNorm folded into the GEMMs, batches that span
+    z-parts): Dice >= 0.999 per slice (BASELINE.md section 4's gate; the caller's metric, validation_protosam.py:169-185), the same
+    number of prompt sets, scores and sigmoid(low_res_masks) (every 4th pixel) within the north-star 1e-3."""
+    from protosam_amd.metrics import dice
+    from protosam_amd.runner import run_slices
+    gold = np.load(os.path.join(GOLD, f"fullvolume_cfg{cfg}.npz"))
+    model, vol_d, sup_imgs, sup_masks, n, _, _ = _volume_setup(dev, cfg)
+    model.use_cca = False
+    zs = list(range(n))
+    for name, batch in (("per-slice", 1), ("batched", 16)):
+        worst_d, worst_p, worst_s, flips = 1.0, 0.0, 0.0, 0
+        for i in range(0, n, 16):
+            chunk = zs[i:i + 16]
+            masks, st = run_slices(model, vol_d, sup_imgs, sup_masks, chunk, dev, batch=batch)
+            masks = masks.cpu()
+            if batch > 1:
+                per = model.last_stats
+                low, iou, sel = per["low_res"].cpu(), per["iou"].cpu(), per["sel"]
+            for b, z in enumerate(chunk):
+                ref = _unpack(gold[f"z{z}_mask"], 512)
+                d = dice(masks[b].float(), ref)
+                worst_d = min(worst_d, d)
+                flips = max(flips, int((masks[b].float() != ref).sum()))
+                ref_scores = gold[f"z{z}_scores"]
+                assert st[b] == len(ref_scores), (name, z, st[b], len(ref_scores))
+                assert d >= 0.999, (name, z, d)
+                if batch > 1:
+                    _, start, cnt = next(sp for sp in per["spans"] if sp[0] == b)
+                    refp = torch.from_numpy(gold[f"z{z}_prob4"].astype(np.float32) / 65535.0)
+                    p = torch.sigmoid(low[start:start + cnt, sel])[..., ::4, ::4]
+                    worst_p = max(worst_p, (p - refp).abs().max().item())
+                    worst_s = max(worst_s, float(np.abs(iou[start:start + cnt, sel].numpy() - ref_scores).max()))
+        print(f"config {cfg} {name}: {n} slices, worst Dice {worst_d:.5f} ({flips} px)" +
+              (f", max |dprob(low_res)| {worst_p:.2e}, scores {worst_s:.2e}" if batch > 1 else ""))
+        assert worst_p <= TOL and worst_s <= TOL
+
+
+def test_config4_slice_vs_reference_full_depth_record(dev):
+    """The HIP path against the REFERENCE's own full-depth run (no oracle in between): tests/golden/reference_fullsize_vith.npz holds
+    what the reference's 32-block `sam_model_registry["vit_h"]` + `SamPredictor.set_image / predict` returned for slice 32 of config
+    4 (oracle/make_reference_fullsize.py, which also asserts the oracle equal to it: embedding and logits bit for bit)."""
+    from protosam_amd.runner import run_slices
+    gold = np.load(os.path.join(GOLD, "reference_fullsize_vith.npz"))
+    model, vol_d, sup_imgs, sup_masks, n, _, _ = _volume_setup(dev, 4)
+    model.use_cca = False
+    z = int(gold["z"][0])
+    masks, _ = run_slices(model, vol_d, sup_imgs, sup_masks, [z], dev)
+    st = model.last_stats
+    low_ref = torch.from_numpy(gold["low_res"])                      # [n, 3, 256, 256] logits of the three mask tokens
+    assert st["n_prompts"] == low_ref.shape[0]
+    # (the decoder keeps four mask tokens; multimask_output=True hands back tokens 1..3, mask_decoder.py:107-112)
+    perr = (torch.sigmoid(st["low_res"][:, 1:4].cpu()) - torch.sigmoid(low_ref)).abs().max().item()
+    serr = float(np.abs(st["iou"][:, 1:4].cpu().numpy() - gold["iou"]).max())
+    print(f"config 4 z={z} vs the reference's ViT-H x32 run: max |dprob(low_res)| over the three tokens {perr:.2e}, iou {serr:.2e}")
+    assert perr <= TOL and serr <= TOL
+    d = (masks[0].cpu().float() != _unpack(gold["mask"], 512)).sum().item()
+    assert d <= 64, d
+
+
 def test_config5_full_depth_vs_oracle_record(dev):
     from protosam_amd.synth_cases import cfg5_inputs
     from protosam_amd.grid_proto_fewshot import FewShotSeg

@@ -177,6 +177,57 @@ def test_forward_batch_equals_per_slice(dev):
         assert len(sb) == len(s1) and np.allclose(np.array(sb, dtype=np.float64), np.array(s1, dtype=np.float64), atol=2e-3)
 
 
+def test_mixed_support_batch_equals_per_support_batches(dev):
+    """forward_batch with a list of (input, n) pairs: slices of DIFFERENT support sets in one batch (a rank of a strong-scaling job,
+    or a batch across two z-parts of a scan). Both encoders, connected components, SAM and the decoder do not depend on the support;
+    the prototype match is done per support set. With every GEMM on one row-independent kernel (tile 1, separate LayerNorm passes)
+    a slice's encoder arithmetic does not depend on what else is in the batch: masks bit for bit equal to the per-support batches,
+    scores to fp32 rounding. With the default kernel choice (which follows the batch's row count): within the bound of the batched-vs-per-slice
+    test above."""
+    from protosam_amd import ops
+    from protosam_amd.protosam import InputFactory, TYPE_ALPNET
+    from protosam_amd.synth import synth_pair
+    model, _ = _build(dev, "random:vit_b:1234:2", 2, use_bbox=True, use_points=True, point_mode="both")
+    model.overlap_streams = "0"
+    sA, mA, q0, _ = synth_pair(512, seed=0)
+    sB, mB, q1, _ = synth_pair(512, seed=3)
+    _, _, q2, _ = synth_pair(512, seed=5)
+    qs = torch.cat([q0, q2, q1, q2, q0], 0).to(dev)          # slices 0-1: support A, 2-4: support B
+    inA = InputFactory.create_input(TYPE_ALPNET, qs[:2], support_images=[sA], support_labels=[mA], isval=True, val_wsize=2)
+    inB = InputFactory.create_input(TYPE_ALPNET, qs[2:], support_images=[sB], support_labels=[mB], isval=True, val_wsize=2)
+    inA.to(dev); inB.to(dev)
+    enc = model.sam.image_encoder
+    dino = model.coarse_segmentation_model.model.encoder
+    for forced in (True, False):
+        fold = (enc.fold_ln, getattr(dino, "fold_ln", None))
+        if forced:
+            ops.gemm_set_tile(1)
+            enc.fold_ln = False
+            if fold[1] is not None:
+                dino.fold_ln = False
+        try:
+            mixed = model.forward_batch(qs, [(inA, 2), (inB, 3)])
+            sep = model.forward_batch(qs[:2], inA) + model.forward_batch(qs[2:], inB)
+        finally:
+            ops.gemm_set_tile(0)
+            enc.fold_ln = fold[0]
+            if fold[1] is not None:
+                dino.fold_ln = fold[1]
+        assert len(mixed) == len(sep) == 5
+        for b, ((pm, sm), (ps, ss)) in enumerate(zip(mixed, sep)):
+            assert pm.shape == ps.shape and len(sm) == len(ss)
+            if forced:      # (the decoder's token-side linears pick their kernel by the number of prompt sets in the call: scores to rounding)
+                assert torch.equal(pm, ps), (b, int((pm != ps).sum()))
+                assert np.allclose(np.array(sm, dtype=np.float64), np.array(ss, dtype=np.float64), atol=2e-6, rtol=0)
+            else:
+                assert (pm != ps).sum().item() <= 32
+                assert np.allclose(np.array(sm, dtype=np.float64), np.array(ss, dtype=np.float64), atol=2e-3)
+    # the supports differ: slice 1 and slice 3 hold the same query image, matched against different prototypes
+    assert not torch.equal(mixed[1][0], mixed[3][0]) or mixed[1][1] != mixed[3][1]
+    with pytest.raises(NotImplementedError):
+        model.forward_batch(qs, [(inA, 2), (inB, 3)], degrees_rotate=10)
+
+
 def test_forward_batch_overlapped_streams_same_result(dev):
     """`overlap_streams`: the SAM encoder on a second stream next to DINOv2 + ALP + connected components gives the same masks and
     scores as the sequential order; "auto" turns it on only after a call without empty slices."""
