@@ -63,7 +63,9 @@ int psam_gemm_set_tile(int tile);
 int psam_gemm_asm_variant(int variant);
 /* Dispatch switches of psam_gemm_f16 (1 = on, the default; initial values also from the environment): "asm" (PSAM_GEMM_ASM) the
  * assembly kernels for the large tiles, "half_tiles" (PSAM_GEMM_HALF) the half-tile assembly kernels for shapes with few 256x256
- * tiles, "splitk" (PSAM_GEMM_SPLITK), "nsplit" (PSAM_GEMM_NSPLIT) the column split of one-slice fc1 shapes. Unknown name: error. */
+ * tiles, "splitk" (PSAM_GEMM_SPLITK), "nsplit" (PSAM_GEMM_NSPLIT) the column split of one-slice fc1 shapes; "max_wgs"
+ * (PSAM_GEMM_MAX_WGS, an integer, 0 = none) caps the persistent grids of the assembly kernels - two streams then run their GEMMs
+ * side by side on disjoint CUs. Unknown name: error. */
 int psam_gemm_set_option(const char* name, int value);
 /* Device scratch for the split-K form of psam_gemm_f16 (fp32 partial sums, [ksplit][M][N]): used only when registered and
  * large enough; EPI 2 on few 256x256 tiles with K >= 2048 then runs `ksplit` workgroups per tile + one reduce pass

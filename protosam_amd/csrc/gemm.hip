@@ -66,16 +66,21 @@ struct GemmArgs {
 // ---- device geometry, read once from the runtime (a full MI355X reports 256 CUs in 8 XCDs; a CPX / NPS partition fewer) ----
 // The XCD-region tile maps below are written for 8 XCDs (block b on XCD b % 8, observed placement, speed only): on any other
 // geometry the launchers fall back to the identity map, and the persistent grids / fill tests use the real CU count.
-static int g_num_cus = 0, g_num_xcds = 0;
-static void device_geometry() {
-  if (g_num_cus > 0) return;
-  int dev = 0, v = 0;
-  (void)hipGetDevice(&dev);
-  g_num_cus = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
-  g_num_xcds = (hipDeviceGetAttribute(&v, hipDeviceAttributeNumberOfXccs, dev) == hipSuccess && v > 0) ? v : 8;
+// (per DEVICE: one process may drive several GPUs; every cache below that holds device-side state is keyed by hipGetDevice())
+struct DevGeom { int cus = 0, xcds = 0; };
+static DevGeom g_geom[64];
+static inline int cur_device() { int dev = 0; (void)hipGetDevice(&dev); return dev; }
+static const DevGeom& device_geometry() {
+  const int dev = cur_device();
+  DevGeom& g = g_geom[dev & 63];
+  if (g.cus > 0) return g;
+  int v = 0;
+  g.cus = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+  g.xcds = (hipDeviceGetAttribute(&v, hipDeviceAttributeNumberOfXccs, dev) == hipSuccess && v > 0) ? v : 8;
   (void)hipGetLastError();
+  return g;
 }
-static inline int num_cus() { device_geometry(); return g_num_cus; }
+static inline int num_cus() { return device_geometry().cus; }
 // Cap on the persistent grids (psam_gemm_set_option("max_wgs", n) / PSAM_GEMM_MAX_WGS; 0 = none): with half the CUs per launch, two
 // streams run their GEMMs side by side on disjoint CUs (one's epilogue traffic beside the other's k-loops)
 static int g_max_wgs = -1;
@@ -84,7 +89,7 @@ static inline int eff_cus() {
   const int n = num_cus();
   return (g_max_wgs > 0 && g_max_wgs < n) ? g_max_wgs : n;
 }
-static inline bool xcd_maps_apply() { device_geometry(); return g_num_xcds == 8 && g_num_cus % 8 == 0; }
+static inline bool xcd_maps_apply() { const DevGeom& g = device_geometry(); return g.xcds == 8 && g.cus % 8 == 0; }
 
 // ---- tile -> workgroup mapping ------------------------------------------------------------------------------------
 // Block b runs on XCD b % 8 (observed placement; used for speed only, never for correctness) and every XCD has a
@@ -1090,26 +1095,31 @@ struct AsmGemmArgs {
   void* out16; float* stats; int ld16, pad2;
 };
 static_assert(sizeof(AsmGemmArgs) == 128, "kernarg layout of gemm_asm_gen.py");
-static hipModule_t g_asm_mod = nullptr;
-static std::map<int, std::vector<hipFunction_t>> g_asm_fns;   // family * 1000 + variant -> {f16, gelu, f32}
+// The code object is loaded once per DEVICE (a hipModule_t / hipFunction_t belongs to the device that was current at load time).
+struct AsmModule { hipModule_t mod = nullptr; int state = 0; std::map<int, std::vector<hipFunction_t>> fns; std::map<std::string, hipFunction_t> named; };
+static std::map<int, AsmModule> g_asm;   // device -> module; fns: family * 1000 + variant -> {f16, gelu, f32, ...}; state 0 not tried, 1 loaded, -1 failed
 static int g_asm_variant = 0;   // 0 = the shipped schedule; > 0: experiment builds (kernel names carry the suffix _v<n>)
-static int g_asm_state = 0;     // 0 not tried, 1 loaded, -1 failed
 extern "C" int psam_gemm_asm_variant(int v) {
   g_asm_variant = v;
   return PSAM_OK;
 }
-static const hipFunction_t* asm_load(int family = 1) {
-  if (g_asm_state == 0) {
-    g_asm_state = -1;
+static AsmModule* asm_module() {
+  AsmModule& m = g_asm[cur_device()];
+  if (m.state == 0) {
+    m.state = -1;
     const char* path = getenv("PSAM_GEMM_ASM_CO");          // (experiments: a code object built from another schedule)
-    hipError_t st = path ? hipModuleLoad(&g_asm_mod, path) : hipModuleLoadData(&g_asm_mod, psam_gemm_asm_co);
+    hipError_t st = path ? hipModuleLoad(&m.mod, path) : hipModuleLoadData(&m.mod, psam_gemm_asm_co);
     if (st != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    g_asm_state = 1;
+    m.state = 1;
   }
-  if (g_asm_state < 0) return nullptr;
+  return m.state < 0 ? nullptr : &m;
+}
+static const hipFunction_t* asm_load(int family = 1) {
+  AsmModule* m = asm_module();
+  if (!m) return nullptr;
   const int key = family * 1000 + g_asm_variant;
-  auto it = g_asm_fns.find(key);
-  if (it != g_asm_fns.end()) return it->second.data();
+  auto it = m->fns.find(key);
+  if (it != m->fns.end()) return it->second.data();
   // [0..2]: f16 / gelu / f32; [3..5] (family 1, shipped schedule): the same with the default cache policy in the epilogue (_l2);
   // [6..8]: the folded-LayerNorm forms (_ln: consumers f16 / gelu, producer f32)
   const char* names[3] = {"f16", "gelu", "f32"};
@@ -1119,24 +1129,24 @@ static const hipFunction_t* asm_load(int family = 1) {
   for (int i = 0; i < nf; ++i) {
     std::string n = std::string(family == 2 ? "psam_gemm_asm2_" : "psam_gemm_asm_") + names[i % 3] + suffix[i / 3] +
                     (g_asm_variant > 0 ? "_v" + std::to_string(g_asm_variant) : std::string());
-    if (hipModuleGetFunction(&f[i], g_asm_mod, n.c_str()) != hipSuccess) {
+    if (hipModuleGetFunction(&f[i], m->mod, n.c_str()) != hipSuccess) {
       (void)hipGetLastError();
       if (i < 6) return nullptr;
       f[i] = nullptr;              // (a _ln form that is not built: the dispatcher keeps those launches on the HIP kernels)
     }
   }
   for (int i = nf; i < 6; ++i) f[i] = f[i - 3];
-  return (g_asm_fns[key] = f).data();
+  return (m->fns[key] = f).data();
 }
 // other kernels of the same code object (csrc/gattn_asm_gen.py): looked up by name from attention.hip
 hipFunction_t psam_asm_function(const char* name) {
-  if (!asm_load(1)) return nullptr;
-  static std::map<std::string, hipFunction_t> cache;
-  auto it = cache.find(name);
-  if (it != cache.end()) return it->second;
+  AsmModule* m = asm_module();
+  if (!m) return nullptr;
+  auto it = m->named.find(name);
+  if (it != m->named.end()) return it->second;
   hipFunction_t f = nullptr;
-  if (hipModuleGetFunction(&f, g_asm_mod, name) != hipSuccess) { (void)hipGetLastError(); f = nullptr; }
-  return cache[name] = f;
+  if (hipModuleGetFunction(&f, m->mod, name) != hipSuccess) { (void)hipGetLastError(); f = nullptr; }
+  return m->named[name] = f;
 }
 struct AsmTable { int grid; int* dev; };
 static std::map<unsigned long long, AsmTable> g_asm_tabs;
@@ -1437,7 +1447,10 @@ extern "C" int psam_gemm_f16(const void* A, const void* W, const float* bias, vo
   // Column split for a tile count just above one round of the persistent kernel (one slice through fc1: 4096x5120x1280 is
   // 16 x 20 = 320 tiles of 256x256 for 256 CUs - two rounds for 1.25 rounds of work, or 2.5 rounds of the 128-tile kernel):
   // the columns that fill the CUs exactly once go to the persistent kernel, the rest to whatever the picker chooses for
-  // them (every kernel accumulates an element's K-tiles in the same order, so the results do not depend on the split).
+  // them. Every kernel accumulates an element's K-tiles in the same order; tiles 1 / 11 / 15 add the bias AFTER the products and are
+  // bit-identical to each other, the half-tile assembly kernels (tile 16) start the accumulators FROM the bias: when the remainder
+  // goes to tile 16 its columns differ from the others by that rounding order (a few fp32 ulps before the fp16 rounding:
+  // tests/test_kernels_core_gpu.py test_gemm_half_tile_pingpong bounds it by one fp16 ulp).
   {
     const int ns_on = gemm_option(OPT_NSPLIT);
     const int ncu = num_cus();

@@ -83,8 +83,9 @@ def gemm(a, w, bias=None, out=None, epilogue=EPI_F16, resid=None, gamma=None, re
          out_seg_stride=0, out_seg_off=0, M=None, out16=None, stats=None, ln_mr=None, ln_s=None):
     """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias). a/w fp16 (K contiguous); out fp16 or fp32 by epilogue.
     Folded LayerNorm (psam_gemm_f16_ln): with EPI_F32, `out16` (fp16 [rows, N]) receives half(out) and `stats` (fp32
-    [rows, N/64, 2]) per-row partial (sum, sum of squares); with EPI_F16 / EPI_GELU_F16, `ln_mr` (fp32 [rows, 2] from
-    `ln_finalize`) and `ln_s` (fp32 [N]) apply out = act(rstd * (acc - mean * ln_s) + bias)."""
+    [rows, N/64, 2]) per-row partial (sum, sum of squares); with EPI_F16 / EPI_GELU_F16, `ln_mr` (the 6-floats-per-row buffer of
+    `ln_finalize`: fp32 (mean, rstd) [rows, 2], then the fp16 MFMA fragments of -mean [rows, 8]) and `ln_s` (the s_ext of
+    `fold_layernorm`: fp32 [N], then fp16 fragments [N, 8]) apply out = act(rstd * (acc - mean * ln_s) + bias)."""
     _req(a, torch.float16, "a"); _req(w, torch.float16, "w")
     _req(bias, torch.float32, "bias"); _req(gamma, torch.float32, "gamma")
     _req(resid, torch.float16 if epilogue == EPI_RELU_F16 else torch.float32, "resid")   # epilogue 3 adds a half map
@@ -107,6 +108,15 @@ def gemm(a, w, bias=None, out=None, epilogue=EPI_F16, resid=None, gamma=None, re
     if fold:
         _req(out16, torch.float16, "out16"); _req(stats, torch.float32, "stats")
         _req(ln_mr, torch.float32, "ln_mr"); _req(ln_s, torch.float32, "ln_s")
+        # extended layouts of the assembly kernels (no size travels across the C ABI): ln_mr = ln_mr_buffer() as psam_ln_finalize
+        # fills it (6 floats per row), ln_s = the s_ext of fold_layernorm (N floats + N fp16 fragments of 8 = 5 N floats), stats
+        # [rows, N / 64, 2]
+        if ln_mr is not None:
+            assert ln_s is not None and ln_mr.numel() >= 6 * M and ln_s.numel() >= 5 * N, (ln_mr.numel(), 6 * M, ln_s.numel(), 5 * N)
+        if stats is not None:
+            assert stats.numel() >= M * (N // 64) * 2 and N % 64 == 0
+        if out16 is not None:
+            assert out16.shape[-1] >= N and out16.numel() >= M * N
     if epilogue == EPI_F32 and a.device.index not in _GEMM_WS:
         _ensure_gemm_workspace(a.device)
     t0 = GEMM_TIMER.start() if GEMM_TIMER is not None else None
