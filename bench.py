@@ -365,8 +365,9 @@ def rank_of_8(args, model, vol_d, sup_imgs, sup_masks, dev, torch):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / n
     return {"slices_per_step": len(zs), "ms_per_step": round(dt * 1e3, 2), "slices_per_s_per_rank": round(len(zs) / dt, 2),
-            "note": "a rank's slices span the three z-parts (different support sets), so its micro-batches are 2-3 slices; x8 ranks = the "
-                    "compute-side ceiling of the 8-GPU strong-scaling number (the all-gather of 2 MiB of masks per rank is not in it)"}
+            "note": "a rank's 8 slices span the three z-parts (different support sets) and run as ONE mixed-support batch (round 4: both "
+                    "encoders, CCL, SAM and the decoder do not depend on the support; the prototype match runs per support set); x8 ranks = "
+                    "the compute-side ceiling of the 8-GPU strong-scaling number (the all-gather of 2 MiB of masks per rank is not in it)"}
 
 
 def other_configs(args, dev, torch, ops):
@@ -387,10 +388,14 @@ def other_configs(args, dev, torch, ops):
         dt = time.perf_counter() - t
         ops.GEMM_TIMER = None
         nl, tg, fl = timer.summary()
+        ach = fl / tg / 1e12 if tg > 0 else None
         out[name] = {"value": round(reps * n_units / dt, 2), "unit": unit, "ms_per_call": round(dt / reps * 1e3, 2),
-                     "gemm_tflops": round(fl / tg / 1e12, 1) if tg > 0 else None,
-                     "gemm_frac_of_mfma_peak": round(fl / tg / 1e12 / PEAK_F16_TFLOPS, 4) if tg > 0 else None,
-                     "gemm_time_share": round(tg / dt, 3), "note": note}
+                     # same definition as the headline's `roofline` (dominant kernel = psam_gemm_f16; one stream: the per-launch events
+                     # of this leg are not blurred by a second stream - ProtoSAM's "auto" overlap backs off while a timer is attached)
+                     "roofline": {"bound": "mfma", "achieved": round(ach, 1) if ach else None, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": round(ach / PEAK_F16_TFLOPS, 4) if ach else None, "launches": nl,
+                                  "avg_launch_us": round(tg / max(nl, 1) * 1e6, 2), "gemm_time_share": round(tg / dt, 3)},
+                     "note": note}
     # config 2: DINOv2 ViT-B/14 + ALP cosine-similarity map, 512x512, batch 1 (coarse prediction only)
     m2, _ = build_protosam(dev, sam_type="vit_b", image_size=512, seed=1234, sam_depth=1, coarse_pred_only=True)
     vol, _ = synth_volume(32, 512, seed=0, kind="mri")
@@ -407,7 +412,8 @@ def other_configs(args, dev, torch, ops):
     m3, _ = build_protosam(dev, sam_type="vit_b", image_size=512, seed=1234)
     zs = list(range(32))
     leg("config3", lambda: run_slices(m3, vol_d, sup_imgs, sup_masks, zs, dev, batch=16), 32, 2,
-        note="full ProtoSAM with SAM ViT-B on the 32-slice MRI-like volume, 16-slice batches per z-part")
+        note="full ProtoSAM with SAM ViT-B on the 32-slice MRI-like volume, two 16-slice batches (a batch spans z-parts: one encoder "
+             "forward, the prototype match per support set)")
     leg("config3_per_slice", lambda: run_slices(m3, vol_d, sup_imgs, sup_masks, zs[:16], dev, batch=1), 16, 2,
         note="one ProtoSAM.forward per slice")
     del m3
