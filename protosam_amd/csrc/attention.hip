@@ -26,7 +26,10 @@
 // psam_relpos from the same fp16 q and added in fp32 after the scale.
 #include "common.h"
 #include <stdlib.h>
+#include <map>
 #include <type_traits>
+#include <utility>
+#include <vector>
 
 struct AttnArgs {
   const half_t* qkv;      // [B, N, 3, H, HD]
@@ -1619,7 +1622,8 @@ extern "C" int psam_attention_set_variant(int v) {   // bit 0: V2 softmax in the
   g_attn_v2 = (v & 1) ? 1 : 0;                        // for the windows. Default 5; A/B and tests
   g_gattn = (v & 8) ? 0 : (v & 16) ? 1 : 3;            // bit 3: the register-staged global kernel (attn_kernel); bit 4: gattn_kernel (HIP, DMA-fed)
                                                       // everywhere; neither: the assembly kernel (gattn_asm_gen.py) where it applies
-  g_wattn = (v >> 1) & 3;                             // bits 1-2: 0 attn_kernel<HD, 2, 7>, 1 wattn_kernel, 2 wattn_p_kernel
+  g_wattn = (v >> 1) & 3;                             // bits 1-2: 0 attn_kernel<HD, 2, 7>, 1 wattn_kernel, 2 the assembly kernel where it
+                                                      // applies (else wattn_p_kernel), 3 wattn_p_kernel everywhere
   return PSAM_OK;
 }
 
@@ -1662,14 +1666,114 @@ static int launch_gattn_asm(const AttnArgs& p, hipStream_t s) {
   return PSAM_OK;
 }
 
+// ---- the hand-written window kernel of csrc/wattn_asm_gen.py (hd = 80, 14 x 14 windows of a 64 x 64 token map): PSAM_WATTN=3 ----------
+struct WattnAsmArgs {
+  const void* qkv; void* out; const void* rpack; const void* pad_row; const int* work; const unsigned* geom;
+  int N, H, rs2, hs2, ws2, orow, G; float sl2, isc; int pad0, pad1, pad2;
+};
+static_assert(sizeof(WattnAsmArgs) == 96, "kernarg layout of wattn_asm_gen.py");
+static bool wattn_asm_eligible(const AttnArgs& p, int hd) {
+  if (hd != 80 || !p.rpack || !p.pad_row || p.gh != 64 || p.gw != 64 || p.ws != 14 || p.N != 4096) return false;
+  if (p.hs != hd || p.ws_ != (long long)p.H * hd || p.ts != 3LL * p.H * hd) return false;      // token-major packed qkv
+  return p.B <= 255 && p.H <= 255 && (long long)p.N * p.ts * 2 < 0x20000000LL;
+}
+// Host tables of the kernel, built once per device: (a) DMA geometry - per (image kind, piece of 64 lanes, lane) the byte offset of
+// the lane's 16-byte chunk relative to the window's first token, its offset inside a pad row, and per edge class (partial last
+// window row / column) the exec masks "token row" / "pad row" of every piece; (b) the work list - per workgroup its (image, head,
+// window) items in the XCD-aware order of wattn_p_kernel (windows of one XCD together, the heads of a window back to back).
+struct WattnTables { unsigned* geom = nullptr; std::map<unsigned long long, std::pair<int*, int>> work; long long rs2 = 0; };
+static std::map<int, WattnTables> g_wattn_tabs;
+static const unsigned* wattn_geometry(WattnTables& t, long long rs2) {
+  if (t.geom && t.rs2 == rs2) return t.geom;
+  constexpr int P = 42, NP = 35, WS = 14, GWID = 64;
+  std::vector<unsigned> h((size_t)3 * P * 64 + (size_t)4 * 2 * P * 4, 0u);
+  for (int img = 0; img < 2; ++img)
+    for (int pc = 0; pc < NP; ++pc)
+      for (int l = 0; l < 64; ++l) {
+        const int S = pc * 64 + l, R = S / 10, c = S - R * 10;
+        int ky, kx;
+        if (img == 0) { ky = R >> 4; kx = R & 15; }
+        else { const int C = R >> 5, rho = R & 31; ky = 2 * C + ((rho >> 3) & 1); kx = 4 * (2 * (rho >> 4) + ((rho >> 2) & 1)) + (rho & 3); }
+        const bool valid = kx < WS && ky < WS;
+        h[((size_t)img * P + pc) * 64 + l] = valid ? (unsigned)((long long)(ky * GWID + kx) * rs2 + c * 16) : 0u;
+        h[((size_t)2 * P + pc) * 64 + l] = (unsigned)(c * 16);
+        for (int cls = 0; cls < 4; ++cls) {
+          const bool ey = cls & 2, ex = cls & 1;
+          const bool in = valid && !(ey && ky >= 8) && !(ex && kx >= 8), pad = valid && !in;
+          unsigned* m = &h[(size_t)3 * P * 64 + (((size_t)cls * 2 + img) * P + pc) * 4];
+          if (in) m[l >> 5] |= 1u << (l & 31);
+          if (pad) m[2 + (l >> 5)] |= 1u << (l & 31);
+        }
+      }
+  if (!t.geom && hipMalloc((void**)&t.geom, h.size() * 4) != hipSuccess) { (void)hipGetLastError(); t.geom = nullptr; return nullptr; }
+  if (hipMemcpy(t.geom, h.data(), h.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  t.rs2 = rs2;
+  return t.geom;
+}
+static const int* wattn_worklist(WattnTables& t, int B, int H, int grid) {
+  const unsigned long long key = ((unsigned long long)B << 40) | ((unsigned long long)H << 20) | (unsigned)grid;
+  auto it = t.work.find(key);
+  if (it != t.work.end()) return it->second.first;
+  const int nwin = 25, ngrp = B * nwin;
+  std::vector<std::vector<int>> lists(grid);
+  size_t rows = 0;
+  for (int wg = 0; wg < grid; ++wg) {
+    const int x = wg & 7, sx = wg >> 3;
+    const int nwg_x = (grid + 7 - x) >> 3;
+    const long long cnt_x = (long long)((ngrp + 7 - x) >> 3) * H;
+    const int it0 = (int)((long long)sx * cnt_x / nwg_x), it1 = (int)((long long)(sx + 1) * cnt_x / nwg_x);
+    for (int i = it0; i < it1; ++i) {
+      const int grpq = i / H, hh = i - grpq * H, grp = grpq * 8 + x;
+      const int win = grp % nwin, b = grp / nwin;
+      lists[wg].push_back(b | (hh << 8) | ((win / 5) << 16) | ((win % 5) << 24));
+    }
+    rows = lists[wg].size() > rows ? lists[wg].size() : rows;
+  }
+  rows += 2;
+  std::vector<int> h(rows * grid, -1);
+  for (int wg = 0; wg < grid; ++wg)
+    for (size_t i = 0; i < lists[wg].size(); ++i) h[i * grid + wg] = lists[wg][i];
+  int* dev = nullptr;
+  if (hipMalloc((void**)&dev, h.size() * 4) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (hipMemcpy(dev, h.data(), h.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  t.work[key] = std::make_pair(dev, (int)rows);
+  return dev;
+}
+static int launch_wattn_asm(const AttnArgs& p, hipStream_t s) {
+  hipFunction_t f = psam_asm_function("psam_wattn_asm_80");
+  if (!f) return PSAM_ERR_LAUNCH;
+  int cus, xcds, dev = 0;
+  psam_device_geometry(&cus, &xcds);
+  (void)hipGetDevice(&dev);
+  WattnTables& t = g_wattn_tabs[dev];
+  const int nitems = p.B * p.nwin * p.H;
+  const int grid = nitems < cus ? nitems : cus;
+  WattnAsmArgs a;
+  a.geom = wattn_geometry(t, p.ts * 2);
+  a.work = wattn_worklist(t, p.B, p.H, grid);
+  if (!a.geom || !a.work) return PSAM_ERR_LAUNCH;
+  a.qkv = p.qkv; a.out = p.out; a.rpack = p.rpack; a.pad_row = p.pad_row;
+  a.N = p.N; a.H = p.H; a.rs2 = (int)(p.ts * 2); a.hs2 = (int)(p.hs * 2); a.ws2 = (int)(p.ws_ * 2); a.orow = p.H * 80 * 2; a.G = grid;
+  a.sl2 = p.scale * 1.4426950408889634f; a.isc = 1.0f / p.scale; a.pad0 = a.pad1 = a.pad2 = 0;
+  size_t sz = sizeof(a);
+  void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  if (hipModuleLaunchKernel(f, grid, 1, 1, 14 * 64, 1, 1, 0, s, nullptr, extra) != hipSuccess) {
+    (void)hipGetLastError();
+    return PSAM_ERR_LAUNCH;
+  }
+  return PSAM_OK;
+}
+
 template <int HD, bool V2>
 static int launch_attn(AttnArgs p, int mode, hipStream_t s) {
   if (mode == 2) {
     constexpr int NW = 7;
     p.nqb = 1;
     const int groups8 = (p.B * p.nwin + 7) / 8;
+    // 2 (default): the assembly kernel of wattn_asm_gen.py where it applies, else wattn_p_kernel; 3: wattn_p_kernel everywhere
     if (g_wattn < 0) { const char* e = getenv("PSAM_WATTN"); g_wattn = e ? atoi(e) : 2; }
-    if (g_wattn == 2 && p.rpack != nullptr) {
+    if (g_wattn == 2 && wattn_asm_eligible(p, HD)) return launch_wattn_asm(p, s);
+    if (g_wattn >= 2 && p.rpack != nullptr) {
       int cus, xcds;
       psam_device_geometry(&cus, &xcds);
       const int nitems = p.B * p.nwin * p.H;

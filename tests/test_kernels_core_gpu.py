@@ -327,11 +327,12 @@ def test_attention_global_relpos(dev, H, hd):
 
 
 @pytest.mark.parametrize("B,g,H,hd", [(2, 64, 2, 64), (2, 64, 2, 80), (3, 32, 3, 80), (1, 20, 1, 64), (5, 30, 16, 80),
-                                      (1, 24, 2, 80)])   # (24 x 24 = 576 tokens: psam_relpos' one-tile-per-wave form)
+                                      (1, 24, 2, 80),    # (24 x 24 = 576 tokens: psam_relpos' one-tile-per-wave form)
+                                      (3, 64, 16, 80)])  # (1200 items: several per workgroup of the persistent kernels, every edge class)
 def test_attention_window_relpos(dev, B, g, H, hd):
     """14x14 windows over a g x g map, zero-padded tokens carry the qkv bias (image_encoder.py:267-271): the two-kernel path
-    (psam_relpos -> relq) and the three window kernels of the fused path (attn_kernel, wattn_kernel, the persistent
-    wattn_p_kernel) against the reference arithmetic. Shapes: the 64 x 64 map of a 1024 input; 32 x 32 (nine windows, three of
+    (psam_relpos -> relq) and the window kernels of the fused path (attn_kernel, wattn_kernel, the assembly kernel of
+    csrc/wattn_asm_gen.py - hd = 80 on the 64 x 64 map -, the persistent wattn_p_kernel) against the reference arithmetic. Shapes: the 64 x 64 map of a 1024 input; 32 x 32 (nine windows, three of
     them ragged on two sides); a map smaller than two windows; item counts below / not a multiple of the XCD and CU counts."""
     from oracle.sam_image_encoder import decomposed_rel_pos_terms, window_partition, window_unpartition
     from protosam_amd import ops
@@ -354,7 +355,7 @@ def test_attention_window_relpos(dev, B, g, H, hd):
         relq = ops.relpos(qkv, rp, B, N, H, hd, g, ws, True, scale)
         outs["relq"] = ops.attention(qkv, B, N, H, hd, scale, mode=2, relq=relq, pad_row=pad, gh=g, gw=g, ws=ws)
     try:
-        for v in (1, 3, 5):
+        for v in (1, 3, 5, 7):
             ops.attention_set_variant(v)
             o = torch.full((B, N, C), float("nan"), device=dev, dtype=torch.float16)
             outs[f"variant{v}"] = ops.attention(qkv, B, N, H, hd, scale, out=o, mode=2, rpack=rp, pad_row=pad, gh=g, gw=g, ws=ws)
