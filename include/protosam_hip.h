@@ -90,7 +90,9 @@ int psam_attention_f16(const void* qkv, void* out, const float* rel_h, const flo
                        const void* rpack, const void* pad_row, int B, int N, int H, int hd, float scale, int mode, int gh,
                        int gw, int ws, int head_major, void* stream);
 /* kernel selection of psam_attention_f16 (A/B, tests; default 5). bit 0: V2 softmax of the HIP global kernels (0 = the serial round-1
- * form); bits 1-2: window kernel (0 attn_kernel, 1 wattn_kernel, 2 the persistent wattn_p_kernel); bit 3: the register-staged HIP
+ * form); bits 1-2: window kernel (0 attn_kernel, 1 wattn_kernel, 2 the assembly kernel of csrc/wattn_asm_gen.py where it applies -
+ * rpack given, hd = 80, 14 x 14 windows of a 64 x 64 token map, token-major qkv - and the persistent wattn_p_kernel elsewhere, 3
+ * wattn_p_kernel everywhere); bit 3: the register-staged HIP
  * global kernel; bit 4: the DMA-fed HIP global kernel everywhere; neither bit 3 nor 4: the assembly global kernel
  * (csrc/gattn_asm_gen.py) where it applies - rel-pos, hd = 80, N a multiple of 256, B * H a multiple of 8, H and N / 256 powers of
  * two - and the DMA-fed HIP kernel elsewhere. */
