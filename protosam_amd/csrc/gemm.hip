@@ -1241,7 +1241,7 @@ static int launch_asm(const GemmArgs& p, int epilogue, hipStream_t s, int family
   a.out16 = p.out16; a.stats = p.stats; a.ld16 = p.ld16; a.pad2 = 0;
   static const char* tr = getenv("PSAM_GEMM_ASM_TRACE");
   const bool trace = tr && g_asm_variant > 0;
-  if (trace) { (void)hipMalloc(&a.trace, (size_t)t->grid * 16); (void)hipMemsetAsync(a.trace, 0, (size_t)t->grid * 16, s); }
+  if (trace) { (void)hipMalloc(&a.trace, (size_t)t->grid * 32); (void)hipMemsetAsync(a.trace, 0, (size_t)t->grid * 32, s); }
   size_t sz = ln_prod ? sizeof(a) : 104;     // (the kernarg segment each kernel declares)
   void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
   // streaming epilogue (nt loads / stores) when the output is far beyond the 32 MB of L2 and only the next launch reads it; the
@@ -1253,15 +1253,17 @@ static int launch_asm(const GemmArgs& p, int epilogue, hipStream_t s, int family
     return PSAM_ERR_LAUNCH;
   }
   if (trace) {   // debugging aid (synchronous): shader cycles inside the k-loops and the epilogues, wave 0 of every workgroup
-    std::vector<unsigned> h((size_t)t->grid * 4);
+    std::vector<unsigned> h((size_t)t->grid * 8);
     (void)hipStreamSynchronize(s);
     (void)hipMemcpy(h.data(), a.trace, h.size() * 4, hipMemcpyDeviceToHost);
     (void)hipFree(a.trace);
-    double loop = 0, epi = 0, kt = 0;
-    for (int b = 0; b < t->grid; ++b) { loop += h[b * 4]; epi += h[b * 4 + 1]; kt += h[b * 4 + 2]; }
+    double loop = 0, epi = 0, kt = 0, tot = 0, rt = 0;
+    unsigned tmax = 0;
+    for (int b = 0; b < t->grid; ++b) rt += h[(size_t)t->grid * 4 + b * 4];
+    for (int b = 0; b < t->grid; ++b) { loop += h[b * 4]; epi += h[b * 4 + 1]; kt += h[b * 4 + 2]; tot += h[b * 4 + 3]; tmax = h[b * 4 + 3] > tmax ? h[b * 4 + 3] : tmax; }
     const double tiles = kt / (p.K / 64);
-    if (kt > 0) fprintf(stderr, "asm v%d %dx%dx%d epi%d: %.0f cycles per K-tile, %.0f cycles per epilogue (%.1f tiles per workgroup)\n", g_asm_variant, p.M, p.N,
-                        p.K, epilogue, loop / kt, epi / tiles, tiles / t->grid);
+    if (kt > 0) fprintf(stderr, "asm v%d %dx%dx%d epi%d: %.0f cycles per K-tile, %.0f cycles per epilogue (%.1f tiles per workgroup) kernel entry to exit: mean %.0f max %u cycles = %.1f us (shader clock %.0f MHz)\n", g_asm_variant, p.M, p.N,
+                        p.K, epilogue, loop / kt, epi / tiles, tiles / t->grid, tot / t->grid, tmax, rt / t->grid * 0.01, rt > 0 ? tot / rt * 100.0 : 0.0);
   }
   return PSAM_OK;
 }
@@ -1455,7 +1457,12 @@ extern "C" int psam_gemm_f16(const void* A, const void* W, const float* bias, vo
     const int ns_on = gemm_option(OPT_NSPLIT);
     const int ncu = num_cus();
     const int ntm = (M + 255) / 256;
-    if (ns_on && g_tile_override <= 0 && (epilogue == EPI_F16 || epilogue == EPI_GELU_F16) && out_seg == 0 && N % 256 == 0 &&
+    // (round 4: with its GELU arithmetic hidden under the MFMAs the half-tile kernel takes the whole fc1 shape faster than the split:
+    // 4096x5120x1280 64-66 us vs 49 + 26 us; one ProtoSAM.forward per slice 98.4-100.4 vs 96.3-96.7 slices/s)
+    const bool whole16 = epilogue == EPI_GELU_F16 && pick_tile(M, N, K, epilogue) == 16 && K / 64 >= PSAM_ASM2_E_GELU + 1 &&
+                         (lda % 8) == 0 && (ldw % 8) == 0 && (ldo % 8) == 0 && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W) |
+                           reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0;
+    if (ns_on && !whole16 && g_tile_override <= 0 && (epilogue == EPI_F16 || epilogue == EPI_GELU_F16) && out_seg == 0 && N % 256 == 0 &&
         K >= 768 && ntm > 0 && ntm <= ncu) {
       const int ntn = N / 256, c1 = ncu / ntm;                       // whole tile columns in one full round
       if (c1 >= 1 && c1 < ntn && ntm * c1 * 100 >= ncu * 95 && (ntn - c1) * 2 <= c1) {   // remainder at most half a round
