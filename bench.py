@@ -32,6 +32,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F16_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+# What the chip SUSTAINS on v_mfma_f32_32x32x16_f16 alone, from registers, on all 256 CUs with random operands: the socket power cap
+# pulls the shader clock from 2.39 to 1.61 GHz (zero operands: 2486 TFLOP/s at 2.39 GHz). tools/micro/mfma_power_bench.hip,
+# profiles/r04_mfma_power_limit.txt. Reported beside `peak`, never instead of it.
+SUSTAINED_F16_TFLOPS = 1624.0
 PEAK_HBM_GBS = 8000.0     # HBM3E peak (6.3 TB/s achievable by a float4 copy), same guide
 
 
@@ -229,7 +233,10 @@ def main():
                 # per-shape file of tools/gemm_traffic_by_shape.sh ONLY when it was measured on the shipped kernel sources
                 "traffic": (_gemm_traffic(args, B) or {}).get("bytes_per_launch_avg"), "traffic_detail": _gemm_traffic(args, B), "launches": nl,
                 "avg_launch_us": round(tg / max(nl, 1) * 1e6, 2), "flop_per_launch_avg": round(fl / max(nl, 1)),
-                "gemm_time_share": round(tg / elapsed, 3)}
+                "gemm_time_share": round(tg / elapsed, 3),
+                "sustained_mfma_only": {"value": SUSTAINED_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / SUSTAINED_F16_TFLOPS, 4),
+                                        "note": "register-only MFMA loop, random fp16 operands, 256 CUs: power-capped at 1.61 GHz "
+                                                "(profiles/r04_mfma_power_limit.txt); `peak` is the nominal 2.39 GHz figure"}}
     res = {
         "metric": "query-slices/sec (512x512) end-to-end ProtoSAM infer",
         "value": round(value, 3), "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
