@@ -131,6 +131,56 @@ def _gemm_traffic(args, B):
         return None
 
 
+class PowerSampler:
+    """Socket power and shader clock of this rank's GPU from the amdgpu hwmon files (power1_input in uW, freq1_input in Hz), sampled by
+    a thread every 20 ms between start() and stop(): evidence for the power cap that binds the fp16 MFMA rate. Absent
+    files (another driver, no permission) => None, nothing else changes."""
+
+    def __init__(self, index):
+        import glob
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"), key=lambda q: int(q.split("/card")[1].split("/")[0]))
+        cards = [c for c in cards if os.path.exists(os.path.join(c, "power1_input")) and os.path.exists(os.path.join(c, "freq1_input"))]
+        self.dir = cards[index] if index < len(cards) else None
+        self.samples, self.run, self.thread = [], False, None
+
+    def _read(self, name):
+        with open(os.path.join(self.dir, name)) as f:
+            return float(f.read().strip())
+
+    def _loop(self):
+        while self.run:
+            try:
+                self.samples.append((self._read("power1_input") * 1e-6, self._read("freq1_input") * 1e-6))
+            except Exception:
+                return
+            time.sleep(0.02)
+
+    def start(self):
+        if self.dir is None:
+            return
+        import threading
+        self.samples, self.run = [], True
+        self.thread = threading.Thread(target=self._loop, daemon=True)
+        self.thread.start()
+
+    def stop(self):
+        if self.thread is None:
+            return None
+        self.run = False
+        self.thread.join()
+        self.thread = None
+        if len(self.samples) < 3:
+            return None
+        pw = [a for a, _ in self.samples]; fq = [b for _, b in self.samples]
+        try:
+            cap = self._read("power1_cap") * 1e-6
+        except Exception:
+            cap = None
+        return {"avg_w": round(sum(pw) / len(pw), 1), "max_w": round(max(pw), 1), "cap_w": cap, "sclk_mhz_avg": round(sum(fq) / len(fq)),
+                "sclk_mhz_min": round(min(fq)), "sclk_mhz_max": round(max(fq)), "samples": len(pw),
+                "source": "amdgpu hwmon power1_input / freq1_input, 20 ms period, over the timed steps"}
+
+
 def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -198,6 +248,9 @@ def main():
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     step_ev[0].record()
+    power = PowerSampler(local_rank) if rank == 0 else None
+    if power:
+        power.start()
     ncomp = []
     for s in range(args.steps):
         zs, full, st = step(args.warmup + s)
@@ -207,6 +260,7 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t1
+    power_clock = power.stop() if power else None
     ops.GEMM_TIMER = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -250,6 +304,7 @@ def main():
                    "mean_components_per_slice": round(sum(ncomp) / max(len(ncomp), 1), 2),
                    "flags": "use_bbox use_points point_mode=both use_cca=False", "weights": "seeded random (1234)"},
         "roofline": roofline,
+        "power_clock": power_clock,
     }
     if world == 1 and not args.no_extras:     # single-GPU legs (they would need the other ranks for the all-gather otherwise)
         res.update(extras(args, model, step, ops, psmod, B, torch, dev))
