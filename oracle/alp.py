@@ -4,7 +4,7 @@ Follows models/alpmodule.py (safe_norm :14-18, MultiProtoAsConv.get_prototypes :
 get_prediction_from_prototypes :57-94, forward :161-198) and models/grid_proto_fewshot.py
 (FewShotSeg.get_features :83-103, forward :150-290; FG/BG modes and thresholds :16-24) for the
 inference configuration the caller uses (isval=True, val_wsize=2, n_ways=n_shots=n_queries=1,
-validation_protosam.py:374-388).
+validation_protosam.py:374-388), and for n_shots > 1 (`fewshot_*_multishot`, pinned by oracle/make_multishot_golden.py).
 """
 import torch
 import torch.nn.functional as F
@@ -89,6 +89,34 @@ def fewshot_scores(qry_ft, sup_ft, fg_mask, kernel_size, val_wsize=2, taps=None)
     if taps is not None:
         taps.update(bg_protos=bg_protos, fg_protos=fg_protos, fg_mode=mode, fg_msk=fg, bg_msk=bg)
     return torch.cat([bg_score, fg_score], dim=1)
+
+
+def fewshot_scores_multishot(qry_ft, sup_fts, fg_masks, kernel_size, val_wsize=2):
+    """n_shots > 1 (grid_proto_fewshot.py:228-262): sup_fts [n,C,h,w], fg_masks [n,H,W]. The background classifier sees ALL shots at
+    once (their grid prototypes concatenated in shot order, alpmodule.py:111-131), the foreground one runs per shot - each with its
+    own mode by the rule of :253-256 - and the shots' raw scores are combined by an element-wise max (:265-266)."""
+    h, w = qry_ft.shape[-2:]
+    fg = F.interpolate(fg_masks[:, None].float(), size=(h, w), mode="nearest")        # [n,1,h,w]
+    bg = F.interpolate((1 - fg_masks)[:, None].float(), size=(h, w), mode="nearest")
+    bg_score, _ = cls_unit(qry_ft, sup_fts, bg, "gridconv", BG_THRESH, val_wsize)
+    raw = []
+    for i in range(sup_fts.shape[0]):
+        mode = fg_mode_for(fg[i:i + 1], kernel_size)
+        raw.append(cls_unit(qry_ft, sup_fts[i:i + 1], fg[i:i + 1], mode, FG_THRESH, val_wsize)[0])
+    fg_score = torch.stack(raw, dim=1).max(dim=1)[0]
+    return torch.cat([bg_score, fg_score], dim=1)
+
+
+def fewshot_forward_multishot(encode_fn, supp_imgs, fg_masks, qry_img, image_size, proto_grid_size=8, val_wsize=2):
+    """FewShotSeg.forward with n_ways = 1, n_shots = len(supp_imgs) (grid_proto_fewshot.py:150-290). supp_imgs: list of [1,3,H,W],
+    fg_masks: list of [1,H,W]."""
+    n = len(supp_imgs)
+    imgs = torch.cat(list(supp_imgs) + [qry_img], dim=0)                              # :181-182 shots first, the query last
+    fm = features_to_map(encode_fn(resize_to_patch_multiple(imgs, image_size)))
+    feature_hw = max(image_size // 14, DEFAULT_FEATURE_SIZE)
+    ks = feature_hw // proto_grid_size
+    pred = fewshot_scores_multishot(fm[n:n + 1], fm[:n], torch.cat(list(fg_masks), dim=0), ks, val_wsize)
+    return F.interpolate(pred, size=supp_imgs[0].shape[-2:], mode="bilinear")
 
 
 def fewshot_forward(encode_fn, supp_img, fg_mask, qry_img, image_size, proto_grid_size=8, val_wsize=2, taps=None):

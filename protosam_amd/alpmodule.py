@@ -43,6 +43,24 @@ class MultiProtoAsConv(nn.Module):
         return ops.alp_sim(qry_tok, q_bstride, ld, B, npix, self.embed_dim, bank, pred=pred, eps=safe_norm_eps(),
                            sim_scale=20.0, which_only=which_only)
 
+    @staticmethod
+    def merge_banks(banks, which):
+        """One bank holding the background (which = 0) or foreground (1) prototypes of several banks, concatenated in order: what
+        the reference's `get_prototypes` yields when `sup_x` carries several shots (alpmodule.py:111-131,155-158: the grid
+        prototypes of all shots, for 'gridconv+' plus every shot's global prototype - a softmax-weighted sum does not care about
+        the order). Host-side (one 8-int read per bank): banks are built once per support set, not per query."""
+        key = ops.META_NFG if which else ops.META_NBG
+        cnt = [int(m[key]) for m in torch.stack([b.meta for b in banks]).cpu()]
+        tot = sum(cnt)
+        merged = ops.AlpBank(max(tot, 1), banks[0].C, banks[0].bank.device)
+        if tot:
+            merged.bank[which * merged.cap:which * merged.cap + tot] = torch.cat(
+                [b.bank[which * b.cap:which * b.cap + n] for b, n in zip(banks, cnt)], dim=0)
+        merged.meta[key] = tot
+        if which:
+            merged.meta[ops.META_FGMODE] = banks[0].meta[ops.META_FGMODE]
+        return merged
+
     # ---- reference-shaped API --------------------------------------------------------------------------------
     def forward(self, qry, sup_x, sup_y, mode, thresh, isval=False, val_wsize=None, vis_sim=False,
                 get_prototypes=False, **kwargs):
@@ -51,21 +69,29 @@ class MultiProtoAsConv(nn.Module):
         qry = qry.squeeze(1)                      # [1, C, h, w]
         sup_x = sup_x.squeeze(0).squeeze(1)       # [nshot, C, h, w]
         sup_y = sup_y.squeeze(0)
-        if sup_x.shape[0] != 1:
-            raise NotImplementedError("n_shots > 1 (the reference caller uses 1 shot, validation_protosam.py:346-362)")
+        nshot = sup_x.shape[0]
         C, h, w = qry.shape[-3:]
         if val_wsize is None or not isval:
             pool_w = self.kernel_size[0]          # alpmodule.py:186-189 / avg_pool_op
         else:
             pool_w = val_wsize
-        sup_y = sup_y.reshape(h, w).float().contiguous()
-        sup_tok = sup_x[0].float().permute(1, 2, 0).reshape(h * w, C).contiguous()
+        sup_y = sup_y.reshape(nshot, h, w).float().contiguous()
         qry_tok = qry[0].float().permute(1, 2, 0).reshape(h * w, C).contiguous()
-        bank = self.build_bank(sup_tok, C, h, w, sup_y, pool_w, thresh, force_mode=_MODES[mode])
-        if mode != "mask" and int(bank.meta[ops.META_NFG].item()) - (1 if mode == "gridconv+" else 0) == 0 \
-                and mode == "gridconv":
-            print("failed to find prototypes")
-            raise RuntimeError("MultiProtoAsConv: no prototype passed the threshold (the reference fails in F.conv2d)")
-        pred = self.scores_token_major(qry_tok, h * w * C, C, 1, h * w, bank, which_only=1)
+        banks = []
+        for i in range(nshot):
+            sup_tok = sup_x[i].float().permute(1, 2, 0).reshape(h * w, C).contiguous()
+            banks.append(self.build_bank(sup_tok, C, h, w, sup_y[i], pool_w, thresh, force_mode=_MODES[mode]))
+        if mode == "mask":
+            # one un-normalised prototype per shot, the prediction is the MAX of the shots' cosine maps (alpmodule.py:59-62)
+            pred = None
+            for b in banks:
+                p = self.scores_token_major(qry_tok, h * w * C, C, 1, h * w, b, which_only=1)
+                pred = p if pred is None else torch.maximum(pred, p)
+        else:
+            bank = banks[0] if nshot == 1 else self.merge_banks(banks, 1)
+            if mode == "gridconv" and int(bank.meta[ops.META_NFG].item()) == 0:
+                print("failed to find prototypes")
+                raise RuntimeError("MultiProtoAsConv: no prototype passed the threshold (the reference fails in F.conv2d)")
+            pred = self.scores_token_major(qry_tok, h * w * C, C, 1, h * w, bank, which_only=1)
         pred_grid = pred[:, 1].reshape(1, 1, h, w)
         return pred_grid, [None], {}, None

@@ -165,27 +165,70 @@ class FewShotSeg(nn.Module):
         if self.cache_support:
             self._sup_cache.insert(0, (supp, fg, bg, (pool_w, getattr(self.encoder, "_weights_epoch", 0)),
                                        (supp._version, fg._version), bank, tok))
-            del self._sup_cache[4:]
+            del self._sup_cache[16:]          # (3 z-parts x a few shots)
         return bank, tok
 
+    def _merged_bg_bank(self, banks):
+        """n_shots > 1: the background classifier sees every shot's grid prototypes at once, concatenated in shot order
+        (grid_proto_fewshot.py:239-240 hands all shots to one `cls_unit` call; alpmodule.py:111-131). Built once per set of shot
+        banks (one 8-int read per shot to size it) and cached beside them."""
+        key = tuple(id(b) for b in banks)
+        hit = self.__dict__.get("_ms_cache")
+        if hit is not None and hit[0] == key:
+            return hit[2]
+        merged = self.cls_unit.merge_banks(banks, 0)
+        self._ms_cache = (key, list(banks), merged)      # (holds the shot banks: their ids stay unique while this entry lives)
+        return merged
+
+    def _shot_banks(self, supp_imgs, fore_mask, back_mask, pool_w):
+        """(bank, support tokens) per shot of a 1-way support set. Encodes whatever is not cached - through the encoder's token
+        workspace, so call it BEFORE the query is encoded."""
+        if len(supp_imgs) != 1:
+            raise AssertionError("Multi-shot has not been implemented yet")      # (the reference's message for n_ways != 1, :171)
+        shots = supp_imgs[0]
+        if any(s.shape[0] != 1 for s in shots):
+            raise NotImplementedError("support batch size 1 per shot (validation_protosam.py:346-362)")
+        return [self._support_bank(shots[i], fore_mask[0][i], back_mask[0][i], pool_w) for i in range(len(shots))]
+
+    def _match(self, qry_tok, q_bstride, q_ld, n, pairs):
+        """prototype match of n query slices against one support set (`_shot_banks`) -> scores [n, 2, g*g]. One shot: one bank,
+        one launch. Several (grid_proto_fewshot.py:244-266): background against the merged bank, foreground per shot with that
+        shot's own mode, element-wise max over the shots."""
+        S, g = self._grid()
+        if len(pairs) == 1:
+            bank = pairs[0][0]
+            pred = self.cls_unit.scores_token_major(qry_tok, q_bstride, q_ld, n, g * g, bank)   # [n, 2, g*g]
+            self._check_bank(bank)
+            return pred
+        banks = [p[0] for p in pairs]
+        merged = self._merged_bg_bank(banks)
+        pred = self.cls_unit.scores_token_major(qry_tok, q_bstride, q_ld, n, g * g, merged, which_only=0)
+        self._check_bank(merged)
+        tmp = None
+        for i, bank in enumerate(banks):
+            tmp = self.cls_unit.scores_token_major(qry_tok, q_bstride, q_ld, n, g * g, bank, pred=tmp, which_only=1)
+            if i == 0:
+                pred[:, 1].copy_(tmp[:, 1])
+            else:
+                torch.maximum(pred[:, 1], tmp[:, 1], out=pred[:, 1])
+        return pred
+
     def forward(self, supp_imgs, fore_mask, back_mask, qry_imgs, isval, val_wsize, show_viz=False, supp_fts=None):
-        n_ways, n_shots, n_queries = len(supp_imgs), len(supp_imgs[0]), len(qry_imgs)
+        n_ways, n_queries = len(supp_imgs), len(qry_imgs)
         assert n_ways == 1, "Multi-shot has not been implemented yet"
         assert n_queries == 1
-        if n_shots != 1 or supp_imgs[0][0].shape[0] != 1:
-            raise NotImplementedError("one support shot per call (validation_protosam.py:346-362)")
         if supp_fts is not None:
             raise NotImplementedError("supp_fts is unusable in the reference as well (SURVEY Q18)")
-        supp, fg, bg, qry = supp_imgs[0][0], fore_mask[0][0], back_mask[0][0], qry_imgs[0]
-        img_size = supp.shape[-2:]
+        qry = qry_imgs[0]
+        img_size = supp_imgs[0][0].shape[-2:]
         S, g = self._grid()
         C = self.encoder.embed_dim
         pool_w = val_wsize if (isval and val_wsize is not None) else self.cls_unit.kernel_size[0]
-        bank, sup_tok = self._support_bank(supp, fg, bg, pool_w)
+        pairs = self._shot_banks(supp_imgs, fore_mask, back_mask, pool_w)
+        sup_tok = pairs[0][1]
         qry_tok, q_bstride, q_ld = self._patch_tokens(qry)        # [B, g*g, C] (strided view or upsampled copy)
         B = qry_tok.shape[0]
-        pred = self.cls_unit.scores_token_major(qry_tok, q_bstride, q_ld, B, g * g, bank)   # [B, 2, g*g]
-        self._check_bank(bank)
+        pred = self._match(qry_tok, q_bstride, q_ld, B, pairs)
         output = ops.bilinear_nchw(pred.view(B, 2, g, g), img_size[0], img_size[1])   # :272-273
         supp_view = sup_tok.reshape(1, 1, 1, g, g, C).permute(0, 1, 2, 5, 3, 4)
         qry_view = qry_tok.unflatten(1, (g, g)).unsqueeze(0).permute(0, 1, 4, 2, 3)   # zero-copy [1,B,C,g,g]
@@ -202,19 +245,18 @@ class FewShotSeg(nn.Module):
         B = qry_imgs.shape[0]
         assert sum(gr[-1] for gr in groups) == B
         img_size = groups[0][0][0][0].shape[-2:]
+        allpairs = []                      # every group's banks first: a support that is not cached yet is encoded through the same
+        for supp_imgs, fore_mask, back_mask, isval, val_wsize, n in groups:       # token workspace the query's tokens will live in
+            assert len(supp_imgs) == 1, "Multi-shot has not been implemented yet"
+            assert tuple(supp_imgs[0][0].shape[-2:]) == tuple(img_size)
+            pool_w = val_wsize if (isval and val_wsize is not None) else self.cls_unit.kernel_size[0]
+            allpairs.append(self._shot_banks(supp_imgs, fore_mask, back_mask, pool_w))
         qry_tok, q_bstride, q_ld = self._patch_tokens(qry_imgs)
         out = torch.empty((B, 2, img_size[0], img_size[1]), dtype=torch.float32, device=qry_imgs.device)
         i0 = 0
-        for supp_imgs, fore_mask, back_mask, isval, val_wsize, n in groups:
-            assert len(supp_imgs) == 1, "Multi-shot has not been implemented yet"
-            if len(supp_imgs[0]) != 1 or supp_imgs[0][0].shape[0] != 1:
-                raise NotImplementedError("one support shot per call (validation_protosam.py:346-362)")
-            supp, fg, bg = supp_imgs[0][0], fore_mask[0][0], back_mask[0][0]
-            assert tuple(supp.shape[-2:]) == tuple(img_size)
-            pool_w = val_wsize if (isval and val_wsize is not None) else self.cls_unit.kernel_size[0]
-            bank, _ = self._support_bank(supp, fg, bg, pool_w)
-            pred = self.cls_unit.scores_token_major(qry_tok[i0:i0 + n], q_bstride, q_ld, n, g * g, bank)   # [n, 2, g*g]
-            self._check_bank(bank)
+        for pairs, gr in zip(allpairs, groups):
+            n = gr[-1]
+            pred = self._match(qry_tok[i0:i0 + n], q_bstride, q_ld, n, pairs)   # [n, 2, g*g]
             ops.bilinear_nchw(pred.view(n, 2, g, g), img_size[0], img_size[1], out=out[i0:i0 + n])
             i0 += n
         return out

@@ -29,6 +29,16 @@ def fewshot_pair(size):
     return synth_pair(size, seed=size)
 
 
+MULTISHOT_CASES = ((448, 2), (448, 3), (252, 2))       # (image_size, n_shots) of tests/golden/reference_multishot.npz
+
+
+def multishot_inputs(size, n_shots):
+    """seeded support shots (images, masks) and one query: the pairs of synth.synth_pair with seeds size, size + 1, ..."""
+    from protosam_amd.synth import synth_pair
+    shots = [synth_pair(size, seed=size + i)[:2] for i in range(n_shots)]
+    return [s[0] for s in shots], [s[1] for s in shots], synth_pair(size, seed=size)[2]
+
+
 SMALL_ENCODER = dict(embed_dim=64, depth=3, num_heads=2, global_attn_indexes=(1,), out_chans=32)
 SMALL_ENCODER_SEED = 4321
 

@@ -173,6 +173,61 @@ def test_fewshot_forward_small_image_upsamples_features(dev):
         assert out.shape == ref.shape and perr < 1e-3
 
 
+def test_fewshot_forward_multishot(dev):
+    """n_shots = 2 / 3 (grid_proto_fewshot.py:244-266: background against all shots' prototypes at once, foreground per shot with
+    its own mode, max over the shots) against the REFERENCE's recorded logits; plus the batched / mixed-support entry point."""
+    import os
+    import numpy as np
+    from protosam_amd import synth_cases as gi
+    from protosam_amd.grid_proto_fewshot import FewShotSeg
+    rec = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_multishot.npz"))
+    for size, n_shots in gi.MULTISHOT_CASES:
+        cfg = dict(CFG)
+        cfg["encoder_depth"] = gi.FEWSHOT_DEPTH
+        m = FewShotSeg(size, None, cfg)
+        m.load_state_dict({"encoder." + k: v for k, v in gi.fewshot_encoder_sd().items()}, strict=True)
+        m = m.to(dev).eval()
+        s_imgs, s_ms, q_img = gi.multishot_inputs(size, n_shots)
+        sup = [[x.to(dev) for x in s_imgs]]
+        fg = [[x.to(dev) for x in s_ms]]
+        bg = [[(1 - x).to(dev) for x in s_ms]]
+        ref = torch.from_numpy(rec[f"fewshot_logits_{size}_{n_shots}shot"])
+        for rep in range(2):          # second call: every shot's bank and the merged background bank come from the cache
+            out = m(sup, fg, bg, [q_img.to(dev)], True, 2)[0].cpu()
+            perr = (out.softmax(1) - ref.softmax(1)).abs().max().item()
+            print(f"image_size {size}, {n_shots} shots: max |dprob| vs REFERENCE record {perr:.3e}")
+            assert out.shape == ref.shape and perr < 1e-3
+        one = m([sup[0][:1]], [fg[0][:1]], [bg[0][:1]], [q_img.to(dev)], True, 2)[0].cpu()
+        assert (one - ref).abs().max().item() > 1.0              # (the record is not the one-shot answer)
+        # two query slices, the first matched against all shots, the second against the first shot only
+        q2 = torch.cat([q_img, q_img], dim=0).to(dev)
+        grp = m.forward_groups(q2, [(sup, fg, bg, True, 2, 1), ([sup[0][:1]], [fg[0][:1]], [bg[0][:1]], True, 2, 1)]).cpu()
+        # (a two-slice encoder forward picks other GEMM tiles than a one-slice one: equal up to fp16-operand rounding)
+        assert (grp[0:1] - out).abs().max().item() < 5e-3 and (grp[1:2] - one).abs().max().item() < 5e-3
+
+
+def test_cls_unit_multishot_modes(dev):
+    """MultiProtoAsConv.forward with several shots in `sup_x` (alpmodule.py:97-159: one prototype set over all shots) against
+    the oracle's restatement, all three modes."""
+    from oracle import alp as oalp
+    from protosam_amd.alpmodule import MultiProtoAsConv
+    g = torch.Generator().manual_seed(5)
+    C, hw, n = 64, 32, 3
+    qry = torch.randn((1, 1, C, hw, hw), generator=g)
+    sup = torch.randn((1, n, 1, C, hw, hw), generator=g)
+    msk = torch.zeros((1, n, 1, hw, hw))
+    msk[0, 0, 0, 7:21, 5:23] = 1
+    msk[0, 1, 0, 2:9, 20:30] = 1
+    msk[0, 2, 0, 16:30, 3:12] = 1
+    unit = MultiProtoAsConv(proto_grid=[8, 8], feature_hw=[hw, hw], embed_dim=C).to(dev)
+    for mode in ("mask", "gridconv", "gridconv+"):
+        out = unit(qry.to(dev), sup.to(dev), msk.to(dev), mode, 0.95, isval=True, val_wsize=2)[0].cpu()
+        ref, _ = oalp.cls_unit(qry[0], sup[0, :, 0], msk[0], mode, 0.95, 2)
+        err = (out - ref).abs()
+        print(f"cls_unit {n} shots mode={mode}: max abs diff {err.max().item():.2e}, mean {err.mean().item():.2e}")
+        assert err.max() < 3e-2 and err.mean() < 2e-3          # (|score| <= 20; the one-shot test of this file uses the same bound)
+
+
 def test_conv_frontend_kernels(dev):
     """psam_im2col (any kernel / stride / dilation / padding), the 7x7 stem im2col and MaxPool2d(3,2,1) against torch's
     unfold / max_pool2d, and the conv + folded-BN + identity + ReLU GEMM epilogue (epilogue 3)."""

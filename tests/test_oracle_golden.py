@@ -58,6 +58,22 @@ def test_fewshot_forward(gold, size):
     _close(out, gold[f"fewshot_logits_{size}"], 1e-4)
 
 
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_fewshot_forward_multishot(case):
+    """n_shots = 2 / 3: the oracle against the REFERENCE's own FewShotSeg.forward (oracle/make_multishot_golden.py)."""
+    import os
+    import numpy as np
+    from oracle import alp as oalp, dinov2 as odino
+    from protosam_amd import synth_cases as gi
+    rec = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_multishot.npz"))
+    size, n_shots = gi.MULTISHOT_CASES[case]
+    sd = gi.fewshot_encoder_sd()
+    s_imgs, s_ms, q_img = gi.multishot_inputs(size, n_shots)
+    enc = lambda im: odino.forward_features(im, sd, "dinov2_b14", depth=gi.FEWSHOT_DEPTH)["x_norm_patchtokens"]  # noqa
+    out = oalp.fewshot_forward_multishot(enc, s_imgs, s_ms, q_img, size)
+    _close(out, rec[f"fewshot_logits_{size}_{n_shots}shot"], 1e-4)
+
+
 def test_sam_image_encoder_small(gold):
     from oracle import sam_image_encoder as oenc
     from protosam_amd import synth_cases as gi

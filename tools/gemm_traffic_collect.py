@@ -5,7 +5,7 @@ which is how the GEMM reads its operands (LDS-DMA) and its residual rows: read b
 import glob, hashlib, json, os, sqlite3, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SOURCES = ["protosam_amd/csrc/gemm.hip", "protosam_amd/csrc/gemm_asm_gen.py", "protosam_amd/csrc/gemm_asm2_gen.py"]
+SOURCES = ["protosam_amd/csrc/gemm.hip", "protosam_amd/csrc/gemm_asm_gen.py", "protosam_amd/csrc/gemm_asm2_gen.py", "protosam_amd/csrc/asm_common.py"]
 
 
 def git_blob_hash(path):
