@@ -148,6 +148,15 @@ def most_conf_point(fg_p, comp):
     return np.array([[xs[i], ys[i]]]), [float(vals[i])]
 
 
+def most_conf_points(fg_p, comp, k):
+    """ProtoSAM.get_most_conf_points (ProtoSAM.py:266-289) for k > 1: the component's probabilities in raster order
+    (`output_p_fg[mask]`) through torch.topk itself - its order among equal values is the reference's by construction."""
+    ys, xs = np.nonzero(comp)
+    conf, idx = torch.topk(torch.as_tensor(fg_p[ys, xs]), k)       # (raises for a component of fewer than k pixels, as the reference)
+    idx = idx.numpy()
+    return np.stack([xs[idx], ys[idx]], axis=1), [float(c) for c in conf]
+
+
 def dilate3x3(mask, iterations):
     """cv2.dilate(mask, np.ones((3, 3)), iterations=n) on a 0/255 image (cv2 absent: restated; the default border of a
     dilation never contributes). n passes of a 3x3 maximum = one (2n+1) x (2n+1) maximum; done literally here."""
@@ -193,20 +202,21 @@ def sam_neg_points(cc, output_p, l=1):
     return out
 
 
-def sam_input_points(cc, output_p, point_mode="both"):
-    """ProtoSAM.py:349-450 (positive points): per component [N,2] points in (x, y)."""
+def sam_input_points(cc, output_p, point_mode="both", k=1):
+    """ProtoSAM.py:349-450 (positive points): per component [N,2] points in (x, y); k = num_points_for_sam."""
     fg_p = output_p[0, 1].cpu().numpy()
+    pick = most_conf_point if k == 1 else (lambda f, c: most_conf_points(f, c, k))
     pts = []
     for cc_id in np.unique(cc[1]):
         if cc_id == 0:
             continue
         comp = cc[1] == cc_id
         if point_mode == "conf":
-            p, _ = most_conf_point(fg_p, comp)
+            p, _ = pick(fg_p, comp)
         elif point_mode == "centroid":
             p = cc[3][cc_id][None, :]
         elif point_mode == "both":
-            p, _ = most_conf_point(fg_p, comp)
+            p, _ = pick(fg_p, comp)
             p = np.vstack([p, cc[3][cc_id][None, :]])
         else:
             raise NotImplementedError(f"point mode {point_mode} not implemented")
@@ -258,7 +268,7 @@ def mask_prompts(cc):
 
 def protosam_forward(query_image, output_logits, sam_sd, sam_type="vit_b", use_bbox=True, use_points=True,
                      point_mode="both", use_cca=False, postprocess="upstream", encoder_depth=None, taps=None,
-                     features=None, use_mask=False, use_neg_points=False):
+                     features=None, use_mask=False, use_neg_points=False, num_points=1):
     """ProtoSAM.forward (models/ProtoSAM.py:536-678) after the coarse model: `output_logits` [1,2,H,W] is what
     `self.coarse_segmentation_model(input)` returned. Returns (pred [H,W] float {0,1}, scores list)."""
     original_size = query_image.shape[-2]
@@ -276,7 +286,7 @@ def protosam_forward(query_image, output_logits, sam_sd, sam_type="vit_b", use_b
     if _pred.max() == 0:                                                                  # :612-613
         return output_p.argmax(dim=1)[0], [0]
     bboxes = bbox_per_cc(cc) if use_bbox else [None] * cc[0]
-    points = sam_input_points(cc, output_p, point_mode) if use_points else [None] * cc[0]
+    points = sam_input_points(cc, output_p, point_mode, num_points) if use_points else [None] * cc[0]
     img_u8 = quantise_image(query_image)                                                   # :651-660 (sam_trans = identity)
     if features is None:
         features = oenc.image_encoder(sam_preprocess(img_u8), sam_sd, model_type=sam_type, depth=encoder_depth)

@@ -23,6 +23,8 @@ Negative points (`use_neg_points=True`, ProtoSAM.py:361-372,395-419,508-511): `p
 most confident background pixel of each component's 10-pixel dilation ring and the global one (p_bg >= 0.95); components
 whose prompt sets end up with different token counts are decoded in separate batches.
 `degrees_rotate != 0` runs the coarse model on the rotated query and rotates its logits back (protosam_amd/rotate.py).
+`num_points_for_sam` = k > 1: the k most confident pixels of every component (`_topk_points`: the reference's own host-side
+`torch.topk` call on the kernels' probabilities), k = 1 comes from the component table on the device.
 Unsupported (outside SURVEY §8's hot path, raise NotImplementedError): `debug` plotting, training mode.
 """
 import os
@@ -250,8 +252,11 @@ class ProtoSAM(nn.Module):
             raise ValueError(f"point mode must be one of {POINT_MODES}")
         self.debug = debug
         self.coarse_pred_only = coarse_pred_only
-        if debug or num_points_for_sam != 1:
-            raise NotImplementedError("debug / num_points_for_sam != 1 are outside the hot path")
+        if debug:
+            raise NotImplementedError("debug plotting is outside the hot path")
+        self.num_points_for_sam = int(num_points_for_sam)
+        if self.num_points_for_sam < 1:
+            raise ValueError("num_points_for_sam must be >= 1")
         self._mask_only = self.use_mask and not (self.use_points or self.use_bbox)
         # predict_w_masks writes 10 / -8 into a float array and hands it over `.astype(np.uint8)` (ProtoSAM.py:473-479):
         # whatever this platform's numpy makes of -8.0 (248 on x86-64) is what SAM sees
@@ -304,7 +309,22 @@ class ProtoSAM(nn.Module):
         self.sam_trans = sam_trans
 
     # ---- host-side prompt assembly from the component table -----------------------------------------------------------
-    def _prompts_from_table(self, tab, neg_keys=None):
+    def _topk_points(self, pfg, labels, S, ids, k):
+        """num_points_for_sam = k > 1 (ProtoSAM.get_most_conf_points, ProtoSAM.py:266-289): the k most confident pixels of each
+        component in `ids` (labels of csrc/ccl.hip). The reference takes `torch.topk(output_p_fg[mask], k)` on the host; so does
+        this - the same call on the same raster-ordered values, hence the same order among equal probabilities (a saturated
+        soft-max has many) - on the probabilities and labels the kernels produced. Not the default (k = 1 comes out of the
+        component table on the device); two 4 MB copies per slice."""
+        pf = pfg.reshape(S, S).cpu()
+        lab = labels.view(S, S).cpu()
+        out = {}
+        for cid in ids:
+            mask = lab == cid
+            conf, idx = torch.topk(pf[mask], k)            # (raises for a component of fewer than k pixels, as the reference)
+            out[cid] = torch.nonzero(mask)[idx][:, [1, 0]].numpy().astype(np.float64)
+        return out
+
+    def _prompts_from_table(self, tab, neg_keys=None, topk=None):
         """tab: fp64 numpy table of csrc/ccl.hip; neg_keys: int64 numpy keys of psam_neg_points (use_neg_points).
         Returns per kept component a list of (x, y) and a list of labels in the prompt kernel's convention (1 = positive
         point, 0 = negative point, 2/3 = box corners, -1 = padding point) following get_sam_input_points (:349-450),
@@ -327,8 +347,13 @@ class ProtoSAM(nn.Module):
             c, lab = [], []
             if self.use_points:
                 if self.point_mode in (CONF_MODE, BOTH_MODE):
-                    c.append([r[8], r[9]])
-                    lab.append(1)
+                    if topk is not None:                    # component first + k of the table carries label first + k + 1
+                        for pt in topk[first + k + 1]:
+                            c.append([pt[0], pt[1]])
+                            lab.append(1)
+                    else:
+                        c.append([r[8], r[9]])
+                        lab.append(1)
                 if self.point_mode in (CENTROID_MODE, BOTH_MODE):
                     c.append([r[1] / r[0], r[2] / r[0]])  # cv2 centroid: float64 mean of x, mean of y
                     lab.append(1)
@@ -511,7 +536,8 @@ class ProtoSAM(nn.Module):
         stats = []
         for b in range(B):
             tab = tabs[b]
-            if int(tab[0]) > int(tab[1]):
+            overflow = int(tab[0]) > int(tab[1])
+            if overflow:
                 # more components than the fast table holds (cv2 + the reference's per-component loop have no limit,
                 # util/utils.py:474-494, ProtoSAM.py:505): redo this slice with the large table
                 tab = self._ccl_overflow(b, bufs, output_p, pred, S)
@@ -540,7 +566,12 @@ class ProtoSAM(nn.Module):
                     ws = self._ccl_big if big else cw
                     neg_keys = ops.neg_points(ws, output_p[b, 0], ws.tabs[0] if big else cw.tabs[b], n,
                                               labels=None if big else cw.labels_b[b]).cpu().numpy()
-            c, l, rows = self._prompts_from_table(tab, neg_keys)
+            topk = None
+            if self.num_points_for_sam > 1 and self.use_points and self.point_mode in (CONF_MODE, BOTH_MODE):
+                ids = [int(tab[3]) + 1] if self.use_cca else list(range(1, n + 1))
+                topk = self._topk_points(output_p[b, 1], self._ccl_big.labels if overflow else cw.labels_b[b], S, ids,
+                                         self.num_points_for_sam)
+            c, l, rows = self._prompts_from_table(tab, neg_keys, topk)
             spans.append((b, len(img_idx), len(l)))
             coords += c
             labels += l

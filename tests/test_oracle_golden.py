@@ -224,6 +224,23 @@ def test_protosam_forward_vs_reference_record(gold, orch, name):
     np.testing.assert_allclose(np.array(scores, dtype=np.float64), gold[f"orch_{name}_scores"], atol=1e-5, rtol=0)
 
 
+@pytest.mark.parametrize("name,k", [("default", 3), ("conf_pts", 3), ("cca", 2)])
+def test_protosam_num_points_vs_reference_record(orch, name, k):
+    """num_points_for_sam = k > 1 (ProtoSAM.py:266-289,376-387): oracle == the reference's recorded run, mask bit for bit."""
+    import os
+    from oracle import glue
+    from protosam_amd import synth_cases as gi
+    rec = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_multishot.npz"))
+    taps = {}
+    with torch.no_grad():
+        pred, scores = glue.protosam_forward(orch["q"], gi.orch_coarse_logits(), orch["sd"], "vit_b", postprocess="batched",
+                                             encoder_depth=gi.ORCH_SAM_DEPTH, features=orch["feats"], taps=taps, num_points=k,
+                                             **gi.ORCH_FLAGS[name])
+    assert np.array_equal(pred.numpy().astype(bool), _unpack(rec[f"orch_{name}_k{k}_mask"], (gi.ORCH_SIZE, gi.ORCH_SIZE)))
+    np.testing.assert_allclose(np.array(scores, dtype=np.float64), rec[f"orch_{name}_k{k}_scores"], atol=1e-5, rtol=0)
+    assert np.array_equal(np.stack([np.asarray(p) for p in taps["points"]]).astype(np.int32), rec[f"orch_{name}_k{k}_points"])
+
+
 def test_protosam_edge_cases_vs_reference_record(gold, orch):
     from oracle import glue
     from protosam_amd import synth_cases as gi

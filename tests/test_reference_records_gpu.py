@@ -71,6 +71,40 @@ def test_protosam_forward_vs_reference(dev, gold, name):
     assert d > 0.999 and serr < 1e-3 and perr < TOL_PROB
 
 
+@pytest.mark.parametrize("name,k", [("default", 3), ("conf_pts", 3), ("cca", 2)])
+def test_protosam_num_points_vs_reference(dev, name, k):
+    """num_points_for_sam = k > 1 (ProtoSAM.py:376-387): the k most confident pixels per component (+ centroid in 'both' mode)
+    against the REFERENCE's recorded run (oracle/make_multishot_golden.py -> tests/golden/reference_multishot.npz)."""
+    from protosam_amd import synth_cases as gi
+    from protosam_amd.metrics import dice
+    from protosam_amd.protosam import InputFactory, ProtoSAM, TYPE_ALPNET
+    rec = np.load(os.path.join(os.path.dirname(GOLD), "reference_multishot.npz"))
+    kw = gi.ORCH_FLAGS[name]
+    model = _model(dev, ProtoSAM, num_points_for_sam=k, use_sam_trans=True, **kw)
+    q = gi.orch_query().to(dev)
+    inp = InputFactory.create_input(TYPE_ALPNET, q, support_images=[q], support_labels=[torch.zeros(1, 512, 512)],
+                                    isval=True, val_wsize=2)
+    pred, scores = model(q, inp, degrees_rotate=0)
+    ref = _unpack(rec[f"orch_{name}_k{k}_mask"], (512, 512))
+    ref_scores = rec[f"orch_{name}_k{k}_scores"]
+    assert pred.shape == (512, 512) and len(scores) == len(ref_scores)
+    st = model.last_stats
+    # the chosen points themselves: the first k prompts of every component (the reference's come first, in top-k order)
+    pts = np.array([[p[:k] for p in st["prompts"][0]]], dtype=np.float64)[0]
+    ref_pts = rec[f"orch_{name}_k{k}_points"][:, :k].astype(np.float64)
+    same_pts = int((pts == ref_pts).all(axis=-1).sum())
+    d = dice(pred.cpu(), ref)
+    serr = float(np.abs(np.array(scores, dtype=np.float64) - ref_scores).max())
+    low = st["low_res"].cpu()
+    ref_low = torch.from_numpy(rec[f"orch_{name}_k{k}_low"].astype(np.float32))
+    sl = low[:, 1:] if ref_low.shape[1] == 3 else low[:, 0:1]
+    perr = (torch.sigmoid(sl[..., ::4, ::4]) - torch.sigmoid(ref_low)).abs().max().item()
+    print(f"{name} k={k}: {len(scores)} prompt sets, {same_pts} of {ref_pts.shape[0] * k} points identical, Dice vs REFERENCE {d:.5f}, "
+          f"scores {serr:.2e}, max |dprob(low_res)| {perr:.2e}")
+    assert same_pts == ref_pts.shape[0] * k
+    assert d > 0.999 and serr < 1e-3 and perr < TOL_PROB
+
+
 def test_protosam_edge_cases_vs_reference(dev, gold):
     from protosam_amd import synth_cases as gi
     from protosam_amd.protosam import InputFactory, ProtoSAM, TYPE_ALPNET
