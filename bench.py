@@ -138,9 +138,20 @@ class PowerSampler:
 
     def __init__(self, index):
         import glob
-        cards = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"), key=lambda q: int(q.split("/card")[1].split("/")[0]))
-        cards = [c for c in cards if os.path.exists(os.path.join(c, "power1_input")) and os.path.exists(os.path.join(c, "freq1_input"))]
-        self.dir = cards[index] if index < len(cards) else None
+        cards = [c for c in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")
+                 if os.path.exists(os.path.join(c, "power1_input")) and os.path.exists(os.path.join(c, "freq1_input"))]
+        self.dir = None
+        try:        # the card whose PCI address is this rank's device (a box can expose the hwmon files of GPUs it does not own)
+            import torch
+            pr = torch.cuda.get_device_properties(index)
+            bdf = "%04x:%02x:%02x." % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            for c in cards:
+                if os.path.basename(os.path.realpath(os.path.join(c, "..", ".."))).startswith(bdf):
+                    self.dir = c
+        except Exception:
+            pass
+        if self.dir is None and len(cards) == 1:
+            self.dir = cards[0]
         self.samples, self.run, self.thread = [], False, None
 
     def _read(self, name):

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""One ablation build of the global attention kernel (PSAM_GEMM_ASM_CO = a code object generated with PSAM_GEN_GATTN_ABLATE): time per
+16-slice call, sampled shader clock, cycles per key-tile iteration (1024 iterations per CU: 16 workgroups x 64 tiles)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import importlib.util
+import torch
+from protosam_amd import ops
+spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+dev = torch.device("cuda:0")
+B, H, hd, N = 16, 16, 80, 4096
+qkv = torch.randn(B, N, 3, H, hd, device=dev).half()
+rh = torch.randn(B, H, N, 64, device=dev) * 0.5; rw = torch.randn(B, H, N, 64, device=dev) * 0.5
+out = torch.empty(B, N, H * hd, device=dev, dtype=torch.float16)
+fn = lambda: ops.attention(qkv, B, N, H, hd, hd ** -0.5, out=out, mode=1, rel_h=rh, rel_w=rw, gh=64, gw=64)
+for _ in range(3):
+    fn()
+torch.cuda.synchronize()
+ps = bench.PowerSampler(0)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+n = 400
+time.sleep(0.2)
+ps.start()
+e0.record()
+for _ in range(n):
+    fn()
+e1.record(); torch.cuda.synchronize()
+pc = ps.stop()
+us = e0.elapsed_time(e1) / n * 1e3
+mhz = pc["sclk_mhz_avg"] if pc else 0
+print(f"{os.environ.get('ABL', '?'):45s} {us:8.1f} us  sclk {mhz:5d} MHz  {us * mhz / 1024:7.0f} cycles per iteration  {pc and pc['avg_w']} W")

@@ -4,11 +4,13 @@ A loop of 64 back-to-back MFMAs on 8 independent accumulators, each followed by 
 v_pk_fma_f32); prints shader cycles per MFMA for v_mfma_f32_32x32x16_f16 (32 cycles of the matrix pipe) and v_mfma_f32_16x16x32_f16
 (16 cycles). One workgroup of 256 threads per CU (160 KB of LDS requested), 256 workgroups."""
 variants = []
-for kind in ("32", "16"):
+for kind in ("32", "16", "16v", "16a", "16va"):
     for fill in ("fma", "exp", "pk", "salu", "mix"):
-        if kind == "16" and fill in ("salu", "mix"):
+        if kind != "32" and fill in ("salu", "mix"):
             continue
-        for n in range(0, 9 if kind == "32" else 6):
+        if kind in ("16v", "16a", "16va") and fill != "fma":
+            continue
+        for n in range(0, 9 if kind == "32" else 6 if kind == "16" else 5):
             if n == 0 and fill != "fma":
                 continue
             variants.append((kind, fill, n))
@@ -21,8 +23,13 @@ for (kind, fill, n) in variants:
         blk = m % 8
         if kind == "32":
             body.append("v_mfma_f32_32x32x16_f16 a[%d:%d], v[4:7], v[8:11], a[%d:%d]" % (blk * 16, blk * 16 + 15, blk * 16, blk * 16 + 15))
-        else:
+        elif kind == "16":
             body.append("v_mfma_f32_16x16x32_f16 a[%d:%d], v[4:7], v[8:11], a[%d:%d]" % (blk * 4, blk * 4 + 3, blk * 4, blk * 4 + 3))
+        else:
+            # the global attention kernel's forms: scores accumulate in VGPRs (v64..), operands come from AGPRs (a96.. / a100..)
+            acc = ("v[%d:%d]" % (64 + blk * 4, 64 + blk * 4 + 3)) if "v" in kind[2:] else ("a[%d:%d]" % (blk * 4, blk * 4 + 3))
+            ab = "a[96:99], a[100:103]" if "a" in kind[2:] else "v[4:7], v[8:11]"
+            body.append("v_mfma_f32_16x16x32_f16 %s, %s, %s" % (acc, ab, acc))
         for j in range(n):
             r = 16 + 2 * (fi % 12)
             fi += 1
@@ -40,11 +47,12 @@ for (kind, fill, n) in variants:
             else:
                 body.append("v_pk_fma_f32 v[%d:%d], v[%d:%d], v[12:13], v[14:15]" % (r, r + 1, r, r + 1))
     name = "k_%s_%s_%d" % (kind, fill, n)
-    clob = ", ".join('"v%d"' % i for i in range(4, 40)) + ", " + ", ".join('"a%d"' % i for i in range(128))
+    clob = ", ".join('"v%d"' % i for i in list(range(4, 40)) + list(range(64, 96))) + ", " + ", ".join('"a%d"' % i for i in range(128))
     asm = "\\n\\t".join(
         ["s_memtime %0", "s_waitcnt lgkmcnt(0)"] +
         ["v_mov_b32 v%d, 0x3c003c00" % i for i in range(4, 12)] + ["v_mov_b32 v%d, 0x3f000000" % i for i in range(12, 16)] +
-        ["v_mov_b32 v%d, 0" % i for i in range(16, 40)] + ["v_accvgpr_write_b32 a%d, 0" % i for i in range(128)] +
+        ["v_mov_b32 v%d, 0" % i for i in list(range(16, 40)) + list(range(64, 96))] + ["v_accvgpr_write_b32 a%d, 0" % i for i in range(128)] +
+        ["v_accvgpr_write_b32 a%d, v4" % i for i in range(96, 104)] +
         ["L_loop_%=:"] + body + ["s_sub_u32 %2, %2, 1", "s_cmp_lg_u32 %2, 0", "s_cbranch_scc1 L_loop_%=", "s_nop 7", "s_nop 7", "s_memtime %1", "s_waitcnt lgkmcnt(0)"])
     out.append('__global__ __launch_bounds__(256, 1) void %s(unsigned long long* out, int iters) {' % name)
     out.append('  extern __shared__ char lds[];')
@@ -61,6 +69,6 @@ for (kind, fill, n) in variants:
     out.append('  hipFuncSetAttribute((const void*)%s, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);' % name)
     out.append('  for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL(%s, dim3(256), dim3(256), 160 * 1024, 0, d, iters); hipDeviceSynchronize(); }' % name)
     out.append('  hipMemcpy(h.data(), d, 1024 * 8, hipMemcpyDeviceToHost); std::sort(h.begin(), h.end());')
-    out.append('  printf("%s x%s: %d fillers per MFMA: %%.1f cycles per MFMA (median wave)\\n", (double)h[512] / (iters * 64.0));' % ("v_mfma_32x32x16" if kind == "32" else "v_mfma_16x16x32", fill, n))
+    out.append('  printf("%s x%s: %d fillers per MFMA: %%.1f cycles per MFMA (median wave)\\n", (double)h[512] / (iters * 64.0));' % ("v_mfma_32x32x16" if kind == "32" else "v_mfma_16x16x32" + {"16": "", "16v": " (C/D in VGPRs)", "16a": " (A/B from AGPRs)", "16va": " (C/D in VGPRs, A/B from AGPRs)"}[kind], fill, n))
 out.append('  return 0; }')
 open("tools/micro/valu_shadow_bench.hip", "w").write("\n".join(out) + "\n")
