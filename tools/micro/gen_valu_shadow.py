@@ -54,15 +54,15 @@ for (kind, fill, n) in variants:
         ["v_mov_b32 v%d, 0" % i for i in list(range(16, 40)) + list(range(64, 96))] + ["v_accvgpr_write_b32 a%d, 0" % i for i in range(128)] +
         ["v_accvgpr_write_b32 a%d, v4" % i for i in range(96, 104)] +
         ["L_loop_%=:"] + body + ["s_sub_u32 %2, %2, 1", "s_cmp_lg_u32 %2, 0", "s_cbranch_scc1 L_loop_%=", "s_nop 7", "s_nop 7", "s_memtime %1", "s_waitcnt lgkmcnt(0)"])
-    out.append('__global__ __launch_bounds__(256, 1) void %s(unsigned long long* out, int iters) {' % name)
+    out.append('__global__ __launch_bounds__(512, 1) void %s(unsigned long long* out, int iters) {' % name)
     out.append('  extern __shared__ char lds[];')
     out.append('  unsigned long long c0, c1; int it = iters;')
     out.append('  asm volatile("%s" : "=s"(c0), "=s"(c1), "+s"(it) : : %s, "memory", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47");' % (asm, clob))
-    out.append('  if ((threadIdx.x & 63) == 0) out[blockIdx.x * 4 + (threadIdx.x >> 6)] = c1 - c0;')
+    out.append('  if ((threadIdx.x & 63) == 0) out[blockIdx.x * 8 + (threadIdx.x >> 6)] = c1 - c0;')
     out.append('  if (iters < 0) lds[threadIdx.x] = 1;')
     out.append('}')
 out.append('int main() {')
-out.append('  unsigned long long* d; hipMalloc(&d, 256 * 4 * 8); std::vector<unsigned long long> h(1024);')
+out.append('  unsigned long long* d; hipMalloc(&d, 256 * 8 * 8); std::vector<unsigned long long> h(2048);')
 out.append('  const int iters = 200;')
 for (kind, fill, n) in variants:
     name = "k_%s_%s_%d" % (kind, fill, n)
@@ -70,5 +70,12 @@ for (kind, fill, n) in variants:
     out.append('  for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL(%s, dim3(256), dim3(256), 160 * 1024, 0, d, iters); hipDeviceSynchronize(); }' % name)
     out.append('  hipMemcpy(h.data(), d, 1024 * 8, hipMemcpyDeviceToHost); std::sort(h.begin(), h.end());')
     out.append('  printf("%s x%s: %d fillers per MFMA: %%.1f cycles per MFMA (median wave)\\n", (double)h[512] / (iters * 64.0));' % ("v_mfma_32x32x16" if kind == "32" else "v_mfma_16x16x32" + {"16": "", "16v": " (C/D in VGPRs)", "16a": " (A/B from AGPRs)", "16va": " (C/D in VGPRs, A/B from AGPRs)"}[kind], fill, n))
+for (kind, fill, n) in variants:
+    if kind != "16" or fill == "pk":
+        continue
+    name = "k_%s_%s_%d" % (kind, fill, n)
+    out.append('  for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL(%s, dim3(256), dim3(512), 160 * 1024, 0, d, iters); hipDeviceSynchronize(); }' % name)
+    out.append('  hipMemcpy(h.data(), d, 2048 * 8, hipMemcpyDeviceToHost); std::sort(h.begin(), h.end());')
+    out.append('  printf("TWO WAVES PER SIMD v_mfma_16x16x32 x%s: %d fillers per MFMA: %%.1f cycles per MFMA and wave = %%.1f per MFMA of the SIMD (median wave)\\n", (double)h[1024] / (iters * 64.0), (double)h[1024] / (iters * 128.0));' % (fill, n))
 out.append('  return 0; }')
 open("tools/micro/valu_shadow_bench.hip", "w").write("\n".join(out) + "\n")
