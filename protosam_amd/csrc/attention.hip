@@ -1720,12 +1720,21 @@ static const int* wattn_worklist(WattnTables& t, int B, int H, int grid) {
   for (int wg = 0; wg < grid; ++wg) {
     const int x = wg & 7, sx = wg >> 3;
     const int nwg_x = (grid + 7 - x) >> 3;
-    const long long cnt_x = (long long)((ngrp + 7 - x) >> 3) * H;
-    const int it0 = (int)((long long)sx * cnt_x / nwg_x), it1 = (int)((long long)(sx + 1) * cnt_x / nwg_x);
-    for (int i = it0; i < it1; ++i) {
-      const int grpq = i / H, hh = i - grpq * H, grp = grpq * 8 + x;
-      const int win = grp % nwin, b = grp / nwin;
+    const int nwin_x = (ngrp + 7 - x) >> 3;        // windows (b, wy, wx) of XCD x: grp = q * 8 + x
+    auto push = [&](int grpq, int hh) {
+      const int grp = grpq * 8 + x, win = grp % nwin, b = grp / nwin;
       lists[wg].push_back(b | (hh << 8) | ((win / 5) << 16) | ((win % 5) << 24));
+    };
+    if (nwg_x % H == 0) {
+      // the workgroups of an XCD that run side by side take the H heads of the SAME window(s): a token's q / k / v rows of adjacent
+      // heads are 160-byte neighbours, i.e. they share 128-byte lines - fetched once into the XCD's L2 instead of once per head
+      // (measured, 16 slices: FETCH_SIZE 834 -> see DESIGN.md; a workgroup keeps ONE head and walks the windows)
+      const int lanes = nwg_x / H, hh = sx % H, lane = sx / H;
+      for (int q = lane; q < nwin_x; q += lanes) push(q, hh);
+    } else {
+      const long long cnt_x = (long long)nwin_x * H;
+      const int it0 = (int)((long long)sx * cnt_x / nwg_x), it1 = (int)((long long)(sx + 1) * cnt_x / nwg_x);
+      for (int i = it0; i < it1; ++i) push(i / H, i % H);
     }
     rows = lists[wg].size() > rows ? lists[wg].size() : rows;
   }

@@ -18,7 +18,7 @@ for _ in range(5):
 torch.cuda.synchronize()
 ps = bench.PowerSampler(0)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-n = 2000
+n = int(os.environ.get("NCALLS", "2000"))
 time.sleep(0.2); ps.start(); e0.record()
 for _ in range(n):
     fn()
