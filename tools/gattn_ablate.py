@@ -19,7 +19,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 ps = bench.PowerSampler(0)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-n = 400
+n = int(os.environ.get("NCALLS", "400"))
 time.sleep(0.2)
 ps.start()
 e0.record()
