@@ -1640,20 +1640,20 @@ static int ilog2_exact(int v) {
   return (1 << l) == v ? l : -1;
 }
 static bool gattn_asm_eligible(const AttnArgs& p, int mode, int hd) {
-  if (mode != 1 || hd != 80 || (p.N % 256) != 0 || p.N < 256 || ((p.B * p.H) % 8) != 0) return false;
-  if (ilog2_exact(p.N / 256) < 0 || ilog2_exact(p.H) < 0) return false;
+  if (mode != 1 || (hd != 80 && hd != 64) || (p.N % 256) != 0 || p.N < 256 || ((p.B * p.H) % 8) != 0) return false;
+  if (ilog2_exact(p.N / 256) < 0 || p.H < 1 || p.H > 64 || (long long)p.B * p.H >= 65536 / p.H) return false;
   const long long lim = 0x7fffffffLL;
   return (long long)p.N * p.ts * 2 < lim && p.hs * 2 < lim && p.ws_ * 2 < lim && (long long)p.N * p.H * hd * 2 < lim;
 }
-static int launch_gattn_asm(const AttnArgs& p, hipStream_t s) {
-  hipFunction_t f = psam_asm_function("psam_gattn_asm_80_rel");
+static int launch_gattn_asm(const AttnArgs& p, hipStream_t s, int hd) {
+  hipFunction_t f = psam_asm_function(hd == 64 ? "psam_gattn_asm_64_rel" : "psam_gattn_asm_80_rel");
   if (!f) return PSAM_ERR_LAUNCH;
   GattnAsmArgs a;
   a.qkv = p.qkv; a.out = p.out; a.rel_h = p.rel_h; a.rel_w = p.rel_w;
-  a.N = p.N; a.H = p.H; a.lg_nqb = ilog2_exact(p.N / 256); a.lg_H = ilog2_exact(p.H);
+  a.N = p.N; a.H = p.H; a.lg_nqb = ilog2_exact(p.N / 256); a.lg_H = (65536 + p.H - 1) / p.H;      // (the slot carries ceil(2^16 / H))
   a.sl2 = p.scale * 1.4426950408889634f;
   a.rs2 = (int)(p.ts * 2); a.hs2 = (int)(p.hs * 2); a.ws2 = (int)(p.ws_ * 2);
-  a.NT = p.N / 64; a.orow = p.H * 80 * 2;
+  a.NT = p.N / 64; a.orow = p.H * hd * 2;
   a.rwmul = 1.0f / p.scale;      // rel_w is staged as rel_w / scale: it enters the score MFMAs as their accumulator input
   a.pad = 0;
   size_t sz = sizeof(a);
@@ -1802,7 +1802,7 @@ static int launch_attn(AttnArgs p, int mode, hipStream_t s) {
     dim3 grid(groups8 * 8 * p.nqb), block(NW * 64);
     const bool full = (p.N % 64) == 0;
     if (g_gattn < 0) { const char* e = getenv("PSAM_GATTN"); g_gattn = e ? atoi(e) : 3; }   // 3: the assembly kernel where it applies, else gattn_kernel
-    if (g_gattn == 3 && gattn_asm_eligible(p, mode, HD)) return launch_gattn_asm(p, s);
+    if (g_gattn == 3 && gattn_asm_eligible(p, mode, HD)) return launch_gattn_asm(p, s, HD);
     if (g_gattn && V2) {
       if (mode == 1) {
         if (full) hipLaunchKernelGGL((gattn_kernel<HD, 1, true>), grid, block, 0, s, p);

@@ -439,7 +439,8 @@ def test_window_attention_fused_relpos(dev):
 
 
 @pytest.mark.parametrize("mode,N,H,hd,B", [(0, 1297, 12, 64, 2), (0, 200, 3, 80, 1), (1, 4096, 2, 80, 1), (1, 4096, 2, 64, 1), (1, 4096, 8, 80, 1),
-                                           (1, 4096, 16, 80, 1), (1, 1024, 8, 80, 2), (1, 512, 8, 80, 1)])
+                                           (1, 4096, 16, 80, 1), (1, 1024, 8, 80, 2), (1, 512, 8, 80, 1),
+                                           (1, 4096, 8, 64, 1), (1, 1024, 12, 64, 2), (1, 4096, 12, 64, 2)])   # hd = 64: the ViT-B kernel; 12 heads
 def test_attention_softmax_variants_agree(dev, mode, N, H, hd, B):
     """V2 (tree reductions, one rescale decision for both query tiles, row sums on the matrix pipe) against the round-1 serial
     form and the fp32 reference, including rows whose maximum jumps late in the key sequence (the lazy-rescale branch: a key
@@ -460,7 +461,7 @@ def test_attention_softmax_variants_agree(dev, mode, N, H, hd, B):
         rel = (rel_h[..., :gh].reshape(B, H, N, gh, 1) + rel_w.view(B, H, N, 1, g)).reshape(B, H, N, N)
     outs = []
     # round-1 serial softmax, V2 on the register-staged kernel, V2 on the DMA-fed HIP kernel (gattn_kernel), the default: the assembly
-    # kernel of csrc/gattn_asm_gen.py where it applies (rel-pos, hd = 80, B * H a multiple of 8, N a multiple of 256: the last two cases)
+    # kernels of csrc/gattn_asm_gen.py where they apply (rel-pos, hd = 80 / 64, B * H a multiple of 8, N a multiple of 256)
     for v in (0, 9, 17, 1):
         ops.attention_set_variant(v)
         try:
