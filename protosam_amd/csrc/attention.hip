@@ -1640,7 +1640,7 @@ static int ilog2_exact(int v) {
   return (1 << l) == v ? l : -1;
 }
 static bool gattn_asm_eligible(const AttnArgs& p, int mode, int hd) {
-  if (mode != 1 || (hd != 80 && hd != 64) || (p.N % 256) != 0 || p.N < 256 || ((p.B * p.H) % 8) != 0) return false;
+  if (mode != 1 || (hd != 80 && hd != 64) || (p.N % 256) != 0 || p.N < 256) return false;
   if (ilog2_exact(p.N / 256) < 0 || p.H < 1 || p.H > 64 || (long long)p.B * p.H >= 65536 / p.H) return false;
   const long long lim = 0x7fffffffLL;
   return (long long)p.N * p.ts * 2 < lim && p.hs * 2 < lim && p.ws_ * 2 < lim && (long long)p.N * p.H * hd * 2 < lim;
@@ -1655,10 +1655,10 @@ static int launch_gattn_asm(const AttnArgs& p, hipStream_t s, int hd) {
   a.rs2 = (int)(p.ts * 2); a.hs2 = (int)(p.hs * 2); a.ws2 = (int)(p.ws_ * 2);
   a.NT = p.N / 64; a.orow = p.H * hd * 2;
   a.rwmul = 1.0f / p.scale;      // rel_w is staged as rel_w / scale: it enters the score MFMAs as their accumulator input
-  a.pad = 0;
+  a.pad = p.B * p.H;             // workgroups of the groups beyond it (the grid is rounded up to eight (b, h) per row of XCDs) leave at once
   size_t sz = sizeof(a);
   void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  const int grid = (p.B * p.H) * (p.N / 256);
+  const int grid = ((p.B * p.H + 7) / 8 * 8) * (p.N / 256);
   if (hipModuleLaunchKernel(f, grid, 1, 1, 256, 1, 1, 0, s, nullptr, extra) != hipSuccess) {
     (void)hipGetLastError();
     return PSAM_ERR_LAUNCH;
