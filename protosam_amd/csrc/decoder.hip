@@ -241,14 +241,22 @@ extern "C" int psam_gemm_f32(const float* a, const float* a2, int a2_mod, const 
   if (M <= 0 || N <= 0 || K <= 0 || (K % 32) || (N % 64) || (lda % 4) || (ldw % 4) || (ldo % 4) || (a2 && a2_mod <= 0))
     return PSAM_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  // large tiles once they fill the 256 CUs; 64x64 tiles for the per-slice calls (M = 4096: 32 x 1 large tiles otherwise)
-  const long long big = (long long)((M + 127) / 128) * (N / 128);
-  if ((N % 128) == 0 && big >= 256)
-    hipLaunchKernelGGL((gemm_f32_kernel<128, 128>), dim3((M + 127) / 128, N / 128), dim3(256), 0, s, a, a2, a2_mod, w, bias,
-                       resid, out, M, N, K, lda, ldw, ldo);
-  else
-    hipLaunchKernelGGL((gemm_f32_kernel<64, 64>), dim3((M + 63) / 64, N / 64), dim3(256), 0, s, a, a2, a2_mod, w, bias,
-                       resid, out, M, N, K, lda, ldw, ldo);
+  // Tile shape by measurement (tools/gemm_f32_shapes.py, us per call at N x K = 128 x 256 for 1 / 2 / 16 / 26 / 40 prompt sets of 4096
+  // tokens; a 32x32x2 fp32 MFMA holds the matrix pipe for 64 cycles, so small tiles cost nothing in LDS traffic and fill the CUs'
+  // last round better): 128x128 24.9 / 23.4 / 47.9 / 90.5 / 119.5 - 64x128 13.7 / 14.1 / 47.8 / 79.7 / 108.5 - 64x64 10.5 / 10.9 /
+  // 50.1 / 85.5 / 116.2.
+  struct Shape { int bm, bn; };
+  const Shape shapes[3] = {{128, 128}, {64, 128}, {64, 64}};
+  int best = (M > 16384 && (N % 128) == 0) ? 1 : 2;
+  { static const char* fe = getenv("PSAM_GEMM_F32_SHAPE"); if (fe && N % shapes[atoi(fe) % 3].bn == 0) best = atoi(fe) % 3; }   // (A/B)
+  if (best < 0) return PSAM_ERR_ARG;
+#define PSAM_GF32(BM_, BN_)                                                                                                     \
+  hipLaunchKernelGGL((gemm_f32_kernel<BM_, BN_>), dim3((M + BM_ - 1) / BM_, N / BN_), dim3(256), 0, s, a, a2, a2_mod, w, bias, \
+                     resid, out, M, N, K, lda, ldw, ldo)
+  if (best == 0) PSAM_GF32(128, 128);
+  else if (best == 1) PSAM_GF32(64, 128);
+  else PSAM_GF32(64, 64);
+#undef PSAM_GF32
   return psam_launch_status();
 }
 
