@@ -94,8 +94,8 @@ int psam_attention_f16(const void* qkv, void* out, const float* rel_h, const flo
  * rpack given, hd = 80, 14 x 14 windows of a 64 x 64 token map, token-major qkv - and the persistent wattn_p_kernel elsewhere, 3
  * wattn_p_kernel everywhere); bit 3: the register-staged HIP
  * global kernel; bit 4: the DMA-fed HIP global kernel everywhere; neither bit 3 nor 4: the assembly global kernel
- * (csrc/gattn_asm_gen.py) where it applies - rel-pos, hd = 80, N a multiple of 256, B * H a multiple of 8, H and N / 256 powers of
- * two - and the DMA-fed HIP kernel elsewhere. */
+ * (csrc/gattn_asm_gen.py) where it applies - rel-pos, hd = 80 or 64, N a multiple of 256 with N / 256 a power of two, any head count
+ * and batch - and the DMA-fed HIP kernel elsewhere. */
 int psam_attention_set_variant(int v);
 
 /* rel_h[b,h,n,k] = q . Rh[qy - k + K-1], rel_w likewise (UNSCALED q), as an MFMA GEMM against the whole table followed by
