@@ -16,6 +16,7 @@ and all LayerNorm statistics are fp32. The nn.Module tree below only holds param
 """
 import math
 import os
+import sys
 
 import torch
 import torch.nn as nn
@@ -195,7 +196,53 @@ class DinoVisionTransformer(nn.Module):
 
     # -- forward ---------------------------------------------------------------------------------------------------
     def forward_tokens(self, imgs, S):
-        """imgs fp32 [B,3,H,W] (any H,W) -> bilinear to SxS -> final-norm tokens fp32 [B, 1+R+n, D] (workspace)."""
+        """imgs fp32 [B,3,H,W] (any H,W) -> bilinear to SxS -> final-norm tokens fp32 [B, 1+R+n, D] (workspace).
+        Small batches replay a captured HIP graph of the ~100 launches (`_graph_tokens`): with one or two slices per call the
+        kernels are shorter than the ~7 us a launch costs the host, and the GPU idled 42 % of such a forward."""
+        if self._graph_wanted(imgs):
+            out = self._graph_tokens(imgs, S)
+            if out is not None:
+                return out
+        return self._forward_tokens(imgs, S)
+
+    def _graph_wanted(self, imgs):
+        mode = os.environ.get("PSAM_HIPGRAPH", "auto")
+        if mode == "0" or not imgs.is_cuda or torch.cuda.is_current_stream_capturing():
+            return False
+        if ops.TIMERS or ops.GEMM_TIMER is not None:      # (per-kernel event timing needs the launches themselves)
+            return False
+        return mode == "1" or imgs.shape[0] <= 2
+
+    def _graph_tokens(self, imgs, S):
+        key = (tuple(imgs.shape), S, str(imgs.device), getattr(self, "_weights_epoch", 0), self.fold_ln)
+        graphs = self.__dict__.setdefault("_graphs", {})
+        ent = graphs.get(key)
+        if ent is None:
+            if len(graphs) >= 4:                          # (shapes of a caller are few: a scan's slices share one)
+                graphs.clear()
+            static_in = imgs.float().contiguous().clone()
+            try:
+                # warm-up outside the capture (work lists, workspaces, weight packing are built on first use), then capture
+                side = torch.cuda.Stream(device=imgs.device)
+                side.wait_stream(torch.cuda.current_stream(imgs.device))
+                with torch.cuda.stream(side):
+                    self._forward_tokens(static_in, S)
+                torch.cuda.current_stream(imgs.device).wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    out = self._forward_tokens(static_in, S)
+                ent = graphs[key] = (g, static_in, out)
+            except Exception as e:                        # (a runtime that cannot capture these launches: stay eager, once)
+                graphs[key] = ent = (None, None, None)
+                print(f"protosam_amd: HIP graph capture of the DINOv2 forward failed ({e!r}); running eagerly", file=sys.stderr)
+        g, static_in, out = ent
+        if g is None:
+            return None
+        static_in.copy_(imgs)
+        g.replay()
+        return out
+
+    def _forward_tokens(self, imgs, S):
         assert S % PATCH == 0
         pk = self._pack()
         B = imgs.shape[0]
