@@ -112,12 +112,14 @@ class DinoVisionTransformer(nn.Module):
         self._packed = None
         self._pos_cache = {}
         self._ws = {}
+        self.__dict__.pop("_graphs", None)          # (captured graphs hold the old packs' / workspaces' addresses)
         return super()._apply(fn, *a, **k)
 
     def _load_from_state_dict(self, *a, **k):   # also reached by a parent's recursive load (FewShotSeg.load_state_dict)
         self._weights_epoch = getattr(self, "_weights_epoch", 0) + 1
         self._packed = None
         self._pos_cache = {}
+        self.__dict__.pop("_graphs", None)
         return super()._load_from_state_dict(*a, **k)
 
     def _pack(self):
@@ -198,49 +200,14 @@ class DinoVisionTransformer(nn.Module):
     def forward_tokens(self, imgs, S):
         """imgs fp32 [B,3,H,W] (any H,W) -> bilinear to SxS -> final-norm tokens fp32 [B, 1+R+n, D] (workspace).
         Small batches replay a captured HIP graph of the ~100 launches (`_graph_tokens`): with one or two slices per call the
-        kernels are shorter than the ~7 us a launch costs the host, and the GPU idled 42 % of such a forward."""
-        if self._graph_wanted(imgs):
-            out = self._graph_tokens(imgs, S)
+        kernels are shorter than the ~7 us a launch costs the host, and the GPU idled 42 % of such a forward (ops.GraphCache)."""
+        if ops.graph_wanted(imgs, 2):
+            gc = self.__dict__.setdefault("_graphs", ops.GraphCache("the DINOv2 forward"))
+            key = (tuple(imgs.shape), S, str(imgs.device), getattr(self, "_weights_epoch", 0), self.fold_ln)
+            out = gc.run(key, imgs.float(), lambda t: self._forward_tokens(t, S))
             if out is not None:
                 return out
         return self._forward_tokens(imgs, S)
-
-    def _graph_wanted(self, imgs):
-        mode = os.environ.get("PSAM_HIPGRAPH", "auto")
-        if mode == "0" or not imgs.is_cuda or torch.cuda.is_current_stream_capturing():
-            return False
-        if ops.TIMERS or ops.GEMM_TIMER is not None:      # (per-kernel event timing needs the launches themselves)
-            return False
-        return mode == "1" or imgs.shape[0] <= 2
-
-    def _graph_tokens(self, imgs, S):
-        key = (tuple(imgs.shape), S, str(imgs.device), getattr(self, "_weights_epoch", 0), self.fold_ln)
-        graphs = self.__dict__.setdefault("_graphs", {})
-        ent = graphs.get(key)
-        if ent is None:
-            if len(graphs) >= 4:                          # (shapes of a caller are few: a scan's slices share one)
-                graphs.clear()
-            static_in = imgs.float().contiguous().clone()
-            try:
-                # warm-up outside the capture (work lists, workspaces, weight packing are built on first use), then capture
-                side = torch.cuda.Stream(device=imgs.device)
-                side.wait_stream(torch.cuda.current_stream(imgs.device))
-                with torch.cuda.stream(side):
-                    self._forward_tokens(static_in, S)
-                torch.cuda.current_stream(imgs.device).wait_stream(side)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    out = self._forward_tokens(static_in, S)
-                ent = graphs[key] = (g, static_in, out)
-            except Exception as e:                        # (a runtime that cannot capture these launches: stay eager, once)
-                graphs[key] = ent = (None, None, None)
-                print(f"protosam_amd: HIP graph capture of the DINOv2 forward failed ({e!r}); running eagerly", file=sys.stderr)
-        g, static_in, out = ent
-        if g is None:
-            return None
-        static_in.copy_(imgs)
-        g.replay()
-        return out
 
     def _forward_tokens(self, imgs, S):
         assert S % PATCH == 0

@@ -753,6 +753,56 @@ def normalize_chw(x, mean3, std3, out=None):
     return out
 
 
+
+# ---- HIP graph replay of a launch-only forward -------------------------------------------------------------------
+def graph_wanted(x, max_batch_rows):
+    """PSAM_HIPGRAPH = auto (default: small calls only) / 1 / 0. Never while per-kernel timers are attached (they need the launches
+    themselves) or inside another capture."""
+    import os
+    mode = os.environ.get("PSAM_HIPGRAPH", "auto")
+    if mode == "0" or not x.is_cuda or torch.cuda.is_current_stream_capturing():
+        return False
+    if TIMERS or GEMM_TIMER is not None:
+        return False
+    return mode == "1" or x.shape[0] <= max_batch_rows
+
+
+class GraphCache:
+    """fn(static_input) -> output living in a persistent workspace, captured once per key and replayed: one host call instead of the
+    forward's hundred-odd launches. A failed capture (a runtime that cannot record these launches) falls back to eager, once."""
+
+    def __init__(self, what, limit=4):
+        self.what, self.limit, self.graphs = what, limit, {}
+
+    def run(self, key, x, fn):
+        ent = self.graphs.get(key)
+        if ent is None:
+            if len(self.graphs) >= self.limit:
+                self.graphs.clear()
+            static_in = x.contiguous().clone()
+            try:
+                # warm-up outside the capture (work lists, workspaces and weight packs are built on first use), then the capture
+                cur = torch.cuda.current_stream(x.device)
+                side = torch.cuda.Stream(device=x.device)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    fn(static_in)
+                cur.wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    out = fn(static_in)
+                ent = self.graphs[key] = (g, static_in, out)
+            except Exception as e:
+                import sys
+                ent = self.graphs[key] = (None, None, None)
+                print(f"protosam_amd: HIP graph capture of {self.what} failed ({e!r}); running eagerly", file=sys.stderr)
+        g, static_in, out = ent
+        if g is None:
+            return None
+        static_in.copy_(x)
+        g.replay()
+        return out
+
 # ---- connected components --------------------------------------------------------------------------------------
 CC_HDR, CC_STRIDE = 8, 12
 

@@ -101,12 +101,16 @@ class ImageEncoderViT(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self._packed, self._ws = None, {}
+        self._weights_epoch = getattr(self, "_weights_epoch", 0) + 1      # (captured graphs hold the old packs' addresses)
+        self.__dict__.pop("_graphs", None)
         return super()._apply(fn, *a, **k)
 
     def _load_from_state_dict(self, *a, **k):
         # runs for this module on EVERY load, also a recursive one started at a parent (Sam / ProtoSAM.load_state_dict):
         # nn.Module.load_state_dict never calls a child's load_state_dict
         self._packed = None
+        self._weights_epoch = getattr(self, "_weights_epoch", 0) + 1
+        self.__dict__.pop("_graphs", None)
         return super()._load_from_state_dict(*a, **k)
 
     def _pack(self):
@@ -160,6 +164,16 @@ class ImageEncoderViT(nn.Module):
         return self._ws[B]
 
     def encode_patches(self, patches, B):
+        """One or two slices: a captured HIP graph of the forward's launches (ops.GraphCache; ~330 for ViT-H), else `_encode_patches`."""
+        if B <= 2 and ops.graph_wanted(patches, 2 * self.grid * self.grid):
+            gc = self.__dict__.setdefault("_graphs", ops.GraphCache("the SAM image encoder forward"))
+            key = (tuple(patches.shape), B, str(patches.device), getattr(self, "_weights_epoch", 0), self.fold_ln)
+            out = gc.run(key, patches, lambda t: self._encode_patches(t, B))
+            if out is not None:
+                return out
+        return self._encode_patches(patches, B)
+
+    def _encode_patches(self, patches, B):
         """patches fp16 [B*4096, 3*16*16] (im2col of the normalised image) -> token-major embedding fp32 [B,4096,out].
         `fold_ln` (optional, see __init__): the blocks' LayerNorms never run as passes of their own - the GEMM that updates the residual
         stream also emits half(x) and per-row partial sums, `ln_finalize` turns them into (mean, rstd), and the consuming
