@@ -8,7 +8,7 @@ spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirn
 bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
 dev = torch.device("cuda:0")
 res = {}
-def leg(name, fn, n_units, reps, unit="slices/s", note=""):
+def leg(name, fn, n_units, reps, unit="slices/s", note="", library_default=False):
     fn(); fn()
     torch.cuda.synchronize()
     t = time.perf_counter()
