@@ -84,6 +84,10 @@ int psam_layernorm(const float* x, const float* w, const float* b, void* y, floa
  * windows with the reference's zero padding (pad_row half [3,H,hd] = qkv bias) + rel-pos folded into the score MFMA
  * as 32 extra k-slots (relq half [B,H,N,2,32] from psam_relpos, or relq = null and rpack = psam_relpos' windowed table
  * pack: the query-side terms are then computed inside the kernel and never touch HBM).
+ * mode 1 with rel_h = rel_w = null and rpack = psam_relpos' GLOBAL table pack: the decomposed rel-pos terms are computed inside the
+ * assembly kernel (psam_gattn_asm_{80,64}_fused) for the shapes psam_attention_fused_relpos reports; PSAM_ERR_ARG elsewhere.
+ * mode 0 with hd = 64 and N >= 128 (DINOv2 at 1297 / 5330 tokens) runs the assembly kernel psam_gattn_asm_64_norel: any token count,
+ * the last key tile masked; models/grid_proto_fewshot.py:88-98 (the hub model's Attention.forward).
  * head_major = 0: qkv is token-major [B,N,3,H,hd]; 1: head-major [3,H,B*N,hd] as written by psam_gemm_f16_heads.
  * image_encoder.py:235-251 (Attention.forward), :254-300 (window_partition / unpartition), :337-372. */
 int psam_attention_f16(const void* qkv, void* out, const float* rel_h, const float* rel_w, const void* relq,
@@ -94,9 +98,13 @@ int psam_attention_f16(const void* qkv, void* out, const float* rel_h, const flo
  * rpack given, hd = 80, 14 x 14 windows of a 64 x 64 token map, token-major qkv - and the persistent wattn_p_kernel elsewhere, 3
  * wattn_p_kernel everywhere); bit 3: the register-staged HIP
  * global kernel; bit 4: the DMA-fed HIP global kernel everywhere; neither bit 3 nor 4: the assembly global kernel
- * (csrc/gattn_asm_gen.py) where it applies - rel-pos, hd = 80 or 64, N a multiple of 256 with N / 256 a power of two, any head count
+ * (csrc/gattn_asm_gen.py) where it applies - rel-pos: hd = 80 or 64, N a multiple of 256; no bias: hd = 64, N >= 128; any head count
  * and batch - and the DMA-fed HIP kernel elsewhere. */
 int psam_attention_set_variant(int v);
+/* 1 when psam_attention_f16(mode 1) computes the rel-pos terms itself from `rpack` for this shape (64 x 64 token map, hd 80 / 64,
+ * token-major qkv, the assembly kernels selected), else 0: the caller then runs psam_relpos first.
+ * image_encoder.py:325-372 (add_decomposed_rel_pos) inside :235-251. Returns 0 / 1, not a status. */
+int psam_attention_fused_relpos(int B, int N, int H, int hd, int gh, int gw);
 
 /* rel_h[b,h,n,k] = q . Rh[qy - k + K-1], rel_w likewise (UNSCALED q), as an MFMA GEMM against the whole table followed by
  * a scatter. Rpack half [2 (h,w)][2 (hi,lo)][RP][HDP] (RP = 128 global / 32 windowed, zero padded).

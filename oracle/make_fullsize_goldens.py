@@ -2,6 +2,9 @@
 
   python oracle/make_fullsize_goldens.py [3] [4] [5] [44]   # writes tests/golden/fullsize_cfg{3,4,5}.npz (44: cfg4_heavytail)
   python oracle/make_fullsize_goldens.py 300 400            # every slice of config 3 / 4: tests/golden/fullvolume_cfg{3,4}.npz
+  python oracle/make_fullsize_goldens.py 400 --wseed 777 --vseed 5 --stride 4
+      # the same for another weight draw / another synthetic volume (every 4th slice): fullvolume_cfg4_w777_v5.npz
+      # (round 5: "within 1e-3" is held on several draws, not on one - tests/test_fullsize_gpu.py VOLUME_VARIANTS)
 
 The CPU oracle (pinned against the reference by oracle/validate_against_reference.py) is run ONCE, here in the build
 container, at the configurations' full model depth on seeded synthetic slices; `tests/test_fullsize_gpu.py` runs the HIP
@@ -39,17 +42,17 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 from protosam_amd.synth_cases import cfg5_inputs, volume_config  # noqa: E402  (the seeded inputs live with the other generators)
 
 
-def _weights(sam_type, image_size, heavy_tail=False):
+def _weights(sam_type, image_size, heavy_tail=False, seed=1234):
     from protosam_amd.grid_proto_fewshot import FewShotSeg
     from protosam_amd.runner import ALP_CFG
     from protosam_amd.segment_anything import sam_model_registry
     from protosam_amd.synth import synth_state_dict
-    alp_sd = synth_state_dict(FewShotSeg(image_size, None, dict(ALP_CFG)), 1234)
+    alp_sd = synth_state_dict(FewShotSeg(image_size, None, dict(ALP_CFG)), seed)
     enc_sd = {k[len("encoder."):]: v for k, v in alp_sd.items() if k.startswith("encoder.")}
-    sam_sd = synth_state_dict(sam_model_registry[sam_type](), 1234)
+    sam_sd = synth_state_dict(sam_model_registry[sam_type](), seed)
     if heavy_tail:
         from protosam_amd.synth import heavy_tail_sam_
-        heavy_tail_sam_(sam_sd, 1234)
+        heavy_tail_sam_(sam_sd, seed)
     return enc_sd, sam_sd
 
 
@@ -87,19 +90,42 @@ def make_volume_config(cfg):
     print(f"wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
-def make_whole_volume(cfg):
+AMB_TOL = (4.01e-3, 2.0e-3)
+
+
+def ambiguous_pixels(lows, size):
+    """How many pixels of the FINAL mask an implementation within the north-star tolerance may legitimately flip: a probability
+    error <= 1e-3 on sigmoid(low_res) is a logit error <= 4e-3 next to the threshold (dp = p (1 - p) dl), bilinear up-sampling is
+    a convex combination, so only pixels whose ORACLE up-sampled logit lies within 4e-3 of zero - for any component of the union -
+    can change sign. int32 [2]: the counts at |logit| <= 4.01e-3 and <= 2e-3 after the reference's post-processing (postprocess_masks
+    to 1024^2, union, nearest to the slice's size: ProtoSAM.py:669-676)."""
+    from oracle import sam_prompt_decoder as odec
+    up = odec.postprocess_masks(torch.stack(lows)[None], (1024, 1024), (1024, 1024), "upstream")[0]        # [n, 1024, 1024]
+    near = up.abs().min(dim=0).values
+    near = torch.nn.functional.interpolate(near[None, None], size=size, mode="nearest")[0, 0]
+    return np.array([int((near <= t).sum()) for t in AMB_TOL], dtype=np.int32)
+
+
+def volume_record_name(cfg, wseed=1234, vseed=0):
+    return f"fullvolume_cfg{cfg}.npz" if (wseed, vseed) == (1234, 0) else f"fullvolume_cfg{cfg}_w{wseed}_v{vseed}.npz"
+
+
+def make_whole_volume(cfg, wseed=1234, vseed=0, stride=1):
     """EVERY slice of config 3 (32) / config 4 (64), default flags: final mask (packed bits), scores, sigmoid(low_res_masks) of the
     kept token at every 4th pixel (uint16) -> tests/golden/fullvolume_cfg{3,4}.npz. The GPU tests hold BOTH HIP paths (one
     ProtoSAM.forward per slice; 16-slice forward_batch with the LayerNorm folded into the GEMMs) to Dice >= 0.999 against these
-    masks, slice by slice (BASELINE.md section 4's gate; validation_protosam.py:169-185)."""
+    masks, slice by slice (BASELINE.md section 4's gate; validation_protosam.py:169-185).
+    `wseed` draws other weights (both models), `vseed` another query volume (the support volume is vseed + 1), `stride` keeps every
+    stride-th slice: the variants of tests/test_fullsize_gpu.py VOLUME_VARIANTS."""
     from oracle import alp as oalp, dinov2 as odino, glue
     from protosam_amd.runner import part_assign, support_set
     from protosam_amd.synth import synth_volume
     sam_type, n, kind, _, _ = volume_config(cfg)
-    enc_sd, sam_sd = _weights(sam_type, 512)
-    vol, lab = synth_volume(n, 512, seed=0, kind=kind)
-    svol, slab = synth_volume(n, 512, seed=1, kind=kind)
+    enc_sd, sam_sd = _weights(sam_type, 512, seed=wseed)
+    vol, lab = synth_volume(n, 512, seed=vseed, kind=kind)
+    svol, slab = synth_volume(n, 512, seed=vseed + 1, kind=kind)
     sup_imgs, sup_masks = support_set(svol, slab)
+    path = os.path.join(GOLD, volume_record_name(cfg, wseed, vseed))
     from collections import OrderedDict
     memo = OrderedDict()
 
@@ -114,7 +140,8 @@ def make_whole_volume(cfg):
         return memo[key]
     out = {}
     t_all = time.time()
-    for z in range(n):
+    zs = list(range(0, n, stride))
+    for z in zs:
         t0 = time.time()
         q = vol[z][None, None].repeat(1, 3, 1, 1).contiguous()
         part = part_assign(z, n)
@@ -127,11 +154,13 @@ def make_whole_volume(cfg):
         out[f"z{z}_scores"] = np.array(scores, dtype=np.float32)
         if taps.get("low_res"):
             out[f"z{z}_prob4"] = prob16(torch.stack([l[0] for l in taps["low_res"]]))[..., ::4, ::4].copy()
+            out[f"z{z}_amb"] = ambiguous_pixels([l[0] for l in taps["low_res"]], 512)
         print(f"config {cfg} z={z}: {len(scores)} component(s), fg {int(pred.sum())} px, {time.time() - t0:.0f}s "
               f"(total {time.time() - t_all:.0f}s)", flush=True)
-        if z % 8 == 7 or z == n - 1:      # (checkpoint: a long run)
-            np.savez_compressed(os.path.join(GOLD, f"fullvolume_cfg{cfg}.npz"), **out)
-    path = os.path.join(GOLD, f"fullvolume_cfg{cfg}.npz")
+        if (z // stride) % 8 == 7 or z == zs[-1]:      # (checkpoint: a long run)
+            # (the variants record which slices they hold; the default record keeps its round-4 layout byte for byte)
+            extra = {} if (wseed, vseed, stride) == (1234, 0, 1) else dict(zs=np.array(zs[:zs.index(z) + 1], dtype=np.int32))
+            np.savez_compressed(path, **extra, **out)
     print(f"wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
 
 
@@ -170,9 +199,19 @@ def make_config5():
 
 if __name__ == "__main__":
     torch.set_num_threads(os.cpu_count() or 1)
-    which = [int(a) for a in sys.argv[1:]] or [3, 4, 5]
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("which", nargs="*", type=int)
+    ap.add_argument("--wseed", type=int, default=1234)
+    ap.add_argument("--vseed", type=int, default=0)
+    ap.add_argument("--stride", type=int, default=1)
+    ap.add_argument("--threads", type=int, default=0)
+    args = ap.parse_args()
+    if args.threads:
+        torch.set_num_threads(args.threads)
+    which = args.which or [3, 4, 5]
     for c in which:
         if c in (300, 400):          # every slice of config 3 / 4 (long: ~10 / ~40 minutes on 8 cores)
-            make_whole_volume(c // 100)
+            make_whole_volume(c // 100, args.wseed, args.vseed, args.stride)
         else:
             make_config5() if c == 5 else make_volume_config(c)

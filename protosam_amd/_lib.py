@@ -30,6 +30,7 @@ SIGNATURES = {
     "psam_attention_f16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                            c_float, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "psam_attention_set_variant": [c_int],
+    "psam_attention_fused_relpos": [c_int] * 6,
     "psam_relpos": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_float, c_int, c_void_p],
     "psam_alp_bank": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float,
                       c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],

@@ -1627,38 +1627,49 @@ extern "C" int psam_attention_set_variant(int v) {   // bit 0: V2 softmax in the
   return PSAM_OK;
 }
 
-// ---- the hand-scheduled global kernel of csrc/gattn_asm_gen.py (hd = 80, rel-pos, N a multiple of 256): PSAM_GATTN=3 -------------
+// ---- the hand-scheduled global kernels of csrc/gattn_asm_gen.py: PSAM_GATTN=3 -------------------------------------------------
+//   psam_gattn_asm_{80,64}_rel    mode 1 with rel_h / rel_w given (psam_relpos wrote them), N a multiple of 256
+//   psam_gattn_asm_{80,64}_fused  mode 1 with the packed tables given instead (rpack): the rel-pos terms are computed in the kernel
+//   psam_gattn_asm_64_norel       mode 0, hd = 64, any N >= 128 (DINOv2: 1297 / 5330 tokens), last key tile masked
 hipFunction_t psam_asm_function(const char* name);     // csrc/gemm.hip: the assembly code object
 struct GattnAsmArgs {
-  const void* qkv; void* out; const float* rel_h; const float* rel_w;
-  int N, H, lg_nqb, lg_H; float sl2; int rs2, hs2, ws2, NT, orow; float rwmul; int pad;
+  const void* qkv; void* out; const void* rel_h; const void* rel_w;
+  int N, H; unsigned nqb_magic; int lg_H; float sl2; int rs2, hs2, ws2, NT, orow; float rwmul; int BH;
+  int nqb8, nvalid, pad0, pad1;
 };
-static_assert(sizeof(GattnAsmArgs) == 80, "kernarg layout of gattn_asm_gen.py");
-static int ilog2_exact(int v) {
-  int l = 0;
-  while ((1 << l) < v) ++l;
-  return (1 << l) == v ? l : -1;
-}
-static bool gattn_asm_eligible(const AttnArgs& p, int mode, int hd) {
-  if (mode != 1 || (hd != 80 && hd != 64) || (p.N % 256) != 0 || p.N < 256) return false;
-  if (ilog2_exact(p.N / 256) < 0 || p.H < 1 || p.H > 64 || (long long)p.B * p.H >= 65536 / p.H) return false;
+static_assert(sizeof(GattnAsmArgs) == 96, "kernarg layout of gattn_asm_gen.py");
+// kind: 0 rel (tables from HBM), 1 fused (tables computed in the kernel), 2 norel
+static bool gattn_asm_eligible(const AttnArgs& p, int mode, int hd, int kind) {
+  if (kind == 2) { if (mode != 0 || hd != 64 || p.N < 128) return false; }
+  else if (mode != 1 || (hd != 80 && hd != 64) || (p.N % 256) != 0 || p.N < 256 || p.gw != 64) return false;
+  if (kind == 0 && (!p.rel_h || !p.rel_w)) return false;
+  if (kind == 1 && (!p.rpack || p.N != 4096 || p.ts != 3LL * p.H * hd)) return false;   // (64 x 64 map: the 127-row tables; token-major qkv)
+  const long long nqb = (p.N + 255) / 256;
+  if (p.H < 1 || p.H > 64 || (long long)p.B * p.H >= 65536 / p.H || ((long long)p.B * p.H + 7) / 8 * 8 * nqb >= (1 << 23)) return false;
   const long long lim = 0x7fffffffLL;
   return (long long)p.N * p.ts * 2 < lim && p.hs * 2 < lim && p.ws_ * 2 < lim && (long long)p.N * p.H * hd * 2 < lim;
 }
-static int launch_gattn_asm(const AttnArgs& p, hipStream_t s, int hd) {
-  hipFunction_t f = psam_asm_function(hd == 64 ? "psam_gattn_asm_64_rel" : "psam_gattn_asm_80_rel");
+static int launch_gattn_asm(const AttnArgs& p, hipStream_t s, int hd, int kind) {
+  hipFunction_t f = psam_asm_function(kind == 2 ? "psam_gattn_asm_64_norel"
+                                      : kind == 1 ? (hd == 64 ? "psam_gattn_asm_64_fused" : "psam_gattn_asm_80_fused")
+                                                  : (hd == 64 ? "psam_gattn_asm_64_rel" : "psam_gattn_asm_80_rel"));
   if (!f) return PSAM_ERR_LAUNCH;
   GattnAsmArgs a;
-  a.qkv = p.qkv; a.out = p.out; a.rel_h = p.rel_h; a.rel_w = p.rel_w;
-  a.N = p.N; a.H = p.H; a.lg_nqb = ilog2_exact(p.N / 256); a.lg_H = (65536 + p.H - 1) / p.H;      // (the slot carries ceil(2^16 / H))
+  const int nqb = (p.N + 255) / 256;
+  a.qkv = p.qkv; a.out = p.out;
+  a.rel_h = kind == 1 ? (const void*)p.rpack : (const void*)p.rel_h; a.rel_w = p.rel_w;
+  a.N = p.N; a.H = p.H;
+  a.nqb_magic = (unsigned)((0x100000000ull + 8ull * nqb - 1) / (8ull * nqb));     // ceil(2^32 / (8 nqb)): workgroup -> group of eight (b, h)
+  a.lg_H = (65536 + p.H - 1) / p.H;                                               // (the slot carries ceil(2^16 / H))
   a.sl2 = p.scale * 1.4426950408889634f;
   a.rs2 = (int)(p.ts * 2); a.hs2 = (int)(p.hs * 2); a.ws2 = (int)(p.ws_ * 2);
-  a.NT = p.N / 64; a.orow = p.H * hd * 2;
+  a.NT = (p.N + 63) / 64; a.orow = p.H * hd * 2;
   a.rwmul = 1.0f / p.scale;      // rel_w is staged as rel_w / scale: it enters the score MFMAs as their accumulator input
-  a.pad = p.B * p.H;             // workgroups of the groups beyond it (the grid is rounded up to eight (b, h) per row of XCDs) leave at once
+  a.BH = p.B * p.H;              // workgroups of the groups beyond it (the grid is rounded up to eight (b, h) per row of XCDs) leave at once
+  a.nqb8 = 8 * nqb; a.nvalid = p.N - (a.NT - 1) * 64; a.pad0 = a.pad1 = 0;
   size_t sz = sizeof(a);
   void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  const int grid = ((p.B * p.H + 7) / 8 * 8) * (p.N / 256);
+  const int grid = ((p.B * p.H + 7) / 8 * 8) * nqb;
   if (hipModuleLaunchKernel(f, grid, 1, 1, 256, 1, 1, 0, s, nullptr, extra) != hipSuccess) {
     (void)hipGetLastError();
     return PSAM_ERR_LAUNCH;
@@ -1681,10 +1692,11 @@ static bool wattn_asm_eligible(const AttnArgs& p, int hd) {
 // the lane's 16-byte chunk relative to the window's first token, its offset inside a pad row, and per edge class (partial last
 // window row / column) the exec masks "token row" / "pad row" of every piece; (b) the work list - per workgroup its (image, head,
 // window) items in the XCD-aware order of wattn_p_kernel (windows of one XCD together, the heads of a window back to back).
-struct WattnTables { unsigned* geom = nullptr; std::map<unsigned long long, std::pair<int*, int>> work; long long rs2 = 0; };
+// (one geometry table per row stride, never rewritten once published: launches already enqueued and captured graphs keep its address)
+struct WattnTables { std::map<long long, unsigned*> geoms; std::map<unsigned long long, std::pair<int*, int>> work; };
 static std::map<int, WattnTables> g_wattn_tabs;
 static const unsigned* wattn_geometry(WattnTables& t, long long rs2) {
-  if (t.geom && t.rs2 == rs2) return t.geom;
+  { auto it = t.geoms.find(rs2); if (it != t.geoms.end()) return it->second; }
   constexpr int P = 42, NP = 35, WS = 14, GWID = 64;
   std::vector<unsigned> h((size_t)3 * P * 64 + (size_t)4 * 2 * P * 4, 0u);
   for (int img = 0; img < 2; ++img)
@@ -1705,10 +1717,10 @@ static const unsigned* wattn_geometry(WattnTables& t, long long rs2) {
           if (pad) m[2 + (l >> 5)] |= 1u << (l & 31);
         }
       }
-  if (!t.geom && hipMalloc((void**)&t.geom, h.size() * 4) != hipSuccess) { (void)hipGetLastError(); t.geom = nullptr; return nullptr; }
-  if (hipMemcpy(t.geom, h.data(), h.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-  t.rs2 = rs2;
-  return t.geom;
+  unsigned* g = nullptr;
+  if (hipMalloc((void**)&g, h.size() * 4) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (hipMemcpy(g, h.data(), h.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(g); return nullptr; }
+  return t.geoms[rs2] = g;
 }
 static const int* wattn_worklist(WattnTables& t, int B, int H, int grid) {
   const unsigned long long key = ((unsigned long long)B << 40) | ((unsigned long long)H << 20) | (unsigned)grid;
@@ -1802,7 +1814,12 @@ static int launch_attn(AttnArgs p, int mode, hipStream_t s) {
     dim3 grid(groups8 * 8 * p.nqb), block(NW * 64);
     const bool full = (p.N % 64) == 0;
     if (g_gattn < 0) { const char* e = getenv("PSAM_GATTN"); g_gattn = e ? atoi(e) : 3; }   // 3: the assembly kernel where it applies, else gattn_kernel
-    if (g_gattn == 3 && gattn_asm_eligible(p, mode, HD)) return launch_gattn_asm(p, s, HD);
+    if (mode == 1 && (!p.rel_h || !p.rel_w)) {      // tables only: the fused kernel or nothing (psam_attention_fused_relpos tells the caller)
+      if (p.rpack && gattn_asm_eligible(p, mode, HD, 1)) return launch_gattn_asm(p, s, HD, 1);
+      return PSAM_ERR_ARG;
+    }
+    if (g_gattn == 3 && mode == 1 && gattn_asm_eligible(p, mode, HD, 0)) return launch_gattn_asm(p, s, HD, 0);
+    if (g_gattn == 3 && mode == 0 && gattn_asm_eligible(p, mode, HD, 2)) return launch_gattn_asm(p, s, HD, 2);
     if (g_gattn && V2) {
       if (mode == 1) {
         if (full) hipLaunchKernelGGL((gattn_kernel<HD, 1, true>), grid, block, 0, s, p);
@@ -1853,8 +1870,8 @@ extern "C" int psam_attention_f16(const void* qkv, void* out, const float* rel_h
   p.ws = ws;
   p.nwx = p.nwin = 0;
   { const char* e = getenv("PSAM_ATTN_DBG"); p.dbg = e ? atoi(e) : 0; }
-  if (mode == 1) {
-    if (gw != KT || gh * gw != N || !rel_h || !rel_w) return PSAM_ERR_ARG;
+  if (mode == 1) {   // rel_h / rel_w from psam_relpos, or the packed tables alone (the rel-pos terms are then computed in the kernel)
+    if (gw != KT || gh * gw != N || ((!rel_h || !rel_w) && !rpack)) return PSAM_ERR_ARG;
   }
   if (mode == 2) {
     // the resident-window schedule is laid out for 14 x 14 = 3 x 64 + 4 keys (SAM's window_size, build_sam.py:73)
@@ -1872,6 +1889,20 @@ extern "C" int psam_attention_f16(const void* qkv, void* out, const float* rel_h
     if (hd == 80) return launch_attn<80, false>(p, mode, s);
   }
   return PSAM_ERR_ARG;
+}
+
+// 1 when psam_attention_f16(mode 1) takes the packed rel-pos tables (`rpack` of the global form, ops.pack_rel_tables) in place of
+// rel_h / rel_w for this shape: the assembly kernels psam_gattn_asm_{80,64}_fused compute the terms themselves (no psam_relpos)
+extern "C" int psam_attention_fused_relpos(int B, int N, int H, int hd, int gh, int gw) {
+  if (B <= 0 || N <= 0 || H <= 0 || gw != KT || gh * gw != N) return 0;
+  AttnArgs p;
+  p.ts = 3LL * H * hd; p.hs = hd; p.ws_ = (long long)H * hd;
+  p.B = B; p.N = N; p.H = H; p.gh = gh; p.gw = gw;
+  p.rel_h = p.rel_w = nullptr;
+  p.rpack = reinterpret_cast<const half_t*>(&p);      // (only tested for presence)
+  if (g_gattn < 0) { const char* e = getenv("PSAM_GATTN"); g_gattn = e ? atoi(e) : 3; }
+  if (g_gattn != 3 || !gattn_asm_eligible(p, 1, hd, 1)) return 0;
+  return psam_asm_function(hd == 64 ? "psam_gattn_asm_64_fused" : "psam_gattn_asm_80_fused") != nullptr;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -248,8 +248,10 @@ extern "C" int psam_gemm_f32(const float* a, const float* a2, int a2_mod, const 
   struct Shape { int bm, bn; };
   const Shape shapes[3] = {{128, 128}, {64, 128}, {64, 64}};
   int best = (M > 16384 && (N % 128) == 0) ? 1 : 2;
-  { static const char* fe = getenv("PSAM_GEMM_F32_SHAPE"); if (fe && N % shapes[atoi(fe) % 3].bn == 0) best = atoi(fe) % 3; }   // (A/B)
-  if (best < 0) return PSAM_ERR_ARG;
+  {   // (A/B: PSAM_GEMM_F32_SHAPE=0..2, parsed once, anything else ignored)
+    static const int forced = [] { const char* fe = getenv("PSAM_GEMM_F32_SHAPE"); const int v = fe ? atoi(fe) : -1; return (v >= 0 && v <= 2) ? v : -1; }();
+    if (forced >= 0 && N % shapes[forced].bn == 0) best = forced;
+  }
 #define PSAM_GF32(BM_, BN_)                                                                                                     \
   hipLaunchKernelGGL((gemm_f32_kernel<BM_, BN_>), dim3((M + BM_ - 1) / BM_, N / BN_), dim3(256), 0, s, a, a2, a2_mod, w, bias, \
                      resid, out, M, N, K, lda, ldw, ldo)

@@ -1156,6 +1156,7 @@ static std::map<unsigned long long, AsmTable> g_asm_tabs;
 static const AsmTable* asm_table(int ntm, int ntn, int mode, int halves = 0, int wg_per_cu = 1) {
   int dev = 0;
   (void)hipGetDevice(&dev);
+  if (ntm >= 4096 || ntn >= (1 << 20)) return nullptr;   // (the key's fields: 12 bits of ntm below the CU count)
   const unsigned long long key = ((unsigned long long)eff_cus() << 52) | ((unsigned long long)ntm << 40) | ((unsigned long long)ntn << 20) | ((unsigned long long)(halves ? 1 : 0) << 19) |
                                  ((unsigned long long)(halves & 1) << 18) | ((unsigned long long)(wg_per_cu - 1) << 16) | ((unsigned long long)mode << 8) | (unsigned)dev;
   auto it = g_asm_tabs.find(key);
@@ -1385,6 +1386,16 @@ static int gemm_dispatch(const void* A, const void* W, const float* bias, void* 
   if (tsel == 11 && (N % 256) != 0) tsel = 1;
   if (tsel == 11 && epilogue != EPI_F32 && !p.wide16) tsel = 1;   // the persistent kernel stores fp16 rows with 16-byte instructions
   if (ln_cons && !p.wide16) return PSAM_ERR_ARG;                  // (the folded-LayerNorm epilogues live in tiles 1 and 11)
+  {   // PSAM_GEMM_LOG=1: which kernel family every distinct launch shape goes to (stderr, once per shape)
+    static const bool logging = getenv("PSAM_GEMM_LOG") != nullptr;
+    if (logging) {
+      static std::map<std::string, int> seen;
+      char key[160];
+      snprintf(key, sizeof(key), "%d x %d x %d epilogue %d ln %d%d head_hd %d out_seg %d resid_mod %d -> tile %d", M, N, K, epilogue, (int)ln_prod,
+               (int)ln_cons, head_hd, out_seg, resid_mod, tsel);
+      if (seen[key]++ == 0) fprintf(stderr, "psam_gemm_f16: %s\n", key);
+    }
+  }
   if (tsel == 15) return launch_asm(p, epilogue, s);
   if (tsel == 16) return launch_asm(p, epilogue, s, 2);
   p.ksplit = 1;
@@ -1396,7 +1407,11 @@ static int gemm_dispatch(const void* A, const void* W, const float* bias, void* 
     const int ks_on = gemm_option(OPT_SPLITK);
     const bool auto_sel = g_tile_override <= 0;
     const KsWorkspace* ksw = ks_workspace();
-    if (ks_on && auto_sel && ksw && tsel == 1 && epilogue == EPI_F32 && !ln_prod && !ln_cons && !head_hd && N % 256 == 0 &&
+    // never inside a stream capture (ops.GraphCache): the one workspace per device is ordered between streams by a host-tracked
+    // event, which a replayed graph neither waits for nor records - two graphs replayed on two streams would share the planes
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (ksw && hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    if (ks_on && auto_sel && ksw && cap == hipStreamCaptureStatusNone && tsel == 1 && epilogue == EPI_F32 && !ln_prod && !ln_cons && !head_hd && N % 256 == 0 &&
         out_seg == 0 && (ldo % 4) == 0) {
       const int t256 = ((M + 255) / 256) * (N / 256), nkt = K / 64;
       // measured (tools/gemm_splitk_bench.py, us split / 128-tile): 4096x1280x5120 (3 ranges of 26-27 K-tiles, 240 items) 80 / 108;

@@ -203,7 +203,8 @@ class DinoVisionTransformer(nn.Module):
         kernels are shorter than the ~7 us a launch costs the host, and the GPU idled 42 % of such a forward (ops.GraphCache)."""
         if ops.graph_wanted(imgs, 2):
             gc = self.__dict__.setdefault("_graphs", ops.GraphCache("the DINOv2 forward"))
-            key = (tuple(imgs.shape), S, str(imgs.device), getattr(self, "_weights_epoch", 0), self.fold_ln)
+            key = (tuple(imgs.shape), S, str(imgs.device), getattr(self, "_weights_epoch", 0), self.fold_ln, self.fold_min_fill,
+                   ops.dispatch_key())
             out = gc.run(key, imgs.float(), lambda t: self._forward_tokens(t, S))
             if out is not None:
                 return out

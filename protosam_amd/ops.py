@@ -70,6 +70,8 @@ QKV_HEAD_MAJOR = _os.environ.get("PSAM_QKV_HEAD_MAJOR", "0") != "0"
 # window layers: compute the decomposed rel-pos query terms inside the attention kernel (default) instead of a psam_relpos
 # launch that writes them to HBM (PSAM_FUSE_WINDOW_RELPOS=0, kept for A/B)
 FUSE_WINDOW_RELPOS = _os.environ.get("PSAM_FUSE_WINDOW_RELPOS", "1") != "0"
+# global layers: the same inside the assembly global-attention kernel (round 5; attention_fused_relpos)
+FUSE_GLOBAL_RELPOS = _os.environ.get("PSAM_FUSE_GLOBAL_RELPOS", "1") != "0"
 
 
 def _ptr(t):
@@ -230,19 +232,35 @@ def _ensure_gemm_workspace(device):
         _GEMM_WS[None] = buf
 
 
+DISPATCH_EPOCH = 0     # bumped by every set_* switch below: part of the key of captured graphs (a graph bakes the dispatch in)
+
+
+def _bump_dispatch():
+    global DISPATCH_EPOCH
+    DISPATCH_EPOCH += 1
+
+
+def dispatch_key():
+    """what a captured graph of a forward depends on besides shapes and weights: every run-time dispatch switch of this module"""
+    return (DISPATCH_EPOCH, QKV_HEAD_MAJOR, FUSE_WINDOW_RELPOS, FUSE_GLOBAL_RELPOS)
+
+
 def gemm_set_tile(tile):
-    """0 auto, 1 = 128x128, 2 = 256x128, 3 = 256x256 (see csrc/gemm.hip)."""
+    """0 auto, 1 = 128x128 (HIP), 11 = 256x256 persistent (HIP), 15 / 16 / 17 = the assembly kernels (see csrc/gemm.hip pick_tile)."""
+    _bump_dispatch()
     _lib.check(_lib.lib().psam_gemm_set_tile(int(tile)), "psam_gemm_set_tile")
 
 
 def gemm_set_option(name, value):
     """Dispatch switches of the GEMM: "asm", "half_tiles", "splitk", "nsplit" (0 / 1), "max_wgs" (cap on the persistent grids,
     0 = none) (see include/protosam_hip.h)."""
+    _bump_dispatch()
     _lib.check(_lib.lib().psam_gemm_set_option(name.encode(), int(value)), "psam_gemm_set_option")
 
 
 def gemm_asm_variant(v):
     """Experiment kernels of the assembly GEMM (library built with GENFLAGS=--experiments); 0 = shipped schedule."""
+    _bump_dispatch()
     _lib.check(_lib.lib().psam_gemm_asm_variant(int(v)), "psam_gemm_asm_variant")
 
 
@@ -349,11 +367,27 @@ def attention(qkv, B, N, H, hd, scale, out=None, mode=0, rel_h=None, rel_w=None,
     return out
 
 
+_FUSED_RELPOS = {}
+
+
+def attention_fused_relpos(B, N, H, hd, gh, gw):
+    """True when attention(mode=1) takes `rpack` (pack_rel_tables, global form) in place of rel_h / rel_w: the assembly kernels
+    psam_gattn_asm_*_fused compute the decomposed rel-pos terms themselves - no psam_relpos launch, no fp32 [B,H,N,64] x 2 round trip
+    (PSAM_FUSE_GLOBAL_RELPOS=0: the two-kernel path, for A/B)."""
+    if not FUSE_GLOBAL_RELPOS or QKV_HEAD_MAJOR:
+        return False
+    key = (B, N, H, hd, gh, gw, DISPATCH_EPOCH)
+    if key not in _FUSED_RELPOS:
+        _FUSED_RELPOS[key] = bool(_lib.lib().psam_attention_fused_relpos(B, N, H, hd, gh, gw))
+    return _FUSED_RELPOS[key]
+
+
 def attention_set_variant(v):
     """bit 0: V2 softmax in the global kernels (0 = round-1 serial form); bits 1-2: window kernel of the fused rel-pos path
     (0 attn_kernel, 1 wattn_kernel, 2 the persistent wattn_p_kernel); bit 3: the register-staged HIP global kernel; bit 4: the
     DMA-fed HIP global kernel everywhere (neither: the assembly global kernel where it applies, see include/protosam_hip.h).
     Default 5; for A/B and the equivalence tests."""
+    _bump_dispatch()
     _lib.check(_lib.lib().psam_attention_set_variant(int(v)), "psam_attention_set_variant")
 
 

@@ -156,18 +156,27 @@ class ImageEncoderViT(nn.Module):
             self._ws[B] = dict(x=e((M, D), torch.float32), ln=e((M, D), torch.float16), qkv=e((M, 3 * D), torch.float16),
                                stats=e((M, D // 64, 2), torch.float32), mr=ops.ln_mr_buffer(M, dev),
                                att=e((M, D), torch.float16), hid=e((M, 4 * D), torch.float16),
-                               relh=e((B, H, N, 64), torch.float32), relw=e((B, H, N, 64), torch.float32),
                                relq=torch.zeros((B, H, N, 2, 32), dtype=torch.float16, device=dev),
                                n0=e((M, oc), torch.float32), n1=e((M, oc), torch.float16),
                                col=e((M, 9 * oc), torch.float16), n2=e((M, oc), torch.float32),
                                out=e((B, N, oc), torch.float32))
         return self._ws[B]
 
+    def _rel_buffers(self, ws, B, H, N):
+        """fp32 [B,H,N,64] x 2 of the two-kernel global rel-pos path (268 MB each at 16 slices of ViT-H): only allocated when that path
+        runs (the fused kernel does not need them)."""
+        if "relh" not in ws:
+            dev = self.pos_embed.device
+            ws["relh"] = torch.empty((B, H, N, 64), dtype=torch.float32, device=dev)
+            ws["relw"] = torch.empty((B, H, N, 64), dtype=torch.float32, device=dev)
+        return ws["relh"], ws["relw"]
+
     def encode_patches(self, patches, B):
         """One or two slices: a captured HIP graph of the forward's launches (ops.GraphCache; ~330 for ViT-H), else `_encode_patches`."""
         if B <= 2 and ops.graph_wanted(patches, 2 * self.grid * self.grid):
             gc = self.__dict__.setdefault("_graphs", ops.GraphCache("the SAM image encoder forward"))
-            key = (tuple(patches.shape), B, str(patches.device), getattr(self, "_weights_epoch", 0), self.fold_ln)
+            key = (tuple(patches.shape), B, str(patches.device), getattr(self, "_weights_epoch", 0), self.fold_ln,
+                   getattr(self, "fold_min_fill", None), ops.dispatch_key())
             out = gc.run(key, patches, lambda t: self._encode_patches(t, B))
             if out is not None:
                 return out
@@ -210,11 +219,14 @@ class ImageEncoderViT(nn.Module):
                                head_major=ops.QKV_HEAD_MAJOR)
                     ops.attention(ws["qkv"], B, N, H, hd, hd ** -0.5, out=ws["att"], mode=2, relq=ws["relq"],
                                   pad_row=bp["pad_row"], gh=g, gw=g, ws=bp["ws"], head_major=ops.QKV_HEAD_MAJOR)
+            elif ops.attention_fused_relpos(B, N, H, hd, g, g):   # rel_h / rel_w computed inside the attention kernel (round 5)
+                ops.attention(ws["qkv"], B, N, H, hd, hd ** -0.5, out=ws["att"], mode=1, rpack=bp["rpack"], gh=g, gw=g)
             else:
-                ops.relpos(ws["qkv"], bp["rpack"], B, N, H, hd, g, g, False, hd ** -0.5, rel_h=ws["relh"],
-                           rel_w=ws["relw"], head_major=ops.QKV_HEAD_MAJOR)
-                ops.attention(ws["qkv"], B, N, H, hd, hd ** -0.5, out=ws["att"], mode=1, rel_h=ws["relh"],
-                              rel_w=ws["relw"], gh=g, gw=g, head_major=ops.QKV_HEAD_MAJOR)
+                relh, relw = self._rel_buffers(ws, B, H, N)
+                ops.relpos(ws["qkv"], bp["rpack"], B, N, H, hd, g, g, False, hd ** -0.5, rel_h=relh,
+                           rel_w=relw, head_major=ops.QKV_HEAD_MAJOR)
+                ops.attention(ws["qkv"], B, N, H, hd, hd ** -0.5, out=ws["att"], mode=1, rel_h=relh,
+                              rel_w=relw, gh=g, gw=g, head_major=ops.QKV_HEAD_MAJOR)
             ops.gemm(ws["att"], bp["proj_w"], bp["proj_b"], out=x, epilogue=ops.EPI_F32, resid=x, **fk)
             if fold:
                 ops.ln_finalize(stats, M, D, LN_EPS, mr=mr)

@@ -26,14 +26,14 @@ def _unpack(bits, S):
     return torch.from_numpy(np.unpackbits(bits)[:S * S].reshape(S, S).astype(np.float32))
 
 
-def _volume_setup(dev, cfg):
+def _volume_setup(dev, cfg, wseed=1234, vseed=0):
     from protosam_amd.synth_cases import volume_config
     from protosam_amd.runner import build_protosam, support_set
     from protosam_amd.synth import synth_volume
     sam_type, n, kind, slices, flagsets = volume_config(cfg)
-    model, _ = build_protosam(dev, sam_type=sam_type, image_size=512, seed=1234, heavy_tail=(cfg == 44))
-    vol, _ = synth_volume(n, 512, seed=0, kind=kind)
-    svol, slab = synth_volume(n, 512, seed=1, kind=kind)
+    model, _ = build_protosam(dev, sam_type=sam_type, image_size=512, seed=wseed, heavy_tail=(cfg == 44))
+    vol, _ = synth_volume(n, 512, seed=vseed, kind=kind)
+    svol, slab = synth_volume(n, 512, seed=vseed + 1, kind=kind)
     sup_imgs, sup_masks = support_set(svol.to(dev), slab.to(dev))
     return model, vol.to(dev), sup_imgs, sup_masks, n, slices, flagsets
 
@@ -130,27 +130,39 @@ def test_volume_runner_equals_per_slice_forward(dev, cfg):
     assert int(diff.max()) <= 256 and all(int(diff[z]) <= 32 or ds[z] >= 0.995 for z in zs)
 
 
-@pytest.mark.parametrize("cfg", [3, 4])
-def test_whole_volume_vs_oracle_masks(dev, cfg):
-    """EVERY slice of config 3 (32) / config 4 (64) against the oracle's final masks (tests/golden/fullvolume_cfg{3,4}.npz), for BOTH
-    HIP paths - one ProtoSAM.forward per slice, and 16-slice forward_batch calls (LayerNorm folded into the GEMMs, batches that span
-    z-parts): mean Dice over the slices >= 0.999 (BASELINE.md section 4's gate with the caller's aggregation: validation_protosam.py
-    computes the metric of :169-185 per slice and averages, :399-403), every slice >= 0.998 or within 32 pixels, the same number of prompt sets, scores and
-    sigmoid(low_res_masks) (every 4th pixel) within the north-star 1e-3."""
+# (config, weight seed, volume seed): the round-4 records (every slice, weights 1234, volume 0) and, round 5, two more weight draws and
+# one more volume per configuration (config 3: every slice; config 4: every 4th) - oracle/make_fullsize_goldens.py --wseed / --vseed
+VOLUME_VARIANTS = [(3, 1234, 0), (4, 1234, 0), (3, 777, 0), (3, 4242, 0), (3, 1234, 5), (4, 777, 0), (4, 4242, 0), (4, 1234, 5)]
+
+
+@pytest.mark.parametrize("cfg,wseed,vseed", VOLUME_VARIANTS)
+def test_whole_volume_vs_oracle_masks(dev, cfg, wseed, vseed):
+    """The slices of config 3 / config 4 volumes against the oracle's records (tests/golden/fullvolume_cfg{3,4}[_w<seed>_v<seed>].npz)
+    on SEVERAL weight draws and volumes (the 1e-3 has to be a property of the implementation, not of one draw), for BOTH HIP paths -
+    one ProtoSAM.forward per slice, and 16-slice forward_batch calls (LayerNorm folded into the GEMMs, batches that span z-parts):
+      * sigmoid(low_res_masks) of the kept token (every 4th pixel) and the scores within the north-star 1e-3, the same number of
+        prompt sets, on both paths;
+      * the final masks: mean Dice over the slices >= 0.999 (BASELINE.md section 4's gate with the caller's aggregation:
+        validation_protosam.py computes the metric of :169-185 per slice and averages, :399-403);
+      * per slice, every flipped pixel has to be one the tolerance explains: at most as many as the oracle's record counts pixels whose
+        up-sampled logit lies within 4e-3 of the threshold (`z<z>_amb`: a probability error of 1e-3 is a logit error of 4e-3 there, and
+        only such a pixel can change sign). Records without the count (none since round 5) fall back to Dice >= 0.998 or <= 32 px."""
+    from oracle.make_fullsize_goldens import volume_record_name
     from protosam_amd.metrics import dice
     from protosam_amd.runner import run_slices
-    gold = np.load(os.path.join(GOLD, f"fullvolume_cfg{cfg}.npz"))
-    model, vol_d, sup_imgs, sup_masks, n, _, _ = _volume_setup(dev, cfg)
+    gold = np.load(os.path.join(GOLD, volume_record_name(cfg, wseed, vseed)))
+    model, vol_d, sup_imgs, sup_masks, n, _, _ = _volume_setup(dev, cfg, wseed, vseed)
     model.use_cca = False
-    zs = list(range(n))
+    zs = [int(z) for z in gold["zs"]] if "zs" in gold.files else list(range(n))
     for name, batch in (("per-slice", 1), ("batched", 16)):
-        dices, worst_p, worst_s, flips, bad = [], 0.0, 0.0, 0, []
-        for i in range(0, n, 16):
-            chunk = zs[i:i + 16]
+        dices, worst_p, worst_s, flips, bad, amb_used = [], 0.0, 0.0, 0, [], 0.0
+        step = 16 if batch > 1 else 1            # (one call per slice on the per-slice path: its last_stats hold that slice's logits)
+        for i in range(0, len(zs), step):
+            chunk = zs[i:i + step]
             masks, st = run_slices(model, vol_d, sup_imgs, sup_masks, chunk, dev, batch=batch)
             masks = masks.cpu()
-            if batch > 1:
-                per = model.last_stats
+            per = model.last_stats
+            if "low_res" in per:
                 low, iou, sel = per["low_res"].cpu(), per["iou"].cpu(), per["sel"]
             for b, z in enumerate(chunk):
                 ref = _unpack(gold[f"z{z}_mask"], 512)
@@ -158,26 +170,27 @@ def test_whole_volume_vs_oracle_masks(dev, cfg):
                 f = int((masks[b].float() != ref).sum())
                 dices.append(d)
                 flips = max(flips, f)
-                if d < 0.998 and f > 32:
+                if f"z{z}_amb" in gold.files:
+                    amb = int(gold[f"z{z}_amb"][0])
+                    amb_used = max(amb_used, f / max(amb, 1))
+                    if f > amb:
+                        bad.append((z, d, f, amb))
+                elif d < 0.998 and f > 32:
                     bad.append((z, d, f))
                 ref_scores = gold[f"z{z}_scores"]
                 assert st[b] == len(ref_scores), (name, z, st[b], len(ref_scores))
-                if batch > 1:
-                    _, start, cnt = next(sp for sp in per["spans"] if sp[0] == b)
+                if f"z{z}_prob4" in gold.files:
+                    _, start, cnt = next(sp for sp in per["spans"] if sp[0] == b) if batch > 1 else (0, 0, low.shape[0])
                     refp = torch.from_numpy(gold[f"z{z}_prob4"].astype(np.float32) / 65535.0)
                     p = torch.sigmoid(low[start:start + cnt, sel])[..., ::4, ::4]
                     worst_p = max(worst_p, (p - refp).abs().max().item())
                     worst_s = max(worst_s, float(np.abs(iou[start:start + cnt, sel].numpy() - ref_scores).max()))
         below = sum(1 for d in dices if d < 0.999)
-        print(f"config {cfg} {name}: {n} slices, mean Dice {np.mean(dices):.5f}, worst {min(dices):.5f}, most flipped pixels {flips}, "
-              f"{below} slice(s) below 0.999" + (f", max |dprob(low_res)| {worst_p:.2e}, scores {worst_s:.2e}" if batch > 1 else ""))
-        # the caller's number is the MEAN of the per-slice Dice (validation_protosam.py:399-403): the 0.999 gate applies to it. A single
-        # slice may sit below: the mask is a threshold of logits that agree to ~5e-4 in probability, and a slice whose boundary runs
-        # through a flat stretch of the logit map flips a few dozen border pixels either way - 19 of a 4 200-pixel mask are Dice 0.9977
-        # (config 4, the small organ cross-sections at the end of the volume), 80 of 70 000 are 0.9988 (config 3). Per slice: Dice >=
-        # 0.998 or at most 32 flipped pixels.
+        print(f"config {cfg} weights {wseed} volume {vseed} {name}: {len(zs)} slices, mean Dice {np.mean(dices):.5f}, worst {min(dices):.5f}, "
+              f"most flipped pixels {flips} (at most {amb_used:.2f} of a slice's tolerance-explained count), {below} slice(s) below 0.999, "
+              f"max |dprob(low_res)| {worst_p:.2e}, scores {worst_s:.2e}")
+        assert worst_p <= TOL and worst_s <= TOL, (name, worst_p, worst_s)
         assert np.mean(dices) >= 0.999 and not bad, (name, np.mean(dices), bad)
-        assert worst_p <= TOL and worst_s <= TOL
 
 
 def test_config4_slice_vs_reference_full_depth_record(dev):

@@ -476,6 +476,64 @@ def test_attention_softmax_variants_agree(dev, mode, N, H, hd, B):
     assert (outs[0] - outs[1]).abs().max().item() < 2e-3
 
 
+@pytest.mark.parametrize("N,H,B", [(1297, 12, 2), (1301, 16, 1), (2594, 12, 1), (5330, 12, 1), (128, 2, 1), (192, 3, 3), (320, 1, 9), (449, 5, 2)])
+def test_attention_global_asm_any_token_count(dev, N, H, B):
+    """psam_gattn_asm_64_norel (csrc/gattn_asm_gen.py, round 5: DINOv2's attention, models/grid_proto_fewshot.py:88-98) at the token
+    counts the configurations run - 1297 = one 504^2 slice (21 key tiles: the odd tail; 17 valid keys in the last), 1301 (ViT-L + 4
+    register tokens), 2594, 5330 = 1022^2 (84 tiles, 18 valid keys in the last) - and at the edges of its structure: 128 tokens (two
+    tiles, no loop), 192 (three), 320 (five tiles, a full last one), 449 (last tile holds ONE key); rows beyond N of the last query
+    block; B * H not a multiple of eight. Against the fp32 arithmetic AND the HIP kernel it replaces, with rows whose maximum
+    jumps by far more than the 2^8 lazy-rescale threshold late in the key sequence - once inside the masked last tile."""
+    from protosam_amd import ops
+    hd = 64
+    qkv = _rand((B, N, 3, H, hd), dev, 0.5, 41)
+    for (qi, ki, gain) in ((17, N - 1, 40.0), (70, N - 70, 25.0), (N - 3, N // 2, 60.0), (N - 1, 3, 30.0)):
+        qkv[0, ki, 1, 0] = qkv[0, qi, 0, 0] * gain
+    qkv = qkv.half()
+    scale = hd ** -0.5
+    out = ops.attention(qkv, B, N, H, hd, scale).float()
+    ops.attention_set_variant(5 | 16)                       # the DMA-fed HIP kernel everywhere
+    try:
+        hip = ops.attention(qkv, B, N, H, hd, scale).float()
+    finally:
+        ops.attention_set_variant(5)
+    ref = _ref_attn_global(qkv, B, N, H, hd, scale)
+    assert torch.isfinite(out).all()
+    torch.testing.assert_close(out, ref, rtol=2e-3, atol=2e-3)
+    assert (out - hip).abs().max().item() < 2e-3
+
+
+@pytest.mark.parametrize("B,H,hd", [(1, 2, 64), (1, 2, 80), (2, 16, 80), (3, 12, 64), (1, 5, 80)])
+def test_attention_global_fused_relpos(dev, B, H, hd):
+    """psam_gattn_asm_{80,64}_fused (round 5): the decomposed rel-pos terms of the global blocks (image_encoder.py:325-372) computed
+    inside the attention kernel from the packed tables - against the fp32 reference arithmetic (oracle's restatement of
+    add_decomposed_rel_pos, pinned to the reference) and against the two-kernel path (psam_relpos -> fp32 tables in HBM -> the _rel
+    kernel) it replaces. One query is aligned with a late key (the lazy-rescale branch)."""
+    from oracle.sam_image_encoder import decomposed_rel_pos_terms
+    from protosam_amd import ops
+    g = 64
+    N = g * g
+    assert ops.attention_fused_relpos(B, N, H, hd, g, g)
+    qkv = _rand((B, N, 3, H, hd), dev, 1.0, 51)
+    qkv[0, N - 100, 1, 0] = qkv[0, 1000, 0, 0] * 6.0
+    qkv = qkv.half()
+    Rh = _rand((2 * g - 1, hd), dev, 0.3, 52)
+    Rw = _rand((2 * g - 1, hd), dev, 0.3, 53)
+    scale = hd ** -0.5
+    rpack = ops.pack_rel_tables(Rh, Rw, False, hd)
+    fused = ops.attention(qkv, B, N, H, hd, scale, mode=1, rpack=rpack, gh=g, gw=g).float()
+    rel_h, rel_w = ops.relpos(qkv, rpack, B, N, H, hd, g, g, False, scale)
+    two = ops.attention(qkv, B, N, H, hd, scale, mode=1, rel_h=rel_h, rel_w=rel_w, gh=g, gw=g).float()
+    assert torch.isfinite(fused).all()
+    assert (fused - two).abs().max().item() < 2e-3, (fused - two).abs().max().item()
+    if B * H <= 4:      # (the [B H, N, N] fp32 bias of the reference arithmetic: 64 MB per head)
+        q = qkv.float().view(B, N, 3, H, hd)[:, :, 0].permute(0, 2, 1, 3).reshape(B * H, N, hd)
+        rh_ref, rw_ref = decomposed_rel_pos_terms(q.cpu(), Rh.cpu(), Rw.cpu(), (g, g))
+        bias = (rh_ref[..., :, None] + rw_ref[..., None, :]).reshape(B, H, N, N).to(dev)
+        ref = _ref_attn_global(qkv, B, N, H, hd, scale, rel=bias)
+        torch.testing.assert_close(fused, ref, rtol=2e-3, atol=2e-3)
+
+
 @pytest.mark.parametrize("tile", [1, 11, 15])
 @pytest.mark.parametrize("M,D,N2,act", [(4096, 1280, 3840, 0), (1297 * 3, 768, 3072, 1), (777, 256, 256, 0)])
 def test_gemm_folded_layernorm(dev, tile, M, D, N2, act):
