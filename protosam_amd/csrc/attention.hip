@@ -1634,10 +1634,40 @@ extern "C" int psam_attention_set_variant(int v) {   // bit 0: V2 softmax in the
 hipFunction_t psam_asm_function(const char* name);     // csrc/gemm.hip: the assembly code object
 struct GattnAsmArgs {
   const void* qkv; void* out; const void* rel_h; const void* rel_w;
-  int N, H; unsigned nqb_magic; int lg_H; float sl2; int rs2, hs2, ws2, NT, orow; float rwmul; int BH;
-  int nqb8, nvalid, pad0, pad1;
+  int N, H; unsigned spare0; int lg_H; float sl2; int rs2, hs2, ws2, NT, orow; float rwmul; int BH;
+  int spare1, nvalid; const int* tab;
 };
 static_assert(sizeof(GattnAsmArgs) == 96, "kernarg layout of gattn_asm_gen.py");
+// Work table of the global kernels, per device and (B * H, query blocks): entry wg = (b * H + h) << 10 | query block, -1 = none.
+// Workgroup wg runs on XCD wg % 8 (observed placement, speed only): the (b, h)-major item list is cut into eight equal contiguous
+// runs, XCD x walks run x - the same number of workgroups on every XCD, and the ones of an XCD that run side by side read the same
+// K / V. (12 heads x 21 query blocks of one 1022^2 DINOv2 image: 252 items = one round of 256 CUs; the arithmetic map of round 4
+// - eight (b, h) pairs per row of XCDs - ran it in two.)
+struct GattnTable { int* dev; int grid; };
+static std::map<unsigned long long, GattnTable> g_gattn_tabs;
+static const GattnTable* gattn_worklist(int BH, int nqb) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int cus, xcds;
+  psam_device_geometry(&cus, &xcds);
+  if (xcds < 1 || xcds > 64) xcds = 8;
+  const unsigned long long key = ((unsigned long long)BH << 32) | ((unsigned long long)nqb << 16) | ((unsigned long long)xcds << 8) | (unsigned)dev;
+  auto it = g_gattn_tabs.find(key);
+  if (it != g_gattn_tabs.end()) return &it->second;
+  const long long items = (long long)BH * nqb;
+  const int per = (int)((items + xcds - 1) / xcds);
+  std::vector<int> h((size_t)per * xcds, -1);
+  for (int x = 0; x < xcds; ++x) {
+    const long long i0 = items * x / xcds, i1 = items * (x + 1) / xcds;
+    for (long long i = i0; i < i1; ++i) h[(size_t)(i - i0) * xcds + x] = (int)(((i / nqb) << 10) | (i % nqb));
+  }
+  GattnTable t;
+  t.grid = per * xcds;
+  t.dev = nullptr;
+  if (hipMalloc((void**)&t.dev, h.size() * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (hipMemcpy(t.dev, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(t.dev); return nullptr; }
+  return &(g_gattn_tabs[key] = t);
+}
 // kind: 0 rel (tables from HBM), 1 fused (tables computed in the kernel), 2 norel
 static bool gattn_asm_eligible(const AttnArgs& p, int mode, int hd, int kind) {
   if (kind == 2) { if (mode != 0 || hd != 64 || p.N < 128) return false; }
@@ -1645,7 +1675,7 @@ static bool gattn_asm_eligible(const AttnArgs& p, int mode, int hd, int kind) {
   if (kind == 0 && (!p.rel_h || !p.rel_w)) return false;
   if (kind == 1 && (!p.rpack || p.N != 4096 || p.ts != 3LL * p.H * hd)) return false;   // (64 x 64 map: the 127-row tables; token-major qkv)
   const long long nqb = (p.N + 255) / 256;
-  if (p.H < 1 || p.H > 64 || (long long)p.B * p.H >= 65536 / p.H || ((long long)p.B * p.H + 7) / 8 * 8 * nqb >= (1 << 23)) return false;
+  if (p.H < 1 || p.H > 64 || (long long)p.B * p.H >= 65536 / p.H || nqb > 1023 || (long long)p.B * p.H * nqb >= (1 << 21)) return false;
   const long long lim = 0x7fffffffLL;
   return (long long)p.N * p.ts * 2 < lim && p.hs * 2 < lim && p.ws_ * 2 < lim && (long long)p.N * p.H * hd * 2 < lim;
 }
@@ -1658,18 +1688,20 @@ static int launch_gattn_asm(const AttnArgs& p, hipStream_t s, int hd, int kind) 
   const int nqb = (p.N + 255) / 256;
   a.qkv = p.qkv; a.out = p.out;
   a.rel_h = kind == 1 ? (const void*)p.rpack : (const void*)p.rel_h; a.rel_w = p.rel_w;
+  const GattnTable* tab = gattn_worklist(p.B * p.H, nqb);
+  if (!tab) return PSAM_ERR_LAUNCH;
   a.N = p.N; a.H = p.H;
-  a.nqb_magic = (unsigned)((0x100000000ull + 8ull * nqb - 1) / (8ull * nqb));     // ceil(2^32 / (8 nqb)): workgroup -> group of eight (b, h)
+  a.spare0 = 0;
   a.lg_H = (65536 + p.H - 1) / p.H;                                               // (the slot carries ceil(2^16 / H))
   a.sl2 = p.scale * 1.4426950408889634f;
   a.rs2 = (int)(p.ts * 2); a.hs2 = (int)(p.hs * 2); a.ws2 = (int)(p.ws_ * 2);
   a.NT = (p.N + 63) / 64; a.orow = p.H * hd * 2;
   a.rwmul = 1.0f / p.scale;      // rel_w is staged as rel_w / scale: it enters the score MFMAs as their accumulator input
   a.BH = p.B * p.H;              // workgroups of the groups beyond it (the grid is rounded up to eight (b, h) per row of XCDs) leave at once
-  a.nqb8 = 8 * nqb; a.nvalid = p.N - (a.NT - 1) * 64; a.pad0 = a.pad1 = 0;
+  a.spare1 = 0; a.nvalid = p.N - (a.NT - 1) * 64; a.tab = tab->dev;
   size_t sz = sizeof(a);
   void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  const int grid = ((p.B * p.H + 7) / 8 * 8) * nqb;
+  const int grid = tab->grid;
   if (hipModuleLaunchKernel(f, grid, 1, 1, 256, 1, 1, 0, s, nullptr, extra) != hipSuccess) {
     (void)hipGetLastError();
     return PSAM_ERR_LAUNCH;
