@@ -595,6 +595,225 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Tile 12 (round 5): the 128x128x64 kernel above for launches with AT MOST ONE workgroup per CU (one DINOv2 slice: 1297 x 768
+// is 66 tiles; one SAM ViT-B image: 4096 x 768 is 192): a ring of four K-tile buffers (128 KiB of LDS), the DMA three K-tiles
+// ahead, counted waits. With two buffers a lone workgroup pays one L2 / HBM round trip per K-tile (the next tile is requested
+// when the current one is consumed, 16 MFMAs = ~0.25 us later it is awaited: 1297x768x3072 ran 48 K-tiles in 37 us = 0.75 us
+// each; two co-resident workgroups hide that for each other, a lone one cannot). Same MFMAs, same k order, same epilogue code:
+// results are bit-identical to tile 1 (tests/test_kernels_core_gpu.py test_gemm_deep_ring).
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f16_deep_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) half_t ring[];      // [4 buffers][A | W][128 * 64]
+  constexpr int NB = 4, TILE = BM * BK;
+  const int ntn = p.N / BN;
+  const int ntm = (p.M + BM - 1) / BM;
+  int tm, tn;
+  if (!tile_map(blockIdx.x, ntm, ntn, p.map_mode, tm, tn)) return;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wv >> 1, wn = wv & 1;
+  const int lr = lane & 31, lg = lane >> 5;
+  const half_t* ag[4];
+  const half_t* wg[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (wv * 4 + j) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    int am = m0 + row;
+    am = am < p.M ? am : p.M - 1;
+    ag[j] = p.A + (size_t)am * p.lda + chunk * 8;
+    wg[j] = p.W + (size_t)(n0 + row) * p.ldw + chunk * 8;
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  auto stage = [&](int kt) {      // eight 1-KiB pieces per wave
+    half_t* b = ring + (size_t)(kt & (NB - 1)) * 2 * TILE;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      glds16(ag[j] + kt * BK, b + (wv * 4 + j) * 8 * BK);
+      glds16(wg[j] + kt * BK, b + TILE + (wv * 4 + j) * 8 * BK);
+    }
+  };
+  const int nk = p.K / BK;
+  // residual rows first (EPI_F32): older than every DMA, so every counted wait below covers them
+  float4 rpre[16];
+  const bool has_res = (EPI == EPI_F32) && p.resid != nullptr;
+  if (EPI == EPI_F32 && has_res) prefetch_resid(p, m0 + wm * 64, n0 + wn * 64, lane, rpre);
+  stage(0);
+  if (nk > 1) stage(1);
+  if (nk > 2) stage(2);
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt has landed for this wave (the stages of tiles kt + 1, kt + 2 may stay in flight), then for all of them; the same
+    // barrier says every wave is done reading tile kt - 1, whose buffer the next stage overwrites
+    const int rem = nk - 1 - kt;
+    if (rem >= 2) wait_vmcnt<16>(); else if (rem == 1) wait_vmcnt<8>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + 3 < nk) stage(kt + 3);
+    const half_t* sa = ring + (size_t)(kt & (NB - 1)) * 2 * TILE;
+    const half_t* sw = sa + TILE;
+    // one wave per SIMD: nothing else hides the LDS latency, so the fragments of k-step s + 1 are requested before the MFMAs of
+    // k-step s (two register sets; the compiler's own order was read - wait - multiply, 4 x (LDS latency + 128 cycles) per K-tile)
+    half8_t fa[2][2], fb[2][2];
+#define PSAM_DEEP_RD(set, s_)                                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                                    \
+        fa[set][i] = *reinterpret_cast<const half8_t*>(&sa[lds_off(wm * 64 + i * 32 + lr, (s_) * 2 + lg)]);                          \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                                    \
+        fb[set][j] = *reinterpret_cast<const half8_t*>(&sw[lds_off(wn * 64 + j * 32 + lr, (s_) * 2 + lg)]);
+    PSAM_DEEP_RD(0, 0)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (s < 3) { PSAM_DEEP_RD((s + 1) & 1, s + 1) }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[s & 1][j], fa[s & 1][i], acc[i][j], 0, 0, 0);  // D^T
+    }
+#undef PSAM_DEEP_RD
+  }
+  __syncthreads();   // every wave is done with the ring: the epilogue parks its slabs in it
+  float* slab = reinterpret_cast<float*>(ring) + wv * 4096;
+  if (EPI == EPI_F32 && has_res)
+    store_slab_staged<EPI, true, false>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], slab, m0 + wm * 64, n0 + wn * 64, lane, p, rpre);
+  else if ((EPI == EPI_F16 || EPI == EPI_GELU_F16) && p.wide16) {
+    half_t* slab16 = reinterpret_cast<half_t*>(slab);
+    slab_park16<EPI, false>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], slab16, n0 + wn * 64, lane, p, m0 + wm * 64);
+    slab_emit16(slab16, m0 + wm * 64, n0 + wn * 64, lane, p);
+  } else
+    store_slab_staged<EPI, false, false>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], slab, m0 + wm * 64, n0 + wn * 64, lane, p);
+}
+// ---------------------------------------------------------------------------------------------------------------------
+// Tile 13 (round 5): 64x64x64 tiles for launches whose 128x128 tiles would leave most CUs idle (one DINOv2 slice through proj /
+// fc2: 1297 x 768 is 66 tiles of 128x128 but 252 of 64x64). What bounds such a launch is not the MFMA rate but what ONE CU can keep
+// in flight towards the L2 (~60 GB/s per CU measured on 1297x768x3072: 48 K-tiles of 32 KiB took 0.54 us each on the deep-ring
+// 128-tile kernel whatever the prefetch depth): spreading the same bytes over four times as many CUs is what the library does
+// there (19 us against our 37). Four waves (2 x 2), one 32x32x16 accumulator each, a ring of four 16-KiB K-tile buffers (two
+// workgroups per CU), DMA three K-tiles ahead with counted waits; bias / LayerScale / residual operands requested before the
+// k-loop; direct 8-/16-byte stores from the accumulator layout (rows of 32 bytes: fine for outputs this small).
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_f16_s64_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) half_t ring[];      // [4 buffers][A | W][64 * 64]
+  constexpr int NB = 4, TILE = 64 * BK;
+  const int ntn = p.N / 64;
+  const int ntm = (p.M + 63) / 64;
+  int tm, tn;
+  if (!tile_map(blockIdx.x, ntm, ntn, p.map_mode, tm, tn)) return;
+  const int m0 = tm * 64, n0 = tn * 64;
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wv >> 1, wn = wv & 1;
+  const int lr = lane & 31, lg = lane >> 5;
+  const half_t* ag[2];
+  const half_t* wg[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = (wv * 2 + j) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    int am = m0 + row;
+    am = am < p.M ? am : p.M - 1;
+    ag[j] = p.A + (size_t)am * p.lda + chunk * 8;
+    wg[j] = p.W + (size_t)(n0 + row) * p.ldw + chunk * 8;
+  }
+  auto stage = [&](int kt) {      // four 1-KiB pieces per wave
+    half_t* b = ring + (size_t)(kt & (NB - 1)) * 2 * TILE;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      glds16(ag[j] + kt * BK, b + (wv * 2 + j) * 8 * BK);
+      glds16(wg[j] + kt * BK, b + TILE + (wv * 2 + j) * 8 * BK);
+    }
+  };
+  // epilogue operands of this lane (row m, columns nb + 8 q + 0..3), requested before the first DMA: older than every counted wait
+  const int m = m0 + wm * 32 + lr, nb = n0 + wn * 32 + 4 * lg;
+  const bool mval = m < p.M;
+  const size_t rrow = p.resid_mod ? (size_t)((mval ? m : 0) % p.resid_mod) : (size_t)(mval ? m : 0);
+  float4 bv[4], gv[4], rv[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    bv[q] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nb + 8 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (EPI == EPI_F32) {
+      gv[q] = p.gamma ? *reinterpret_cast<const float4*>(p.gamma + nb + 8 * q) : make_float4(1.f, 1.f, 1.f, 1.f);
+      rv[q] = p.resid ? *reinterpret_cast<const float4*>(p.resid + rrow * p.ldr + nb + 8 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  asm volatile("" ::: "memory");
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int nk = p.K / BK;
+  stage(0);
+  if (nk > 1) stage(1);
+  if (nk > 2) stage(2);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int rem = nk - 1 - kt;
+    if (rem >= 2) wait_vmcnt<8>(); else if (rem == 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + 3 < nk) stage(kt + 3);
+    const half_t* sa = ring + (size_t)(kt & (NB - 1)) * 2 * TILE;
+    const half_t* sw = sa + TILE;
+    half8_t fa[4], fb[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      fa[s] = *reinterpret_cast<const half8_t*>(&sa[lds_off(wm * 32 + lr, s * 2 + lg)]);
+      fb[s] = *reinterpret_cast<const half8_t*>(&sw[lds_off(wn * 32 + lr, s * 2 + lg)]);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[s], fa[s], acc, 0, 0, 0);  // D^T
+  }
+  if (!mval) return;
+  const size_t orow = p.out_seg ? (size_t)(m / p.out_seg) * p.out_seg_stride + p.out_seg_off + (m % p.out_seg) : (size_t)m;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int n = nb + 8 * q;
+    float4 v = make_float4(acc[4 * q] + bv[q].x, acc[4 * q + 1] + bv[q].y, acc[4 * q + 2] + bv[q].z, acc[4 * q + 3] + bv[q].w);
+    if (EPI == EPI_F16) {
+      half4_t h = {(half_t)v.x, (half_t)v.y, (half_t)v.z, (half_t)v.w};
+      *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(p.out) + orow * p.ldo + n) = h;
+    } else if (EPI == EPI_GELU_F16) {
+      half4_t h = {(half_t)gelu_erf(v.x), (half_t)gelu_erf(v.y), (half_t)gelu_erf(v.z), (half_t)gelu_erf(v.w)};
+      *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(p.out) + orow * p.ldo + n) = h;
+    } else {
+      if (p.gamma) { v.x *= gv[q].x; v.y *= gv[q].y; v.z *= gv[q].z; v.w *= gv[q].w; }
+      if (p.resid) { v.x += rv[q].x; v.y += rv[q].y; v.z += rv[q].z; v.w += rv[q].w; }
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + orow * p.ldo + n) = v;
+    }
+  }
+}
+template <int EPI>
+static void launch_s64(const GemmArgs& p, hipStream_t s) {
+  constexpr int LDS = 4 * 2 * 64 * BK * 2;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm_f16_s64_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr = true;
+  }
+  const int ntm = (p.M + 63) / 64, ntn = p.N / 64;
+  hipLaunchKernelGGL((gemm_f16_s64_kernel<EPI>), dim3(tile_map_grid(ntm, ntn, p.map_mode)), dim3(256), LDS, s, p);
+}
+
+template <int EPI>
+static void launch_deep(const GemmArgs& p, dim3 grid, hipStream_t s) {
+  constexpr int LDS = 4 * 2 * BM * BK * 2;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm_f16_deep_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr = true;
+  }
+  hipLaunchKernelGGL((gemm_f16_deep_kernel<EPI>), grid, dim3(256), LDS, s, p);
+}
+
 
 // =====================================================================================================
 // 256 x 256 x 64, 8 waves (2 x 4, wave tile 128 x 64), "8-phase" schedule (tile 7).
@@ -1275,10 +1494,10 @@ static int launch_asm(const GemmArgs& p, int epilogue, hipStream_t s, int family
 // HIP schedules of rounds 1 / 2 (tiles 2 ... 10, 13, 14) lost to these and are gone (history: DESIGN.md).
 // (PSAM_GEMM_TILE env var or psam_gemm_set_tile)
 // dispatch switches (A/B and tests): initial values from the environment, psam_gemm_set_option overrides at run time
-enum { OPT_ASM = 0, OPT_HALF, OPT_SPLITK, OPT_NSPLIT, OPT_COUNT };
-static const char* const g_opt_names[OPT_COUNT] = {"asm", "half_tiles", "splitk", "nsplit"};
-static const char* const g_opt_env[OPT_COUNT] = {"PSAM_GEMM_ASM", "PSAM_GEMM_HALF", "PSAM_GEMM_SPLITK", "PSAM_GEMM_NSPLIT"};
-static int g_opt[OPT_COUNT] = {-1, -1, -1, -1};
+enum { OPT_ASM = 0, OPT_HALF, OPT_SPLITK, OPT_NSPLIT, OPT_DEEP, OPT_SMALL, OPT_COUNT };
+static const char* const g_opt_names[OPT_COUNT] = {"asm", "half_tiles", "splitk", "nsplit", "deep", "small"};
+static const char* const g_opt_env[OPT_COUNT] = {"PSAM_GEMM_ASM", "PSAM_GEMM_HALF", "PSAM_GEMM_SPLITK", "PSAM_GEMM_NSPLIT", "PSAM_GEMM_DEEP", "PSAM_GEMM_SMALL"};
+static int g_opt[OPT_COUNT] = {-1, -1, -1, -1, -1, -1};
 static int gemm_option(int i) {
   if (g_opt[i] < 0) { const char* e = getenv(g_opt_env[i]); g_opt[i] = e ? (atoi(e) != 0) : 1; }
   return g_opt[i];
@@ -1382,7 +1601,7 @@ static int gemm_dispatch(const void* A, const void* W, const float* bias, void* 
   // the assembly kernels (tile 15) take plain row-major operands; everything else they were picked for goes to the persistent HIP kernel
   if (tsel == 16 && !asm2_eligible(p, epilogue, ln_prod || ln_cons)) tsel = (g_tile_override > 0 || ln_prod || ln_cons) ? 15 : 1;
   if (tsel == 15 && !asm_eligible(p, epilogue, ln_prod || ln_cons)) tsel = (N % 256 == 0) ? 11 : 1;
-  if (tsel != 1 && tsel != 11 && tsel != 15 && tsel != 16) tsel = (N % 256 == 0) ? 11 : 1;   // (tiles 2 ... 14 of rounds 1 / 2 are gone)
+  if (tsel != 1 && tsel != 11 && tsel != 12 && tsel != 13 && tsel != 15 && tsel != 16) tsel = (N % 256 == 0) ? 11 : 1;   // (tiles 2 ... 14 of rounds 1 / 2 are gone)
   if (tsel == 11 && (N % 256) != 0) tsel = 1;
   if (tsel == 11 && epilogue != EPI_F32 && !p.wide16) tsel = 1;   // the persistent kernel stores fp16 rows with 16-byte instructions
   if (ln_cons && !p.wide16) return PSAM_ERR_ARG;                  // (the folded-LayerNorm epilogues live in tiles 1 and 11)
@@ -1429,6 +1648,30 @@ static int gemm_dispatch(const void* A, const void* W, const float* bias, void* 
     }
   }
   const bool lnf = ln_prod || ln_cons;
+  // tile 13: 64x64 tiles where the 128x128 tiles would leave more than half of the CUs idle (gemm_f16_s64_kernel); psam_gemm_set_option("small", 0)
+  // / PSAM_GEMM_SMALL=0 keeps the larger tiles; psam_gemm_set_tile(13) forces it
+  if ((tsel == 13 || (tsel == 1 && g_tile_override <= 0 && gemm_option(OPT_SMALL) && (int)grid.x * 2 <= num_cus())) && !lnf && K >= 64 &&
+      epilogue != EPI_RELU_F16 && (epilogue == EPI_F32 || (ldo % 4) == 0)) {
+    switch (epilogue) {
+      case EPI_F16: launch_s64<EPI_F16>(p, s); break;
+      case EPI_GELU_F16: launch_s64<EPI_GELU_F16>(p, s); break;
+      default: launch_s64<EPI_F32>(p, s); break;
+    }
+    return psam_launch_status();
+  }
+  if (tsel == 13) tsel = 1;
+  // tile 12: the 128x128 kernel with a four-deep K-tile ring where a launch leaves at most one workgroup per CU (gemm_f16_deep_kernel;
+  // bit-identical to tile 1). PSAM_GEMM_DEEP=0 / psam_gemm_set_option("deep", 0) keeps tile 1; psam_gemm_set_tile(12) forces it.
+  if ((tsel == 12 || (tsel == 1 && g_tile_override <= 0 && gemm_option(OPT_DEEP) && (int)grid.x <= num_cus())) && !lnf && K >= 256 &&
+      epilogue != EPI_RELU_F16) {
+    switch (epilogue) {
+      case EPI_F16: launch_deep<EPI_F16>(p, grid, s); break;
+      case EPI_GELU_F16: launch_deep<EPI_GELU_F16>(p, grid, s); break;
+      default: launch_deep<EPI_F32>(p, grid, s); break;
+    }
+    return psam_launch_status();
+  }
+  if (tsel == 12) tsel = 1;
   if (tsel == 11) {
     if (lnf) {   // separate instantiations: the plain kernels stay as they were
       if (epilogue == EPI_F16) launch8kp<EPI_F16, true>(p, s);

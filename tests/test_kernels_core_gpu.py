@@ -67,6 +67,40 @@ def test_gemm_large_tiles(dev, tile, M, N, K, epi):
         ops.gemm_set_tile(0)
 
 
+@pytest.mark.parametrize("M,N,K", [(1297, 768, 768), (1297, 768, 3072), (1297, 2304, 768), (1297, 3072, 768), (4096, 768, 3072), (4096, 256, 2304),
+                                   (130, 128, 256), (5330, 768, 64), (5330, 768, 128), (300, 256, 192)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_deep_ring(dev, M, N, K, epi):
+    """Tiles 12 and 13 (round 5). Tile 12 ( the 128x128 kernel with a four-deep K-tile ring and counted waits, taken automatically where a launch leaves
+    at most one workgroup per CU - one DINOv2 slice, one SAM ViT-B image) is BIT-IDENTICAL to tile 1 (same MFMAs, k order and epilogue
+    code) and right against the fp32 arithmetic: K of 1 ... 48 K-tiles (the ring's fill and drain paths), ragged M, in-place residual."""
+    from protosam_amd import ops
+    a = _rand((M, K), dev, 1.0, 61).half()
+    w = _rand((N, K), dev, 0.05, 62).half()
+    bias = _rand((N,), dev, 0.5, 63)
+    gamma = _rand((N,), dev, 1.0, 65)
+    ref = a.float() @ w.float().t() + bias
+    outs = []
+    for tile in (12, 1, 0, 13):
+        ops.gemm_set_tile(tile)
+        try:
+            if epi == 2:
+                x = _rand((M, N), dev, 1.0, 64)
+                outs.append(ops.gemm(a, w, bias, out=x, epilogue=ops.EPI_F32, resid=x, gamma=gamma))     # x += gamma * (a w^T + b)
+            else:
+                outs.append(ops.gemm(a, w, bias, epilogue=epi))
+        finally:
+            ops.gemm_set_tile(0)
+    assert torch.equal(outs[0], outs[1])
+    if epi == 2:
+        torch.testing.assert_close(outs[0], _rand((M, N), dev, 1.0, 64) + gamma * ref, rtol=1e-4, atol=2e-4)
+    else:
+        torch.testing.assert_close(outs[0].float(), ref if epi == 0 else torch.nn.functional.gelu(ref), rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(outs[2].float(), outs[0].float(), rtol=2e-3, atol=2e-3)      # (auto may pick another family)
+    # tile 13 (64x64 tiles for launches that would leave most CUs idle): same k order, its own epilogue code
+    torch.testing.assert_close(outs[3].float(), outs[0].float(), rtol=1e-3 if epi != 2 else 1e-5, atol=1e-3 if epi != 2 else 1e-5)
+
+
 @pytest.mark.parametrize("M,N,K", [(20000, 1536, 128), (70001, 768, 64), (33000, 2304, 192)])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_gemm_persistent_tile_walks_many_tiles(dev, M, N, K, epi):

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 from protosam_amd import ops
 dev = torch.device("cuda:0")
-tiles = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "0,1,15,16").split(",")]
+tiles = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "0,1,12,15,16").split(",")]
 
 
 def timeit(fn, n=20):
