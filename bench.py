@@ -57,8 +57,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the per-slice / no-cache / stage / HBM-roofline legs")
     ap.add_argument("--cpu-slices", type=int, default=3, help="slices of the CPU baseline at all cores")
-    ap.add_argument("--cpu-1thread-slices", type=int, default=0, help="slices of the CPU baseline at 1 thread, as the reference "
-                    "runs (validation_protosam.py:299: one slice takes about a minute); 0 (default) skips it")
+    ap.add_argument("--cpu-1thread-slices", type=int, default=1, help="slices of the CPU baseline at 1 thread, as the reference "
+                    "runs (validation_protosam.py:299: one slice takes about a minute); 0 skips it")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak: --batch slices per rank per step; strong: "
                     "a step is ONE pass over the --slices volume, rank r takes z = r (mod world) (SURVEY 8e), one all-gather per step")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the BASELINE configs 2 / 3 / 5 legs of the default run")
@@ -302,6 +302,19 @@ def main():
                 "sustained_mfma_only": {"value": SUSTAINED_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / SUSTAINED_F16_TFLOPS, 4),
                                         "note": "register-only MFMA loop, random fp16 operands, 256 CUs: power-capped at 1.61 GHz "
                                                 "(profiles/r04_mfma_power_limit.txt); `peak` is the nominal 2.39 GHz figure"}}
+    # the GEMM launches of the timed steps by shape: the four Linear layers of a SAM block as the pipeline runs them (bias / GELU /
+    # residual + LayerNorm epilogues included), each against the MFMA peak AND against HBM on its algorithmic bytes - the proj shape
+    # (K = N = 1280 with an fp32 residual: 210 FLOP per byte, below the machine balance of 2500 / 8 = 312) is bound by bytes, not by MFMAs
+    by_shape = []
+    for (Mg, Ng, Kg, epi, folded), (cnt, secs, flops) in sorted(timer.by_tag().items(), key=lambda kv: -kv[1][1])[:8]:
+        byts = 2.0 * Mg * Kg + 2.0 * Ng * Kg + (8.0 * Mg * Ng + (2.0 * Mg * Ng + 8.0 * Mg * (Ng // 64) if folded else 0.0) if epi == 2 else 2.0 * Mg * Ng)
+        by_shape.append({"M": Mg, "N": Ng, "K": Kg, "epilogue": ["fp16", "gelu fp16", "fp32 residual", "relu fp16"][epi] + (" + folded LayerNorm" if folded else ""),
+                         "launches": cnt, "avg_us": round(secs / cnt * 1e6, 1), "share_of_step": round(secs / elapsed, 4),
+                         "tflops": round(flops / secs / 1e12, 1), "mfma_frac": round(flops / secs / 1e12 / PEAK_F16_TFLOPS, 4),
+                         "algorithmic_gb_per_launch": round(byts / 1e9, 3), "hbm_gbs": round(byts * cnt / secs / 1e9, 1),
+                         "hbm_frac": round(byts * cnt / secs / 1e9 / PEAK_HBM_GBS, 4),
+                         "bound": "hbm" if flops / cnt / byts < PEAK_F16_TFLOPS * 1e3 / PEAK_HBM_GBS else "mfma"})
+    roofline["by_shape"] = by_shape
     res = {
         "metric": "query-slices/sec (512x512) end-to-end ProtoSAM infer",
         "value": round(value, 3), "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -372,15 +385,25 @@ def extras(args, model, step, ops, psmod, B, torch, dev):
         hbm.append(e)
     ops.TIMERS.clear()
     out["roofline_hbm"] = hbm
-    # (a2) the library's default stream mode: SAM image encoder on a second stream beside DINOv2 + ALP + connected components
+    # (a2) the library's default stream mode: SAM image encoder on a second stream beside DINOv2 + ALP + connected components.
+    #      Interleaved A/B against the single-stream mode in this process: five blocks of two steps each way (round 4 compared a
+    #      3-step sample with the headline of another minute of the run: 143 vs 150 on the driver's box, 149 vs 147 the round before)
+    import numpy as np
     model.overlap_streams = "auto"
     timed(4)                                                     # ("auto" overlaps after four dense batched calls)
-    dt = timed(3)
+    ab = {"auto": [], "0": []}
+    for blk in range(5):
+        for mode in ("auto", "0"):
+            model.overlap_streams = mode
+            ab[mode].append(2 * B / timed(2))
     model.overlap_streams = "0"
-    out["overlap_streams_auto"] = {"value": round(3 * B / dt, 2), "unit": "slices/s",
+    out["overlap_streams_auto"] = {"value": round(float(np.mean(ab["auto"])), 2), "unit": "slices/s", "std": round(float(np.std(ab["auto"])), 2),
+                                   "single_stream_same_minute": round(float(np.mean(ab["0"])), 2), "single_stream_std": round(float(np.std(ab["0"])), 2),
+                                   "steps_each": 10,
                                    "note": "headline configuration with PSAM_OVERLAP_STREAMS=auto (the library default): the SAM image "
-                                           "encoder runs on a second HIP stream beside the coarse model; per-kernel event timing is "
-                                           "blurred by the concurrency, so the headline and its roofline are measured without it"}
+                                           "encoder runs on a second HIP stream beside the coarse model; five interleaved blocks of two "
+                                           "steps per mode; per-kernel event timing is blurred by the concurrency, so the headline and "
+                                           "its roofline are measured without it"}
     # (b) the reference-shaped call pattern: one ProtoSAM.forward per slice (validation_protosam.py:387)
     model.overlap_streams = "auto"                                # (the library default; no per-kernel timing in this leg)
     timed(1, micro=1)

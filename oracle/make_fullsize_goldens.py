@@ -106,6 +106,28 @@ def ambiguous_pixels(lows, size):
     return np.array([int((near <= t).sum()) for t in AMB_TOL], dtype=np.int32)
 
 
+TIE_TOL = 1e-3
+
+
+def prompt_record(taps):
+    """The oracle's DISCRETE decisions of a slice, so that a test can tell a tolerance-sized logit difference from a different
+    prompt: float32 [components, 8] = most confident point (x, y), centroid (x, y), box (x0, y0, x1, y1) in the 1024^2 frame
+    (ProtoSAM.py:242-289, 349-450), and the packed 1024 x 1024 mask of every pixel whose foreground probability lies within 1e-3
+    of its component's maximum: an implementation whose coarse probabilities are within the north-star 1e-3 may pick ANY of those as
+    the most confident point (torch.topk over near-ties; softmax saturating to 1.0 inside a confident region makes them many)."""
+    pts, boxes = np.asarray(taps["points"], dtype=np.float32), np.asarray(taps["bboxes"], dtype=np.float32)
+    rec = np.concatenate([pts.reshape(len(pts), -1)[:, :4], boxes.reshape(len(boxes), 4)], axis=1).astype(np.float32)
+    fg = taps["output_p"][0, 1].numpy()
+    labels = taps["cc"][1]
+    tie = np.zeros(fg.shape, dtype=bool)
+    for cid in np.unique(labels):
+        if cid == 0:
+            continue
+        comp = labels == cid
+        tie |= comp & (fg >= fg[comp].max() - TIE_TOL)
+    return rec, np.packbits(tie)
+
+
 def volume_record_name(cfg, wseed=1234, vseed=0):
     return f"fullvolume_cfg{cfg}.npz" if (wseed, vseed) == (1234, 0) else f"fullvolume_cfg{cfg}_w{wseed}_v{vseed}.npz"
 
@@ -155,6 +177,7 @@ def make_whole_volume(cfg, wseed=1234, vseed=0, stride=1):
         if taps.get("low_res"):
             out[f"z{z}_prob4"] = prob16(torch.stack([l[0] for l in taps["low_res"]]))[..., ::4, ::4].copy()
             out[f"z{z}_amb"] = ambiguous_pixels([l[0] for l in taps["low_res"]], 512)
+            out[f"z{z}_prompts"], out[f"z{z}_tie"] = prompt_record(taps)
         print(f"config {cfg} z={z}: {len(scores)} component(s), fg {int(pred.sum())} px, {time.time() - t0:.0f}s "
               f"(total {time.time() - t_all:.0f}s)", flush=True)
         if (z // stride) % 8 == 7 or z == zs[-1]:      # (checkpoint: a long run)

@@ -356,6 +356,35 @@ extern "C" int psam_cast_f16(const float* x, void* y, long long n, void* stream)
   return psam_launch_status();
 }
 
+// fp32 -> (hi, lo) fp16 pair: hi = half(x) (written when `hi_out`, else read: the folded-LayerNorm GEMM already wrote it), lo = half(x -
+// float(hi)). A GEMM on [hi | lo] against [W_hi | W_lo] (three products: hi W_hi + lo W_hi + hi W_lo) then carries ~22 mantissa bits of
+// both operands: used for the neck of the SAM image encoder, whose fp16-operand GEMMs alone were 4.0e-4 of the 6.4e-4 embedding error
+// (image_encoder.py:90-106).
+__global__ void split_f16_kernel(const float* __restrict__ x, half_t* __restrict__ hi, half_t* __restrict__ lo, int write_hi, size_t n8) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const float4 a = reinterpret_cast<const float4*>(x)[2 * i], b = reinterpret_cast<const float4*>(x)[2 * i + 1];
+  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  half8_t h, l;
+  if (write_hi) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) h[e] = (half_t)v[e];
+    reinterpret_cast<half8_t*>(hi)[i] = h;
+  } else {
+    h = reinterpret_cast<const half8_t*>(hi)[i];
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) l[e] = (half_t)(v[e] - (float)h[e]);
+  reinterpret_cast<half8_t*>(lo)[i] = l;
+}
+extern "C" int psam_split_f16(const float* x, void* hi, void* lo, long long n, int write_hi, void* stream) {
+  if (n <= 0 || (n & 7) || !x || !hi || !lo) return PSAM_ERR_ARG;
+  size_t n8 = (size_t)n / 8;
+  hipLaunchKernelGGL(split_f16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (half_t*)hi,
+                     (half_t*)lo, write_hi, n8);
+  return psam_launch_status();
+}
+
 // Sam.preprocess normalisation (modeling/sam.py:163-168): y[b,c,:,:] = (x[b,c,:,:] - mean[c]) / std[c].
 // in_u8 = 1: x is uint8 (the predictor's image tensor, predictor.py:57-58), else fp32. 3 channels.
 __global__ void normalize_chw_kernel(const void* __restrict__ x, int in_u8, size_t plane, float m0, float m1, float m2,

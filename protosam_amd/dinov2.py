@@ -104,7 +104,7 @@ class DinoVisionTransformer(nn.Module):
         # consumers' 3.8 ms; it also lowers the embedding error). Round 2 measured the opposite on the HIP kernels (122.2 vs 124.3:
         # +10 ms of epilogue). PSAM_FOLD_LN=0 / `fold_ln = False` selects the separate passes.
         self.fold_ln = os.environ.get("PSAM_FOLD_LN", "1") != "0"
-        self.fold_min_fill = 0.8      # ... where the launches fill the CUs (ops.fold_pays); 0 = always
+        self.fold_min_fill = float(os.environ.get("PSAM_FOLD_MIN_FILL", "0.8"))      # ... where the launches fill the CUs (ops.fold_pays); 0 = always
 
     # -- weight packing (fp16 GEMM operands); rebuilt whenever parameters change -----------------------------
     def _apply(self, fn, *a, **k):

@@ -25,16 +25,28 @@ class KernelTimer:
 
     def __init__(self):
         self.records = []  # (start_event, end_event, work)
+        self.tags = {}     # record index -> tag
 
     def start(self):
         e = torch.cuda.Event(enable_timing=True)
         e.record()
         return e
 
-    def stop(self, e0, work):
+    def stop(self, e0, work, tag=None):
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
         self.records.append((e0, e1, work))
+        if tag is not None:
+            self.tags[len(self.records) - 1] = tag
+
+    def by_tag(self):
+        """{tag: (launches, seconds, work)} over the tagged records (the GEMM timer tags a launch with (M, N, K, epilogue, folded))."""
+        out = {}
+        for i, tag in self.tags.items():
+            a, b, w = self.records[i]
+            n, t, f = out.get(tag, (0, 0.0, 0.0))
+            out[tag] = (n + 1, t + a.elapsed_time(b) * 1e-3, f + float(w[0] if isinstance(w, tuple) else w))
+        return out
 
     def summary(self):
         """(n_launches, total_seconds, total_work) -- call after a device synchronize. `work` may be a tuple (bytes, flops):
@@ -141,7 +153,7 @@ def gemm(a, w, bias=None, out=None, epilogue=EPI_F16, resid=None, gamma=None, re
                                      a2.stride(0), w.stride(0), out2.stride(0), ldr, resid_mod, out_seg,
                                      out_seg_stride, out_seg_off, epilogue, _stream())
     if t0 is not None:
-        GEMM_TIMER.stop(t0, 2.0 * M * N * K)
+        GEMM_TIMER.stop(t0, 2.0 * M * N * K, tag=(M, N, K, epilogue, 1 if fold else 0))
     _lib.check(st, "psam_gemm_f16_ln" if fold else "psam_gemm_f16")
     return out
 
@@ -601,6 +613,28 @@ def cast_f16(x, out=None):
     st = _lib.lib().psam_cast_f16(_ptr(x), _ptr(out), x.numel(), _stream())
     _lib.check(st, "psam_cast_f16")
     return out
+
+
+def split_f16(x, hi=None, lo=None, write_hi=True):
+    """fp32 x -> (hi = half(x), lo = half(x - hi)); write_hi=False: `hi` already holds half(x) (a folded-LayerNorm GEMM wrote it)."""
+    _req(x, torch.float32, "x")
+    assert x.is_contiguous()
+    if hi is None:
+        assert write_hi
+        hi = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    if lo is None:
+        lo = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    _req(hi, torch.float16, "hi"); _req(lo, torch.float16, "lo")
+    st = _lib.lib().psam_split_f16(_ptr(x), _ptr(hi), _ptr(lo), x.numel(), 1 if write_hi else 0, _stream())
+    _lib.check(st, "psam_split_f16")
+    return hi, lo
+
+
+def split_weight_f16(w):
+    """fp32 weight -> (hi, lo) fp16 pair (one-time packing)."""
+    w = w.detach().float()
+    hi = w.half()
+    return hi.contiguous(), (w - hi.float()).half().contiguous()
 
 
 # ---- SAM prompt encoder / mask decoder -----------------------------------------------------------------------

@@ -422,8 +422,14 @@ class ProtoSAM(nn.Module):
             q = ops.bilinear_nchw(q, S, S, out=bufs["q1024"][:B])
         mm, patches = bufs["mm"][:2 * B], bufs["patches"][:B * 4096]       # B may be a sub-batch (non-empty slices only)
         ops.minmax(q, B, mm=mm)
-        ops.sam_patchify(q, mm, S, sam.image_encoder.patch_size, sam._mean_host, sam._std_host, True, out=patches)
-        return sam.image_encoder.encode_patches(patches, B)
+        enc = sam.image_encoder
+        if getattr(enc, "split_fp16", False):
+            # the quantised pixel values themselves (0 ... 255 are exact in fp16); Sam.preprocess' (x - mean) / std lives in the patch-
+            # embedding weights (ImageEncoderViT._patch_raw): no fp16 rounding of the normalised pixels
+            ops.sam_patchify(q, mm, S, enc.patch_size, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), True, out=patches)
+            return enc.encode_patches(patches, B, raw_norm=(tuple(sam._mean_host), tuple(sam._std_host)))
+        ops.sam_patchify(q, mm, S, enc.patch_size, sam._mean_host, sam._std_host, True, out=patches)
+        return enc.encode_patches(patches, B)
 
     def forward(self, query_image, coarse_model_input, degrees_rotate=0):
         """Reference contract (ProtoSAM.py:536-678): one query slice [1,3,H,W] -> (pred [H,W] float {0,1}, scores)."""
@@ -465,6 +471,8 @@ class ProtoSAM(nn.Module):
         B = query_images.shape[0]
         original_size = query_images.shape[-2]
         dev = query_images.device
+        if self.coarse_pred_only:                                               # ProtoSAM.py:580-590: nothing of SAM runs
+            return self._coarse_only_batch(self._coarse_logits(query_images, coarse_model_input, degrees_rotate), original_size)
         bufs = self._work_buffers(dev, B)
         sam = self.sam
         S = sam.image_encoder.img_size
@@ -659,6 +667,44 @@ class ProtoSAM(nn.Module):
             else:
                 self.last_stats.update(low_res=masks, iou=iou, sel=sel, spans=spans)
         return results
+
+    def _coarse_only_batch(self, output_logits, original_size):
+        """`_coarse_only` for B slices at once: one softmax / argmax launch, one connected-components chain, one copy of the
+        component tables to the host (round 5: forward_batch used to run SAM and drop its result when `coarse_pred_only` was set)."""
+        B = output_logits.shape[0]
+        if B == 1:
+            return [self._coarse_only(output_logits, original_size)]
+        dev = output_logits.device
+        H = int(original_size)
+        key = (str(dev), H, B)
+        cache = self.__dict__.setdefault("_coarse_bufs", {})
+        if key not in cache:
+            cache[key] = dict(fg_sum=torch.zeros(B, dtype=torch.int32, device=dev),
+                              prob=torch.empty((B, 2, H, H), dtype=torch.float32, device=dev),
+                              pred=torch.empty((B, H, H), dtype=torch.uint8, device=dev),
+                              ccl=ops.CclWorkspace(H, H, MAX_COMPONENTS, dev, slots=B))
+        bufs = cache[key]
+        bufs["fg_sum"].zero_()
+        prob, pred = ops.prob_argmax(output_logits.float().contiguous(), H, H, prob=bufs["prob"], pred=bufs["pred"],
+                                     fg_sum=bufs["fg_sum"])
+        cw = ops.ccl_batch(pred, prob, bufs["ccl"], fg_sum=bufs["fg_sum"])
+        tabs = cw.tabs[:B].cpu().numpy()
+        out = []
+        for b in range(B):
+            tab = tabs[b]
+            if int(tab[0]) > int(tab[1]):                        # more components than the fast table holds: the one-slice path's large table
+                out.append(self._coarse_only(output_logits[b:b + 1], original_size))
+                continue
+            n = int(tab[1])
+            rows = tab[ops.CC_HDR:ops.CC_HDR + ops.CC_STRIDE * n].reshape(n, ops.CC_STRIDE)
+            if not self.use_cca:
+                out.append((pred[b].long(), [float(rows[:, 7].sum())]))
+            elif n == 0:
+                out.append((pred[b].long() * 0, [0]))
+            else:
+                k = int(tab[3])
+                out.append(((cw.labels_b[b].view(H, H) == (k + 1)).long(), [float(rows[k, 7])]))
+        return out
 
     def _coarse_only(self, output_logits, original_size):
         """ProtoSAM.py:580-590 (inference): logits (bilinear to the query's size if they differ) -> argmax map, mean fg

@@ -97,7 +97,14 @@ class ImageEncoderViT(nn.Module):
         # consumers' 3.8 ms; it also lowers the embedding error). Round 2 measured the opposite on the HIP kernels (122.2 vs 124.3:
         # +10 ms of epilogue). PSAM_FOLD_LN=0 / `fold_ln = False` selects the separate passes.
         self.fold_ln = os.environ.get("PSAM_FOLD_LN", "1") != "0"
-        self.fold_min_fill = 0.8      # ... where the launches fill the CUs (ops.fold_pays); 0 = always
+        self.fold_min_fill = float(os.environ.get("PSAM_FOLD_MIN_FILL", "0.8"))      # ... where the launches fill the CUs (ops.fold_pays); 0 = always
+        # Split-fp16 operands (round 5) where the fp16 rounding of an operand costs the most output accuracy per FLOP: the neck's two
+        # GEMMs run on (hi, lo) pairs of activations AND weights (hi W_hi + lo W_hi + hi W_lo: ~22 mantissa bits of each), the patch
+        # embedding on the EXACT uint8 pixel values (the SAM normalisation folded into the weights, which are split) when the caller
+        # hands the quantised image over (ProtoSAM's hand-off does). tools/emulate_ln_fusion.py priced these three GEMMs at 4.0e-4 of
+        # the 6.4e-4 embedding error; they are 2.5 % of the encoder's FLOPs. PSAM_SPLIT_FP16=0: plain fp16 operands (A/B).
+        self.split_fp16 = os.environ.get("PSAM_SPLIT_FP16", "1") != "0"
+        self._split_parts = os.environ.get("PSAM_SPLIT_PARTS", "neck,patch").split(",")     # (A/B of the two halves)
 
     def _apply(self, fn, *a, **k):
         self._packed, self._ws = None, {}
@@ -135,12 +142,28 @@ class ImageEncoderViT(nn.Module):
             d["qkv_wf"], d["qkv_s"], d["qkv_t"] = ops.fold_layernorm(a.qkv.weight, a.qkv.bias, blk.norm1.weight, blk.norm1.bias)
             d["l1wf"], d["l1s"], d["l1t"] = ops.fold_layernorm(blk.mlp.lin1.weight, blk.mlp.lin1.bias, blk.norm2.weight,
                                                                blk.norm2.bias)
-        pk["neck0"] = f16(self.neck[0].weight.reshape(oc, D))
+        pk["neck0"], pk["neck0_lo"] = ops.split_weight_f16(self.neck[0].weight.reshape(oc, D))
+        pk["neck2"], pk["neck2_lo"] = ops.split_weight_f16(self.neck[2].weight.permute(0, 2, 3, 1).reshape(oc, 9 * oc))  # [out, (ky,kx,cin)]
+        pk["raw"] = {}       # (mean, std) -> patch-embed weights for raw uint8 pixel values (see _patch_raw)
         pk["neck1w"], pk["neck1b"] = f32(self.neck[1].weight), f32(self.neck[1].bias)
-        pk["neck2"] = f16(self.neck[2].weight.permute(0, 2, 3, 1).reshape(oc, 9 * oc))  # [out, (ky,kx,cin)]
         pk["neck3w"], pk["neck3b"] = f32(self.neck[3].weight), f32(self.neck[3].bias)
         self._packed = pk
         return pk
+
+    def _patch_raw(self, pk, mean3, std3):
+        """Patch-embedding weights for patches of RAW uint8 pixel values p (exact in fp16): conv((p - mean) / std) = conv'(p) with
+        W'[n, c, :] = W[n, c, :] / std[c] (split into an fp16 hi / lo pair) and bias' = bias - sum_c mean[c] * sum(W'[n, c, :])."""
+        key = (tuple(float(v) for v in mean3), tuple(float(v) for v in std3))
+        if key not in pk["raw"]:
+            D = self.embed_dim
+            W = self.patch_embed.proj.weight.detach().double().reshape(D, 3, -1)
+            mean = torch.tensor(key[0], dtype=torch.float64, device=W.device)
+            std = torch.tensor(key[1], dtype=torch.float64, device=W.device)
+            Wp = W / std[None, :, None]
+            b = self.patch_embed.proj.bias.detach().double() - (Wp.sum(-1) * mean[None, :]).sum(-1)
+            hi, lo = ops.split_weight_f16(Wp.reshape(D, -1).float())
+            pk["raw"][key] = (hi, lo, b.float().contiguous())
+        return pk["raw"][key]
 
     def _workspace(self, B):
         if B not in self._ws:
@@ -159,6 +182,8 @@ class ImageEncoderViT(nn.Module):
                                relq=torch.zeros((B, H, N, 2, 32), dtype=torch.float16, device=dev),
                                n0=e((M, oc), torch.float32), n1=e((M, oc), torch.float16),
                                col=e((M, 9 * oc), torch.float16), n2=e((M, oc), torch.float32),
+                               ln_lo=e((M, D), torch.float16), n1f=e((M, oc), torch.float32), n1_lo=e((M, oc), torch.float16),
+                               col_lo=e((M, 9 * oc), torch.float16),
                                out=e((B, N, oc), torch.float32))
         return self._ws[B]
 
@@ -171,18 +196,21 @@ class ImageEncoderViT(nn.Module):
             ws["relw"] = torch.empty((B, H, N, 64), dtype=torch.float32, device=dev)
         return ws["relh"], ws["relw"]
 
-    def encode_patches(self, patches, B):
-        """One or two slices: a captured HIP graph of the forward's launches (ops.GraphCache; ~330 for ViT-H), else `_encode_patches`."""
+    def encode_patches(self, patches, B, raw_norm=None):
+        """One or two slices: a captured HIP graph of the forward's launches (ops.GraphCache; ~330 for ViT-H), else `_encode_patches`.
+        raw_norm = (mean3, std3): `patches` hold RAW uint8 pixel values (exact in fp16) and the normalisation is folded into the
+        patch-embedding weights (`split_fp16`)."""
         if B <= 2 and ops.graph_wanted(patches, 2 * self.grid * self.grid):
             gc = self.__dict__.setdefault("_graphs", ops.GraphCache("the SAM image encoder forward"))
             key = (tuple(patches.shape), B, str(patches.device), getattr(self, "_weights_epoch", 0), self.fold_ln,
-                   getattr(self, "fold_min_fill", None), ops.dispatch_key())
-            out = gc.run(key, patches, lambda t: self._encode_patches(t, B))
+                   getattr(self, "fold_min_fill", None), ops.dispatch_key(), self.split_fp16,
+                   None if raw_norm is None else (tuple(raw_norm[0]), tuple(raw_norm[1])))
+            out = gc.run(key, patches, lambda t: self._encode_patches(t, B, raw_norm))
             if out is not None:
                 return out
-        return self._encode_patches(patches, B)
+        return self._encode_patches(patches, B, raw_norm)
 
-    def _encode_patches(self, patches, B):
+    def _encode_patches(self, patches, B, raw_norm=None):
         """patches fp16 [B*4096, 3*16*16] (im2col of the normalised image) -> token-major embedding fp32 [B,4096,out].
         `fold_ln` (optional, see __init__): the blocks' LayerNorms never run as passes of their own - the GEMM that updates the residual
         stream also emits half(x) and per-row partial sums, `ln_finalize` turns them into (mean, rstd), and the consuming
@@ -199,7 +227,15 @@ class ImageEncoderViT(nn.Module):
         M = B * N
         x16, stats, mr = ws["ln"], ws["stats"], ws["mr"]
         fk = dict(out16=x16, stats=stats) if fold else {}
-        ops.gemm(patches, pk["patch_w"], pk["patch_b"], out=x, epilogue=ops.EPI_F32, resid=pk["pos"], resid_mod=N, **fk)
+        if raw_norm is not None:     # exact uint8 pixel values against the split (hi + lo) weights of the folded normalisation
+            pw_hi, pw_lo, pb = self._patch_raw(pk, *raw_norm)
+            if "patch" in self._split_parts:
+                ops.gemm(patches, pw_hi, pb, out=x, epilogue=ops.EPI_F32, resid=pk["pos"], resid_mod=N)
+                ops.gemm(patches, pw_lo, None, out=x, epilogue=ops.EPI_F32, resid=x, **fk)
+            else:
+                ops.gemm(patches, pw_hi, pb, out=x, epilogue=ops.EPI_F32, resid=pk["pos"], resid_mod=N, **fk)
+        else:
+            ops.gemm(patches, pk["patch_w"], pk["patch_b"], out=x, epilogue=ops.EPI_F32, resid=pk["pos"], resid_mod=N, **fk)
         for bp in pk["blocks"]:
             if fold:
                 ops.ln_finalize(stats, M, D, LN_EPS, mr=mr)
@@ -238,12 +274,26 @@ class ImageEncoderViT(nn.Module):
         # neck (image_encoder.py:90-106): the residual stream goes through the 1x1-conv GEMM as fp16 (with `fold_ln` the last
         # lin2 epilogue already wrote that copy)
         xh = ws["ln"]
-        if not fold:
-            ops.cast_f16(x, xh)
-        ops.gemm(xh, pk["neck0"], None, out=ws["n0"], epilogue=ops.EPI_F32)
-        ops.layernorm(ws["n0"], pk["neck1w"], pk["neck1b"], LN_EPS, out=ws["n1"])
-        ops.im2col3x3(ws["n1"], B, g, g, self.out_chans, out=ws["col"])
-        ops.gemm(ws["col"], pk["neck2"], None, out=ws["n2"], epilogue=ops.EPI_F32)
+        if self.split_fp16 and "neck" in self._split_parts:
+            # (hi, lo) pairs of the activations and of the weights: hi W_hi + lo W_hi + hi W_lo, accumulated in the fp32 output
+            ops.split_f16(x, hi=xh, lo=ws["ln_lo"], write_hi=not fold)
+            ops.gemm(xh, pk["neck0"], None, out=ws["n0"], epilogue=ops.EPI_F32)
+            ops.gemm(ws["ln_lo"], pk["neck0"], None, out=ws["n0"], epilogue=ops.EPI_F32, resid=ws["n0"])
+            ops.gemm(xh, pk["neck0_lo"], None, out=ws["n0"], epilogue=ops.EPI_F32, resid=ws["n0"])
+            ops.layernorm(ws["n0"], pk["neck1w"], pk["neck1b"], LN_EPS, out=ws["n1"], out2=ws["n1f"])
+            ops.split_f16(ws["n1f"], hi=ws["n1"], lo=ws["n1_lo"], write_hi=False)
+            ops.im2col3x3(ws["n1"], B, g, g, self.out_chans, out=ws["col"])
+            ops.im2col3x3(ws["n1_lo"], B, g, g, self.out_chans, out=ws["col_lo"])
+            ops.gemm(ws["col"], pk["neck2"], None, out=ws["n2"], epilogue=ops.EPI_F32)
+            ops.gemm(ws["col_lo"], pk["neck2"], None, out=ws["n2"], epilogue=ops.EPI_F32, resid=ws["n2"])
+            ops.gemm(ws["col"], pk["neck2_lo"], None, out=ws["n2"], epilogue=ops.EPI_F32, resid=ws["n2"])
+        else:
+            if not fold:
+                ops.cast_f16(x, xh)
+            ops.gemm(xh, pk["neck0"], None, out=ws["n0"], epilogue=ops.EPI_F32)
+            ops.layernorm(ws["n0"], pk["neck1w"], pk["neck1b"], LN_EPS, out=ws["n1"])
+            ops.im2col3x3(ws["n1"], B, g, g, self.out_chans, out=ws["col"])
+            ops.gemm(ws["col"], pk["neck2"], None, out=ws["n2"], epilogue=ops.EPI_F32)
         ops.layernorm(ws["n2"], pk["neck3w"], pk["neck3b"], LN_EPS, out=ws["out"].view(B * N, self.out_chans),
                       out_dtype=torch.float32)
         return ws["out"]

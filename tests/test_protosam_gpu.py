@@ -538,6 +538,28 @@ def test_coarse_pred_only(dev, use_cca):
     assert flips <= 40 and abs(float(conf[0]) - conf_ref) < 2e-3
 
 
+@pytest.mark.parametrize("use_cca", [False, True])
+def test_coarse_pred_only_batch_equals_per_slice(dev, use_cca):
+    """forward_batch with coarse_pred_only (round 5: one softmax / argmax launch, one connected-components chain and one table copy
+    for the batch, nothing of SAM) returns per slice what `forward` returns for it (ProtoSAM.py:580-590)."""
+    from protosam_amd.protosam import InputFactory, TYPE_ALPNET
+    from protosam_amd.synth import synth_pair
+    model, _ = _build(dev, "random:vit_b:1234:1", 2, use_bbox=True, use_points=True, coarse_pred_only=True, use_cca=use_cca)
+    s_img, s_m, _, _ = synth_pair(512, seed=0)
+    qs = torch.cat([synth_pair(512, seed=sd)[2] for sd in (0, 3, 4)]).to(dev)
+    mk = lambda q: InputFactory.create_input(TYPE_ALPNET, q, support_images=[s_img], support_labels=[s_m], isval=True, val_wsize=2)  # noqa: E731
+    inp = mk(qs)
+    inp.to(dev)
+    batched = model.forward_batch(qs, inp)
+    assert len(batched) == 3
+    for b in range(3):
+        inp1 = mk(qs[b:b + 1])
+        inp1.to(dev)
+        pred, conf = model(qs[b:b + 1], inp1)
+        assert batched[b][0].shape == pred.shape and batched[b][0].dtype == pred.dtype
+        assert int((batched[b][0] != pred).sum()) <= 8 and abs(float(batched[b][1][0]) - float(conf[0])) < 1e-4
+
+
 def test_protomedsam_coarse_pred_only(dev):
     from protosam_amd.grid_proto_fewshot import FewShotSeg
     from protosam_amd.protomedsam import ProtoMedSAM

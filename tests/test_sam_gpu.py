@@ -219,3 +219,34 @@ def test_image_encoder_folded_layernorm_path(dev):
         print(f"fold_ln={fold}: max abs err {err.max():.3e} mean {err.mean():.3e}")
         assert err.max() < 5e-2 and err.mean() < 3e-3
     assert (outs[True] - outs[False]).abs().max() < 5e-2
+
+
+def test_image_encoder_split_fp16_neck_and_patch_embedding(dev):
+    """Round 5 (`split_fp16`): the neck's two GEMMs on (hi, lo) fp16 pairs of activations and weights, the patch embedding on the exact
+    uint8 pixel values against split weights with Sam.preprocess' normalisation folded in (image_encoder.py:90-122, sam.py:163-168).
+    On a 0-block encoder (patch embedding + neck only) the embedding has to match the fp32 oracle far below the plain fp16-operand path;
+    with blocks in between it must not be worse; the [0 ... 255] hand-off equals the normalised-pixel route up to that rounding."""
+    from oracle import sam_image_encoder as oenc
+    from protosam_amd import ops
+    for depth, bound in ((0, 5e-4), (3, 5e-2)):
+        sam, sd = _sam(dev, "vit_b", depth)
+        enc = sam.image_encoder
+        img = _image(5)                                                     # uint8-valued [1,3,1024,1024]
+        x = (img.float() - torch.tensor([123.675, 116.28, 103.53]).view(1, 3, 1, 1)) / torch.tensor(
+            [58.395, 57.12, 57.375]).view(1, 3, 1, 1)
+        ref = oenc.image_encoder(x, sd, model_type="vit_b", depth=depth)    # [1,256,64,64]
+        errs = {}
+        for split in (False, True):
+            enc.split_fp16 = split
+            if split:      # raw pixel values, normalisation inside the weights (what ProtoSAM._sam_features hands over)
+                patches = ops.patchify_bilinear(img.float().to(dev).contiguous(), 1024, 16, 768)
+                tok = enc.encode_patches(patches, 1, raw_norm=(sam._mean_host, sam._std_host))
+            else:
+                tok = enc.forward_tokens(sam.preprocess(img.to(dev)))
+            out = tok.view(1, 64, 64, 256).permute(0, 3, 1, 2).cpu()
+            errs[split] = (out - ref).abs()
+        enc.split_fp16 = True
+        print(f"depth {depth}: plain fp16 operands max {errs[False].max():.3e} mean {errs[False].mean():.3e}; "
+              f"split neck + exact-pixel patch embedding max {errs[True].max():.3e} mean {errs[True].mean():.3e}")
+        assert errs[True].max() < bound
+        assert errs[True].mean() <= errs[False].mean() * (0.25 if depth == 0 else 1.02)
