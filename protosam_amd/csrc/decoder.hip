@@ -67,14 +67,20 @@ __global__ __launch_bounds__(256) void small_linear_mfma_kernel(const float* __r
   const float* wr = W + (size_t)g * wg + (size_t)(n0 + lrow) * K + lcol;
   const bool xin = m0 + lrow < M, win = n0 + lrow < N;
   f32x16 acc = {0};
-  for (int k0 = 0; k0 < K; k0 += 32) {
-    float xv[8], wv[8];
+  // the k slab AFTER the one being multiplied is requested before its MFMAs (round 5): with sixteen workgroups on the chip - nine
+  // tokens of 27 prompt sets against a 256 x 256 weight - nothing else hides the ~2 us of a global load, and the two-way block's
+  // 2048 -> 256 projection walked its 64 slabs at that pace (186 us for 0.25 GFLOP)
+  float xv[8], wv[8];
+  auto fetch = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       xv[i] = xin ? xr[k0 + i] : 0.f;
       if (x2r && xin) xv[i] += x2r[k0 + i];
       wv[i] = win ? wr[k0 + i] : 0.f;
     }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < K; k0 += 32) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -82,6 +88,7 @@ __global__ __launch_bounds__(256) void small_linear_mfma_kernel(const float* __r
       Ws[lrow * SLM_LD + lcol + i] = wv[i];
     }
     __syncthreads();
+    if (k0 + 32 < K) fetch(k0 + 32);
 #pragma unroll
     for (int s2 = 0; s2 < 16; ++s2) {
       const float a = Ws[(wn * 32 + lr) * SLM_LD + 2 * s2 + lk];
@@ -426,10 +433,78 @@ __global__ __launch_bounds__(256) void t2i_attention_kernel(const float* __restr
   }
 }
 
+// Round 5: ALL tokens of a (prompt set, head) in one workgroup, one WAVE per token - lane kl walks keys kl, kl + 64, ... with an online
+// softmax, the 64 lanes merge at the end (no LDS, no barrier). The kernel above gives every (token, head, prompt set) its own
+// workgroup, each of which streams the head's whole K / V slices (512 KB): nine tokens read them nine times (1 GB through the L2
+// per launch at 27 prompt sets; 173-281 us for 113 MB of K / V); here the T waves of a workgroup share them in the CU's caches.
+// (A first form with sixteen key lanes per token - 256 serial keys per thread - was latency-bound at the old kernel's 221 us.)
+template <typename KT>
+__global__ __launch_bounds__(1024) void t2i_attention_all_kernel(const float* __restrict__ q, const KT* __restrict__ K,
+                                                                const KT* __restrict__ V, float* __restrict__ out, int T,
+                                                                int Nk, int NH) {
+  constexpr int HD = 16;
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, t = tid >> 6, kl = tid & 63;
+  const int C = NH * HD;
+  const bool active = t < T;
+  const float inv = 1.0f / sqrtf((float)HD);
+  float qv[HD];
+  {
+    const float* qp = q + ((size_t)b * T + (active ? t : 0)) * C + h * HD;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) qv[d] = qp[d] * inv;
+  }
+  float m = -INFINITY, l = 0.f, o[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) o[d] = 0.f;
+  const KT* kp = K + (size_t)b * Nk * C + h * HD;
+  const KT* vp = V + (size_t)b * Nk * C + h * HD;
+#pragma unroll 4
+  for (int key = kl; key < Nk; key += 64) {
+    float kv[HD], vv[HD];
+    load16<KT>(kp + (size_t)key * C, kv);
+    load16<KT>(vp + (size_t)key * C, vv);
+    float a = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) a += qv[d] * kv[d];
+    const float mn = fmaxf(m, a);
+    const float sc = expf(m - mn), p = expf(a - mn);
+    l = l * sc + p;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[d] = o[d] * sc + p * vv[d];
+    m = mn;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {     // the 64 key lanes of a token are one wave
+    const float m2 = __shfl_xor(m, off), l2 = __shfl_xor(l, off);
+    const float mn = fmaxf(m, m2);
+    const float a1 = expf(m - mn), a2 = expf(m2 - mn);
+    l = l * a1 + l2 * a2;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[d] = o[d] * a1 + __shfl_xor(o[d], off) * a2;
+    m = mn;
+  }
+  if (active && kl == 0) {
+    float* op = out + ((size_t)b * T + t) * C + h * HD;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) op[d] = o[d] / l;
+  }
+}
+
 // kv_f32 = 1: K / V are fp32 (outputs of psam_gemm_f32, the default decoder path); 0: fp16 (outputs of psam_gemm_f16).
 extern "C" int psam_t2i_attention(const float* q, const void* K, const void* V, float* out, int B, int T, int Nk, int NH,
                                   int kv_f32, void* stream) {
   if (B <= 0 || T <= 0 || Nk <= 0 || Nk > 4096) return PSAM_ERR_ARG;
+  static const int all_tokens = [] { const char* e = getenv("PSAM_T2I_ALL"); return e ? atoi(e) : 1; }();      // (0: the round-1 kernel, A/B)
+  if (all_tokens && T <= 16 && Nk >= 64) {
+    if (kv_f32)
+      hipLaunchKernelGGL(t2i_attention_all_kernel<float>, dim3(NH, B), dim3(64 * T), 0, (hipStream_t)stream, q, (const float*)K,
+                         (const float*)V, out, T, Nk, NH);
+    else
+      hipLaunchKernelGGL(t2i_attention_all_kernel<half_t>, dim3(NH, B), dim3(64 * T), 0, (hipStream_t)stream, q, (const half_t*)K,
+                         (const half_t*)V, out, T, Nk, NH);
+    return psam_launch_status();
+  }
   if (kv_f32)
     hipLaunchKernelGGL(t2i_attention_kernel<float>, dim3(T, NH, B), dim3(256), 0, (hipStream_t)stream, q, (const float*)K,
                        (const float*)V, out, T, Nk, NH);
@@ -556,6 +631,7 @@ extern "C" int psam_prompt_tokens(const float* coords, const int* labels, const 
 // upscale_tail (mask_decoder.py:53-59,137-144): u1 = ConvT(256->64,2,2)(keys) as a GEMM [B*4096, 4*64] (+bias);
 // per mid pixel (token, dy, dx): LayerNorm2d(64) -> GELU -> ConvT(64->32,2,2) -> GELU -> dot with the 4
 // hyper-network vectors -> masks[b, 0:4, 4*ty+2*dy+dy2, 4*tx+2*dx+dx2]. `upscaled_embedding` is never written.
+template <bool MFMA>
 __global__ __launch_bounds__(256) void upscale_tail_kernel(const float* __restrict__ u1, const float* __restrict__ lnw,
                                                            const float* __restrict__ lnb, const float* __restrict__ W2r,
                                                            const float* __restrict__ b2, const float* __restrict__ hyper,
@@ -596,6 +672,49 @@ __global__ __launch_bounds__(256) void upscale_tail_kernel(const float* __restri
   }
   __syncthreads();
   const int W = 4 * g;
+  if (MFMA) {
+    // Round 5: the second transposed convolution as [256 mid pixels] x [4 x 32 outputs] x [64 channels] on the exact-fp32 MFMA
+    // (v_mfma_f32_32x32x2_f32: W2 as the A operand, the mid pixels as B, both straight from the LDS images above) instead of 8192
+    // scalar FMAs per thread fed by one 16-byte LDS read per four of them (365-592 us per 27 prompt sets: LDS-issue bound). A wave
+    // owns 64 mid pixels = two 32-pixel blocks x four sub-positions d2; after the GELU a lane holds 16 of a pixel's 32 channels,
+    // the partner lane (+32) the others: four dot products with the hyper-network vectors, one cross-lane add.
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 31, lk = lane >> 5;
+#pragma unroll 1
+    for (int pb = 0; pb < 2; ++pb) {
+      const int px = wave * 64 + pb * 32 + lr;                 // this lane's mid pixel (B operand row, output column)
+      const float* mrow = mids + px * 65 + lk;
+#pragma unroll 1
+      for (int d2 = 0; d2 < 4; ++d2) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = b2s[(r & 3) + 8 * (r >> 2) + 4 * lk];
+        const float* wcol = w2s + lk * 128 + d2 * 32 + lr;
+#pragma unroll 8
+        for (int s2 = 0; s2 < 32; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wcol[s2 * 256], mrow[2 * s2], acc, 0, 0, 0);
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c2 = (r & 3) + 8 * (r >> 2) + 4 * lk;
+          const float a = gelu_erf(acc[r]);
+          o0 += hs[c2] * a;
+          o1 += hs[32 + c2] * a;
+          o2 += hs[64 + c2] * a;
+          o3 += hs[96 + c2] * a;
+        }
+        o0 += __shfl_xor(o0, 32); o1 += __shfl_xor(o1, 32); o2 += __shfl_xor(o2, 32); o3 += __shfl_xor(o3, 32);
+        if (lk == 0) {
+          const int tk = blockIdx.x * 64 + (px >> 2), pdd = px & 3;
+          const int y = 4 * (tk / g) + 2 * (pdd >> 1) + (d2 >> 1), x = 4 * (tk % g) + 2 * (pdd & 1) + (d2 & 1);
+          float* mp = masks + (size_t)b * 4 * W * W + (size_t)y * W + x;
+          mp[0] = o0;
+          mp[(size_t)W * W] = o1;
+          mp[(size_t)2 * W * W] = o2;
+          mp[(size_t)3 * W * W] = o3;
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll 1
   for (int d2 = 0; d2 < 4; ++d2) {
     float acc[32];
@@ -638,11 +757,17 @@ extern "C" int psam_upscale_tail(const float* u1, const float* lnw, const float*
   if (B <= 0 || (g * g) % 64) return PSAM_ERR_ARG;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)upscale_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, UPS_LDS);
+    (void)hipFuncSetAttribute((const void*)upscale_tail_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, UPS_LDS);
+    (void)hipFuncSetAttribute((const void*)upscale_tail_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, UPS_LDS);
     attr_set = true;
   }
-  hipLaunchKernelGGL(upscale_tail_kernel, dim3(g * g / 64, B), dim3(256), UPS_LDS, (hipStream_t)stream, u1, lnw, lnb, W2r, b2,
-                     hyper, masks, g);
+  static const int mfma = [] { const char* e = getenv("PSAM_UPSCALE_MFMA"); return e ? atoi(e) : 1; }();      // (0: the scalar round-1 form, A/B)
+  if (mfma)
+    hipLaunchKernelGGL(upscale_tail_kernel<true>, dim3(g * g / 64, B), dim3(256), UPS_LDS, (hipStream_t)stream, u1, lnw, lnb, W2r, b2,
+                       hyper, masks, g);
+  else
+    hipLaunchKernelGGL(upscale_tail_kernel<false>, dim3(g * g / 64, B), dim3(256), UPS_LDS, (hipStream_t)stream, u1, lnw, lnb, W2r, b2,
+                       hyper, masks, g);
   return psam_launch_status();
 }
 

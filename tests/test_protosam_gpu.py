@@ -285,7 +285,7 @@ def test_forward_batch_skips_sam_for_empty_slices(dev, mask_only):
     calls = []
     enc = model.sam.image_encoder
     orig = enc.encode_patches
-    enc.encode_patches = lambda patches, B: (calls.append(B), orig(patches, B))[1]
+    enc.encode_patches = lambda patches, B, **kw: (calls.append(B), orig(patches, B, **kw))[1]
     try:
         model.coarse_segmentation_model = SomeEmpty()
         batched = model.forward_batch(qs, inp)

@@ -54,8 +54,8 @@ def main():
     ie = model.sam.image_encoder
     orig = ie.encode_patches
 
-    def cap(patches, B):
-        out = orig(patches, B)
+    def cap(patches, B, **kw):
+        out = orig(patches, B, **kw)
         captured["feat"] = out.clone()
         captured["x"] = ie._ws[B]["x"].clone()          # residual stream after the last block, token-major [B*4096, D]
         return out
