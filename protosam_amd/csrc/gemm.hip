@@ -1531,7 +1531,13 @@ static int pick_tile(int M, int N, int K, int epilogue) {
     // K >= 768: DINOv2-B's shapes at 16 slices (M = 20752) measured 5-45 % faster on the persistent 256-tile kernel than on the
     // 128-tile one (tools/gemm_tiles.py 1,11: qkv 790-820 vs 750, proj 730-760 vs 500-620, fc1 870 vs 740 TFLOP/s; fp32 epilogue
     // 557 vs 497); per-slice calls (M = 1297) fail the fill test and stay on the 128-tile kernel (350 vs 200)
-    if (K >= 768 && t256 * 100 >= rounds * ncu * (short_f32 ? 95 : 80)) {
+    // (round 5, tools/r05/gemm_small_sweep.py: with an fp16 / GELU epilogue the 256-tile assembly kernel still wins at half-filled rounds -
+    // 4096x2304x768, 144 tiles: 20.9 us against 23.8 on the half tiles; 4096x3072x768, 192 tiles: 29.5 against 32-34 on the 128-tile
+    // kernel; 2594x3072x768, 132 tiles: 26.1 against 31.5 - a launch that leaves CUs idle runs at a higher clock under the power cap;
+    // at 99 tiles (2594x2304x768) it loses, 19.9 against 15.4)
+    // (one partial round only: 4096x5120x1280 - 320 tiles, 1.25 rounds - stays on the half tiles, 64 against 71.5 us)
+    const int fill = short_f32 ? 95 : (epilogue == EPI_F32 || rounds > 1) ? 80 : 50;
+    if (K >= 768 && t256 * 100 >= rounds * ncu * fill) {
       // the assembly kernels (tile 15) take every shape the persistent HIP kernel took, when eligible (gemm_dispatch)
       return gemm_option(OPT_ASM) ? 15 : 11;
     }

@@ -581,3 +581,64 @@ def test_protomedsam_coarse_pred_only(dev):
             assert torch.equal(pred.bool(), logits.argmax(1)[0].bool())
         else:
             assert int(pred.sum()) <= int(logits.argmax(1)[0].sum())
+
+
+def _with_env(name, value, fn):
+    import os
+    old = os.environ.get(name)
+    os.environ[name] = value
+    try:
+        return fn()
+    finally:
+        if old is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = old
+
+
+def test_graph_replay_equals_eager_and_follows_new_weights(dev):
+    """The one- / two-slice encoder forwards replay captured HIP graphs (ops.GraphCache): (i) the replay is bit-identical to the eager
+    launches (PSAM_HIPGRAPH=0) for DINOv2 `forward_tokens`, SAM `encode_patches` and the whole `ProtoSAM.forward`; (ii) a
+    `load_state_dict` after the capture drops the graphs - the next call computes with the NEW weights, equal to an eager run of them
+    (a graph holds the addresses of the old weight packs); (iii) a dispatch switch flipped after the capture (`gemm_set_tile`) is part of
+    the graph key: the call after it is the switched computation, not a replay of the old kernels."""
+    from protosam_amd import ops
+    from protosam_amd.protosam import InputFactory, TYPE_ALPNET
+    from protosam_amd.synth import synth_pair, synth_state_dict
+    model, _ = _build(dev, "random:vit_b:1234:2", 2, use_bbox=True, use_points=True, point_mode="both", use_cca=False)
+    s_img, s_m, q_img, _ = synth_pair(512, seed=0)
+    q = q_img.to(dev)
+
+    def run():
+        inp = InputFactory.create_input(TYPE_ALPNET, q, support_images=[s_img], support_labels=[s_m], isval=True, val_wsize=2)
+        inp.to(dev)
+        pred, scores = model(q, inp)
+        return pred.clone(), model.last_stats["low_res"].clone()
+    enc, sam_enc = model.coarse_segmentation_model.model.encoder, model.sam.image_encoder
+    for mode in ("auto", "0"):            # graphs are captured on the first call of a shape, replayed on the second
+        _with_env("PSAM_HIPGRAPH", mode, run)
+    g_pred, g_low = _with_env("PSAM_HIPGRAPH", "auto", run)
+    assert enc.__dict__.get("_graphs") is not None and sam_enc.__dict__.get("_graphs") is not None      # (the replay path was taken)
+    e_pred, e_low = _with_env("PSAM_HIPGRAPH", "0", run)
+    assert torch.equal(g_pred, e_pred) and torch.equal(g_low, e_low)
+    tok_g = _with_env("PSAM_HIPGRAPH", "auto", lambda: enc.forward_tokens(q, 504).clone())
+    tok_e = _with_env("PSAM_HIPGRAPH", "0", lambda: enc.forward_tokens(q, 504).clone())
+    assert torch.equal(tok_g, tok_e)
+    # (ii) new weights for both encoders after the capture
+    model.sam.load_state_dict(synth_state_dict(model.sam, 4321))
+    alp = model.coarse_segmentation_model.model
+    alp.load_state_dict(synth_state_dict(alp, 4321))
+    assert "_graphs" not in enc.__dict__ and "_graphs" not in sam_enc.__dict__
+    n_pred, n_low = _with_env("PSAM_HIPGRAPH", "auto", run)
+    n_pred2, n_low2 = _with_env("PSAM_HIPGRAPH", "auto", run)                      # (captured with the new weights, replayed)
+    ne_pred, ne_low = _with_env("PSAM_HIPGRAPH", "0", run)
+    assert not torch.equal(n_low, g_low)
+    assert torch.equal(n_low, ne_low) and torch.equal(n_low2, ne_low) and torch.equal(n_pred, ne_pred)
+    # (iii) a dispatch switch after the capture
+    ops.gemm_set_tile(1)
+    try:
+        t1_g = _with_env("PSAM_HIPGRAPH", "auto", lambda: enc.forward_tokens(q, 504).clone())
+        t1_e = _with_env("PSAM_HIPGRAPH", "0", lambda: enc.forward_tokens(q, 504).clone())
+    finally:
+        ops.gemm_set_tile(0)
+    assert torch.equal(t1_g, t1_e)
