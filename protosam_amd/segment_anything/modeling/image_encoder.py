@@ -103,7 +103,7 @@ class ImageEncoderViT(nn.Module):
         # embedding on the EXACT uint8 pixel values (the SAM normalisation folded into the weights, which are split) when the caller
         # hands the quantised image over (ProtoSAM's hand-off does). tools/emulate_ln_fusion.py priced these three GEMMs at 4.0e-4 of
         # the 6.4e-4 embedding error; they are 2.5 % of the encoder's FLOPs. PSAM_SPLIT_FP16=0: plain fp16 operands (A/B).
-        self.split_fp16 = os.environ.get("PSAM_SPLIT_FP16", "1") != "0"
+        self.split_fp16 = os.environ.get("PSAM_SPLIT_FP16", "0") != "0"
         self._split_parts = os.environ.get("PSAM_SPLIT_PARTS", "neck,patch").split(",")     # (A/B of the two halves)
 
     def _apply(self, fn, *a, **k):
