@@ -37,6 +37,7 @@ PEAK_F16_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X
 # profiles/r04_mfma_power_limit.txt. Reported beside `peak`, never instead of it.
 SUSTAINED_F16_TFLOPS = 1624.0
 PEAK_HBM_GBS = 8000.0     # HBM3E peak (6.3 TB/s achievable by a float4 copy), same guide
+PEAK_F32_MFMA_TFLOPS = 157.0   # v_mfma_f32_32x32x2_f32, same guide (tools/micro/mfma_f32_rate.hip measures 149-155)
 
 
 def log(*a):
@@ -379,7 +380,12 @@ def extras(args, model, step, ops, psmod, B, torch, dev):
              "frac": round(by / tt / 1e9 / PEAK_HBM_GBS, 4), "launches_per_step": nl // nst,
              "avg_launch_us": round(tt / nl * 1e6, 2), "bytes_per_launch": round(by / nl)}
         fl = ops.TIMERS[n].summary2()
-        if fl > 0:   # the attention kernels are also priced against the MFMA roofline
+        if fl > 0 and n == "alp_sim":   # fp32 operands: priced against the fp32-MFMA rate (its real roof; FLOPs at bank capacity: upper bound)
+            e["mfma_tflops"] = round(fl / tt / 1e12, 1)
+            e["mfma_frac"] = round(fl / tt / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+            e["mfma_peak"] = PEAK_F32_MFMA_TFLOPS
+            e["bound"] = "mfma (fp32)"
+        elif fl > 0:   # the attention kernels are also priced against the MFMA roofline
             e["mfma_tflops"] = round(fl / tt / 1e12, 1)
             e["mfma_frac"] = round(fl / tt / 1e12 / PEAK_F16_TFLOPS, 4)
         hbm.append(e)

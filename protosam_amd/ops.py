@@ -508,7 +508,9 @@ def alp_sim(qry, q_bstride, ld, B, npix, C, bank, pred=None, part=None, eps=1e-4
     h = _tstart("alp_sim")
     st = _lib.lib().psam_alp_sim(_ptr(qry), q_bstride, ld, B, npix, C, _ptr(bank.bank), bank.cap, _ptr(bank.meta),
                                 float(eps), float(sim_scale), _ptr(part), _ptr(pred), which_only, _stream())
-    _tstop(h, B * npix * C * 4 + 2 * bank.cap * C * 4 + B * 2 * npix * 4)     # bank at capacity: an upper bound
+    # bytes: bank at capacity (an upper bound); FLOPs: every query pixel against 2 x cap prototypes on the fp32 MFMA (also an upper bound:
+    # the kernel walks the occupied slots only) - this kernel's roof is the 157 TFLOP/s fp32-MFMA rate, not HBM
+    _tstop(h, (B * npix * C * 4 + 2 * bank.cap * C * 4 + B * 2 * npix * 4, 2.0 * B * npix * C * 2 * bank.cap))
     _lib.check(st, "psam_alp_sim")
     return pred
 
