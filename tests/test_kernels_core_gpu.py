@@ -129,7 +129,7 @@ def test_gemm_persistent_tile_walks_many_tiles(dev, M, N, K, epi):
         # fp16 result differs in its last place where that shift crosses a rounding boundary: ~7 % of the outputs, whose ulp around
         # |y| = 0.1 is 6e-5)
         d = (outs[0].float() - outs[1].float()).abs()
-        assert (d <= outs[0].float().abs() * 2.0 ** -10 + 1e-6).all() and (d > 0).float().mean().item() < 0.15
+        assert (d <= outs[0].float().abs() * 2.0 ** -10 + 5e-6).all() and (d > 0).float().mean().item() < 0.15
     else:
         assert all(torch.equal(outs[0], o) for o in outs[1:])
     ref = a.float() @ w.float().t() + bias

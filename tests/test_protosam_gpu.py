@@ -181,8 +181,8 @@ def test_mixed_support_batch_equals_per_support_batches(dev):
     """forward_batch with a list of (input, n) pairs: slices of DIFFERENT support sets in one batch (a rank of a strong-scaling job,
     or a batch across two z-parts of a scan). Both encoders, connected components, SAM and the decoder do not depend on the support;
     the prototype match is done per support set. With every GEMM on one row-independent kernel (tile 1, separate LayerNorm passes)
-    a slice's encoder arithmetic does not depend on what else is in the batch: masks bit for bit equal to the per-support batches,
-    scores to fp32 rounding. With the default kernel choice (which follows the batch's row count): within the bound of the batched-vs-per-slice
+    a slice's encoder arithmetic does not depend on what else is in the batch: masks equal to the per-support batches (up to a
+    pixel on the threshold: the decoder's token side rounds differently for other prompt counts), scores to fp32 rounding. With the default kernel choice (which follows the batch's row count): within the bound of the batched-vs-per-slice
     test above."""
     from protosam_amd import ops
     from protosam_amd.protosam import InputFactory, TYPE_ALPNET
@@ -216,8 +216,9 @@ def test_mixed_support_batch_equals_per_support_batches(dev):
         assert len(mixed) == len(sep) == 5
         for b, ((pm, sm), (ps, ss)) in enumerate(zip(mixed, sep)):
             assert pm.shape == ps.shape and len(sm) == len(ss)
-            if forced:      # (the decoder's token-side linears pick their kernel by the number of prompt sets in the call: scores to rounding)
-                assert torch.equal(pm, ps), (b, int((pm != ps).sum()))
+            if forced:      # (the decoder's token-side linears pick their kernel by the number of prompt sets in the call: scores - and the
+                            #  hyper-network vectors - to fp32 rounding, so a mask pixel whose logit is within ~1e-6 of zero may differ)
+                assert int((pm != ps).sum()) <= 2, (b, int((pm != ps).sum()))
                 assert np.allclose(np.array(sm, dtype=np.float64), np.array(ss, dtype=np.float64), atol=2e-6, rtol=0)
             else:
                 assert (pm != ps).sum().item() <= 32
