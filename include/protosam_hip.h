@@ -178,6 +178,11 @@ int psam_ccl_batch(const void* pred, const float* pfg, long long pfg_stride, int
 int psam_small_linear(const float* x, const float* x2, const float* W, const float* b, const float* resid, float* y,
                       int G, int M, int N, int K, long long xg, long long wg, long long bg, long long yg, int ldx,
                       int ldy, int act, void* stream);
+/* One fp32 linear y = x W^T + b (+ resid) with few rows and a long contraction (the two-way block's MLP output 2048 -> 256,
+ * modeling/transformer.py:170-171, common.py:13-26) as `ks` K ranges in one launch + a fixed-order sum: parts fp32 [ks][M][N] is
+ * caller-owned scratch. W [N, K] row-major, K % (64 ks) == 0, ks >= 2. */
+int psam_small_linear_splitk(const float* x, const float* W, const float* b, const float* resid, float* y, float* parts, int M, int N,
+                             int K, int ks, int ldx, int ldy, void* stream);
 /* softmax(q k^T / sqrt(hd)) v with <= 16 keys (token self-attention; image->token attention). transformer.py:151-182 */
 int psam_small_attention(const void* q, const float* k, const float* v, void* out, int B, int Tq, int Tk, int NH, int hd,
                          int ldq, int ldk, int ldv, int ldo, int q_f16, void* stream);
@@ -189,6 +194,11 @@ int psam_t2i_attention(const float* q, const void* K, const void* V, float* out,
  * transformer.py:163-167,176-180,98-103,218-240 (k_proj / v_proj / q_proj / out_proj); mask_decoder.py:54,137 */
 int psam_gemm_f32(const float* a, const float* a2, int a2_mod, const float* w, const float* bias, const float* resid,
                   float* out, int M, int N, int K, int lda, int ldw, int ldo, void* stream);
+/* psam_gemm_f32 with a HEAD-MAJOR result: out fp32 [M / nk][N / hd][nk][hd] (image, head, key, channel) - the K / V projections of the
+ * two-way transformer's token-to-image attention (modeling/transformer.py:228-230 on the 4096-token operand), read by psam_t2i_attention
+ * with bit 1 of kv_f32 set. M % nk == 0, N % hd == 0, hd % 4 == 0; no residual. */
+int psam_gemm_f32_heads(const float* a, const float* a2, int a2_mod, const float* w, const float* bias, float* out, int M, int N, int K,
+                        int lda, int ldw, int nk, int hd, void* stream);
 /* y = [LayerNorm](x[src row] + add_vec); emits fp32 y, half y, half (y + pe[row % pe_mod]). With in_mod > 0 the input
  * is one [in_mod,256] embedding per image and prompt row/in_mod reads image img_of_prompt[prompt] (null: image 0).
  * mask_decoder.py:126-127; transformer.py:164,178,180 */

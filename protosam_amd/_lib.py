@@ -50,6 +50,8 @@ SIGNATURES = {
     "psam_small_attention": [c_void_p] * 4 + [c_int] * 10 + [c_void_p],
     "psam_t2i_attention": [c_void_p] * 4 + [c_int] * 5 + [c_void_p],
     "psam_gemm_f32": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p],
+    "psam_gemm_f32_heads": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p],
+    "psam_small_linear_splitk": [c_void_p] * 6 + [c_int] * 6 + [c_void_p],
     "psam_ln_pe": [c_void_p] * 8 + [c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p],
     "psam_dense_pe": [c_void_p, c_int, c_int, c_void_p, c_void_p],
     "psam_prompt_tokens": [c_void_p] * 5 + [c_int, c_int, c_float, c_void_p, c_void_p],

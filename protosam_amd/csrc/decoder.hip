@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void small_linear_mfma_kernel(const float* __r
                                                                 const float* __restrict__ W, const float* __restrict__ b,
                                                                 const float* __restrict__ resid, float* __restrict__ y,
                                                                 int M, int N, int K, long long xg, long long wg,
-                                                                long long bg, long long yg, int ldx, int ldy, int act) {
+                                                                long long bg, long long yg, int ldx, int ldy, int act, int ldw) {
   __shared__ float Xs[64 * SLM_LD], Ws[64 * SLM_LD];
   const int g = blockIdx.z, m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63, lr = lane & 31, lk = lane >> 5;
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void small_linear_mfma_kernel(const float* __r
   const int lrow = t >> 2, lcol = (t & 3) * 8;
   const float* xr = x + (size_t)g * xg + (size_t)(m0 + lrow) * ldx + lcol;
   const float* x2r = x2 ? x2 + (size_t)g * xg + (size_t)(m0 + lrow) * ldx + lcol : nullptr;
-  const float* wr = W + (size_t)g * wg + (size_t)(n0 + lrow) * K + lcol;
+  const float* wr = W + (size_t)g * wg + (size_t)(n0 + lrow) * ldw + lcol;
   const bool xin = m0 + lrow < M, win = n0 + lrow < N;
   f32x16 acc = {0};
   // the k slab AFTER the one being multiplied is requested before its MFMAs (round 5): with sixteen workgroups on the chip - nine
@@ -114,6 +114,33 @@ __global__ __launch_bounds__(256) void small_linear_mfma_kernel(const float* __r
   }
 }
 
+// y = sum over `ks` planes of parts[ks][M][N] + bias (+ resid): the second half of psam_small_linear_splitk
+__global__ void sum_planes_kernel(const float* __restrict__ parts, int ks, const float* __restrict__ b, const float* __restrict__ resid,
+                                  float* __restrict__ y, int M, int N, int ldy) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * N) return;
+  const int m = i / N, n = i % N;
+  float v = b ? b[n] : 0.f;
+  for (int k = 0; k < ks; ++k) v += parts[(size_t)k * M * N + i];
+  const size_t o = (size_t)m * ldy + n;
+  if (resid) v += resid[o];
+  y[o] = v;
+}
+// A token-side linear with a LONG contraction and few rows (the two-way block's MLP output, 2048 -> 256 on 9 tokens per prompt set,
+// transformer.py:170-171 / common.py:13-26): sixteen 64x64 tiles walking 64 k slabs each leave 240 CUs idle (156 us for 0.25 GFLOP).
+// Here K is cut into `ks` ranges that run as the groups of one small_linear_mfma launch (fp32 partial planes in `parts`, [ks][M][N],
+// caller-owned: no hidden state), then one pass adds them in a fixed order with the bias and the residual. K % (64 ks) == 0.
+extern "C" int psam_small_linear_splitk(const float* x, const float* W, const float* b, const float* resid, float* y, float* parts,
+                                        int M, int N, int K, int ks, int ldx, int ldy, void* stream) {
+  if (M <= 0 || N <= 0 || ks < 2 || (K % (64 * ks)) != 0 || !parts) return PSAM_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int kr = K / ks;
+  hipLaunchKernelGGL(small_linear_mfma_kernel, dim3((M + 63) / 64, (N + 63) / 64, ks), dim3(256), 0, s, x, (const float*)nullptr, W,
+                     (const float*)nullptr, (const float*)nullptr, parts, M, N, kr, (long long)kr, (long long)kr, 0LL, (long long)M * N, ldx, N, 0, K);
+  hipLaunchKernelGGL(sum_planes_kernel, dim3((M * N + 255) / 256), dim3(256), 0, s, parts, ks, b, resid, y, M, N, ldy);
+  return psam_launch_status();
+}
+
 extern "C" int psam_small_linear(const float* x, const float* x2, const float* W, const float* b, const float* resid,
                                  float* y, int G,
                                  int M, int N, int K, long long xg, long long wg, long long bg, long long yg, int ldx,
@@ -122,7 +149,7 @@ extern "C" int psam_small_linear(const float* x, const float* x2, const float* W
   hipStream_t s = (hipStream_t)stream;
   if (M >= 32 && (K % 32) == 0) {
     hipLaunchKernelGGL(small_linear_mfma_kernel, dim3((M + 63) / 64, (N + 63) / 64, G), dim3(256), 0, s, x, x2, W, b,
-                       resid, y, M, N, K, xg, wg, bg, yg, ldx, ldy, act);
+                       resid, y, M, N, K, xg, wg, bg, yg, ldx, ldy, act, K);
     return psam_launch_status();
   }
   dim3 grid((N + 3) / 4, G), block(256);
@@ -153,7 +180,7 @@ template <int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ a, const float* __restrict__ a2, int a2_mod,
                                                        const float* __restrict__ w, const float* __restrict__ bias,
                                                        const float* __restrict__ resid, float* __restrict__ out, int M,
-                                                       int N, int K, int lda, int ldw, int ldo) {
+                                                       int N, int K, int lda, int ldw, int ldo, int hm_nk, int hm_hd) {
   constexpr int MI = BM / 64, NI = BN / 64;       // 32x32 blocks per wave in m / n
   constexpr int AV = BM * 8 / 256, WV = BN * 8 / 256;   // float4 loads per thread and slab
   __shared__ float As[BM * GF_LD], Ws[BN * GF_LD];
@@ -238,13 +265,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
           const float4 r = *reinterpret_cast<const float4*>(resid + (size_t)m * ldo + n);
           v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
         }
-        *reinterpret_cast<float4*>(out + (size_t)m * ldo + n) = v;
+        if (hm_nk > 0) {   // head-major: out[image = m / nk][head = n / hd][m % nk][n % hd] (psam_gemm_f32_heads)
+          const size_t o = ((size_t)(m / hm_nk) * (N / hm_hd) + n / hm_hd) * hm_nk * hm_hd + (size_t)(m % hm_nk) * hm_hd + n % hm_hd;
+          *reinterpret_cast<float4*>(out + o) = v;
+        } else {
+          *reinterpret_cast<float4*>(out + (size_t)m * ldo + n) = v;
+        }
       }
   }
 }
 
-extern "C" int psam_gemm_f32(const float* a, const float* a2, int a2_mod, const float* w, const float* bias,
-                             const float* resid, float* out, int M, int N, int K, int lda, int ldw, int ldo, void* stream) {
+static int gemm_f32_launch(const float* a, const float* a2, int a2_mod, const float* w, const float* bias,
+                           const float* resid, float* out, int M, int N, int K, int lda, int ldw, int ldo, int hm_nk, int hm_hd, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || (K % 32) || (N % 64) || (lda % 4) || (ldw % 4) || (ldo % 4) || (a2 && a2_mod <= 0))
     return PSAM_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
@@ -261,12 +293,25 @@ extern "C" int psam_gemm_f32(const float* a, const float* a2, int a2_mod, const 
   }
 #define PSAM_GF32(BM_, BN_)                                                                                                     \
   hipLaunchKernelGGL((gemm_f32_kernel<BM_, BN_>), dim3((M + BM_ - 1) / BM_, N / BN_), dim3(256), 0, s, a, a2, a2_mod, w, bias, \
-                     resid, out, M, N, K, lda, ldw, ldo)
+                     resid, out, M, N, K, lda, ldw, ldo, hm_nk, hm_hd)
   if (best == 0) PSAM_GF32(128, 128);
   else if (best == 1) PSAM_GF32(64, 128);
   else PSAM_GF32(64, 64);
 #undef PSAM_GF32
   return psam_launch_status();
+}
+extern "C" int psam_gemm_f32(const float* a, const float* a2, int a2_mod, const float* w, const float* bias,
+                             const float* resid, float* out, int M, int N, int K, int lda, int ldw, int ldo, void* stream) {
+  return gemm_f32_launch(a, a2, a2_mod, w, bias, resid, out, M, N, K, lda, ldw, ldo, 0, 0, stream);
+}
+// The same product written HEAD-MAJOR: out fp32 [M / nk images][N / hd heads][nk][hd] - the K / V projections of the token-to-image
+// attention (transformer.py:228-230 on the 4096-token operand), whose kernel then reads a head's keys as contiguous 64-byte rows
+// (token-major, a (key, head) slice is 64 bytes of a 512-byte row: every 16-byte load of a wave touches 64 different lines and the
+// kernel ran at the L1's line rate, 128-328 us for 113 MB). M % nk == 0, hd % 4 == 0, N % hd == 0; no residual.
+extern "C" int psam_gemm_f32_heads(const float* a, const float* a2, int a2_mod, const float* w, const float* bias, float* out, int M,
+                                   int N, int K, int lda, int ldw, int nk, int hd, void* stream) {
+  if (nk <= 0 || hd <= 0 || (hd % 4) || (N % hd) || (M % nk)) return PSAM_ERR_ARG;
+  return gemm_f32_launch(a, a2, a2_mod, w, bias, nullptr, out, M, N, K, lda, ldw, N, nk, hd, stream);
 }
 
 // =====================================================================================================
@@ -441,7 +486,7 @@ __global__ __launch_bounds__(256) void t2i_attention_kernel(const float* __restr
 template <typename KT>
 __global__ __launch_bounds__(1024) void t2i_attention_all_kernel(const float* __restrict__ q, const KT* __restrict__ K,
                                                                 const KT* __restrict__ V, float* __restrict__ out, int T,
-                                                                int Nk, int NH) {
+                                                                int Nk, int NH, int head_major) {
   constexpr int HD = 16;
   const int h = blockIdx.x, b = blockIdx.y;
   const int tid = threadIdx.x, t = tid >> 6, kl = tid & 63;
@@ -457,13 +502,16 @@ __global__ __launch_bounds__(1024) void t2i_attention_all_kernel(const float* __
   float m = -INFINITY, l = 0.f, o[HD];
 #pragma unroll
   for (int d = 0; d < HD; ++d) o[d] = 0.f;
-  const KT* kp = K + (size_t)b * Nk * C + h * HD;
-  const KT* vp = V + (size_t)b * Nk * C + h * HD;
+  // token-major [B][Nk][NH * 16] (psam_gemm_f32 / psam_gemm_f16) or head-major [B][NH][Nk][16] (psam_gemm_f32_heads: a wave's 64 keys are
+  // 4 KiB of contiguous rows)
+  const int rs = head_major ? HD : C;
+  const KT* kp = head_major ? K + ((size_t)b * NH + h) * Nk * HD : K + (size_t)b * Nk * C + h * HD;
+  const KT* vp = head_major ? V + ((size_t)b * NH + h) * Nk * HD : V + (size_t)b * Nk * C + h * HD;
 #pragma unroll 4
   for (int key = kl; key < Nk; key += 64) {
     float kv[HD], vv[HD];
-    load16<KT>(kp + (size_t)key * C, kv);
-    load16<KT>(vp + (size_t)key * C, vv);
+    load16<KT>(kp + (size_t)key * rs, kv);
+    load16<KT>(vp + (size_t)key * rs, vv);
     float a = 0.f;
 #pragma unroll
     for (int d = 0; d < HD; ++d) a += qv[d] * kv[d];
@@ -495,14 +543,17 @@ __global__ __launch_bounds__(1024) void t2i_attention_all_kernel(const float* __
 extern "C" int psam_t2i_attention(const float* q, const void* K, const void* V, float* out, int B, int T, int Nk, int NH,
                                   int kv_f32, void* stream) {
   if (B <= 0 || T <= 0 || Nk <= 0 || Nk > 4096) return PSAM_ERR_ARG;
+  const int head_major = (kv_f32 >> 1) & 1;      // bit 1: K / V head-major [B][NH][Nk][16] (psam_gemm_f32_heads)
+  kv_f32 &= 1;
+  if (head_major && !(T <= 16 && Nk >= 64)) return PSAM_ERR_ARG;
   static const int all_tokens = [] { const char* e = getenv("PSAM_T2I_ALL"); return e ? atoi(e) : 1; }();      // (0: the round-1 kernel, A/B)
-  if (all_tokens && T <= 16 && Nk >= 64) {
+  if ((all_tokens || head_major) && T <= 16 && Nk >= 64) {
     if (kv_f32)
       hipLaunchKernelGGL(t2i_attention_all_kernel<float>, dim3(NH, B), dim3(64 * T), 0, (hipStream_t)stream, q, (const float*)K,
-                         (const float*)V, out, T, Nk, NH);
+                         (const float*)V, out, T, Nk, NH, head_major);
     else
       hipLaunchKernelGGL(t2i_attention_all_kernel<half_t>, dim3(NH, B), dim3(64 * T), 0, (hipStream_t)stream, q, (const half_t*)K,
-                         (const half_t*)V, out, T, Nk, NH);
+                         (const half_t*)V, out, T, Nk, NH, head_major);
     return psam_launch_status();
   }
   if (kv_f32)

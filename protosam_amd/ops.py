@@ -674,17 +674,45 @@ def small_attention(q, k, v, out, B, Tq, Tk, NH, hd, ldq, ldk, ldv, ldo):
     return out
 
 
-def t2i_attention(q, K, V, out, B, T, Nk, NH):
+def t2i_attention(q, K, V, out, B, T, Nk, NH, head_major=False):
+    """head_major: K / V are [B][NH][Nk][16] (gemm_f32(..., heads=(Nk, 16))) instead of token-major [B][Nk][NH * 16]."""
     _req(q, torch.float32, "q"); _req(K, K.dtype, "K"); _req(V, K.dtype, "V"); _req(out, torch.float32, "out")
     assert K.dtype in (torch.float16, torch.float32)
     st = _lib.lib().psam_t2i_attention(_ptr(q), _ptr(K), _ptr(V), _ptr(out), B, T, Nk, NH,
-                                      1 if K.dtype == torch.float32 else 0, _stream())
+                                      (1 if K.dtype == torch.float32 else 0) | (2 if head_major else 0), _stream())
     _lib.check(st, "psam_t2i_attention")
     return out
 
 
-def gemm_f32(a, w, bias=None, out=None, resid=None, a2=None, a2_mod=0):
-    """out[M,N] = (a[M,K] [+ a2[m % a2_mod]]) @ w[N,K]^T + bias [+ resid]; everything fp32 (exact-fp32 MFMA)."""
+def small_linear_splitk(x, W, b, resid, out, parts, ks):
+    """out[M,N] = x[M,K] @ W[N,K]^T + b (+ resid) as `ks` K ranges in one launch + a fixed-order sum (few rows, long contraction);
+    parts: fp32 scratch of at least ks * M * N elements."""
+    _req(x, torch.float32, "x"); _req(W, torch.float32, "W"); _req(b, torch.float32, "b"); _req(resid, torch.float32, "resid")
+    _req(out, torch.float32, "out"); _req(parts, torch.float32, "parts")
+    M, K = x.shape[-2], x.shape[-1]
+    N = W.shape[0]
+    assert W.shape[1] == K and W.is_contiguous() and parts.numel() >= ks * M * N and out.stride(-1) == 1
+    assert resid is None or resid.stride(-2) == out.stride(-2)
+    st = _lib.lib().psam_small_linear_splitk(_ptr(x), _ptr(W), _ptr(b), _ptr(resid), _ptr(out), _ptr(parts), M, N, K, ks, x.stride(-2),
+                                            out.stride(-2), _stream())
+    _lib.check(st, "psam_small_linear_splitk")
+    return out
+
+
+def gemm_f32(a, w, bias=None, out=None, resid=None, a2=None, a2_mod=0, heads=None):
+    """out[M,N] = (a[M,K] [+ a2[m % a2_mod]]) @ w[N,K]^T + bias [+ resid]; everything fp32 (exact-fp32 MFMA).
+    heads = (nk, hd): the result is written head-major, out fp32 [M / nk][N / hd][nk][hd] (no residual)."""
+    if heads is not None:
+        _req(a, torch.float32, "a"); _req(w, torch.float32, "w"); _req(bias, torch.float32, "bias"); _req(a2, torch.float32, "a2")
+        nk, hd = heads
+        M, K = a.shape
+        N = w.shape[0]
+        assert resid is None and out is not None and out.dtype == torch.float32 and out.is_contiguous() and out.numel() >= M * N
+        assert a2 is None or (a2.stride(0) == a.stride(0) and a2_mod > 0)
+        st = _lib.lib().psam_gemm_f32_heads(_ptr(a), _ptr(a2), a2_mod, _ptr(w), _ptr(bias), _ptr(out), M, N, K, a.stride(0), w.stride(0),
+                                           nk, hd, _stream())
+        _lib.check(st, "psam_gemm_f32_heads")
+        return out
     _req(a, torch.float32, "a"); _req(w, torch.float32, "w"); _req(bias, torch.float32, "bias")
     _req(resid, torch.float32, "resid"); _req(a2, torch.float32, "a2")
     assert a.dim() == 2 and w.dim() == 2 and w.shape[1] == a.shape[1]

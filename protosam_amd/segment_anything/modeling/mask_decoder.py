@@ -114,7 +114,7 @@ class MaskDecoder(nn.Module):
                 kpe16=e((M, 256), torch.float16) if h else None,
                 p0=e((M, 128), pdt), p1=e((M, 128), pdt), u1=e((M, 256)),
                 q=e((B * T, 256)), tq128=e((B * T, 128)), ta128=e((B * T, 128)), tq=e((B * T, 256)), tk=e((B * T, 256)), tv=e((B * T, 256)), ta=e((B * T, 256)),
-                t1=e((B * T, 256)), hid=e((B * T, 2048)), h1=e((B, 4, 256)), h2=e((B, 4, 256)), hyper=e((B, 4, 32)),
+                t1=e((B * T, 256)), hid=e((B * T, 2048)), parts=e((8, B * T, 256)), h1=e((B, 4, 256)), h2=e((B, 4, 256)), hyper=e((B, 4, 32)),
                 i1=e((B, 256)), i2=e((B, 256)), iou=e((B, 4)), masks=e((B, 4, 256, 256)))
         return self._ws[key]
 
@@ -141,18 +141,21 @@ class MaskDecoder(nn.Module):
         ops.ln_pe(feat_tok, pe_tok, B * Nk, y32=keys, y16=k16, ype16=kpe16, add_vec=dense_vec, in_mod=Nk, pe_mod=Nk,
                   img_of_prompt=img_of_prompt)
 
-        def img_proj(w_name, ap, out, with_pe):
-            """image-token projection: (keys [+ key_pe]) @ W^T + b (transformer.py:228-230 of the 4096-token operand)"""
+        def img_proj(w_name, ap, out, with_pe, heads=None):
+            """image-token projection: (keys [+ key_pe]) @ W^T + b (transformer.py:228-230 of the 4096-token operand); heads = (Nk, hd):
+            written head-major [B][NH][Nk][hd] for the token-to-image attention kernel"""
             if h16:
                 ops.gemm(kpe16 if with_pe else k16, ap[w_name + "16"], ap[w_name[0] + "b"], out=out, epilogue=ops.EPI_F16)
             else:
-                ops.gemm_f32(keys, ap[w_name], ap[w_name[0] + "b"], out=out, a2=pe_tok if with_pe else None, a2_mod=Nk)
+                ops.gemm_f32(keys, ap[w_name], ap[w_name[0] + "b"], out=out, a2=pe_tok if with_pe else None, a2_mod=Nk, heads=heads)
+
+        hm = (not h16) and T <= 16 and Nk >= 64       # K / V of the token-to-image attention head-major (contiguous 64-byte key rows)
 
         def t2i(ap, resid_ln):
             lin(q, ap["qw"], ap["qb"], out=ws["tq128"], x2=tok2)
-            img_proj("kw", ap, ws["p0"], True)
-            img_proj("vw", ap, ws["p1"], False)
-            ops.t2i_attention(ws["tq128"], ws["p0"], ws["p1"], ws["ta128"], B, T, Nk, NH)
+            img_proj("kw", ap, ws["p0"], True, heads=(Nk, 128 // NH) if hm else None)
+            img_proj("vw", ap, ws["p1"], False, heads=(Nk, 128 // NH) if hm else None)
+            ops.t2i_attention(ws["tq128"], ws["p0"], ws["p1"], ws["ta128"], B, T, Nk, NH, head_major=hm)
             lin(ws["ta128"], ap["ow"], ap["ob"], out=ws["t1"], resid=q)
             ops.layernorm(ws["t1"], resid_ln[0], resid_ln[1], LN_EPS, out=q, out_dtype=torch.float32)
 
@@ -171,7 +174,10 @@ class MaskDecoder(nn.Module):
             ops.layernorm(ws["t1"], L["n"][0][0], L["n"][0][1], LN_EPS, out=q, out_dtype=torch.float32)
             t2i(L["t2i"], L["n"][1])
             lin(q, L["l1w"], L["l1b"], out=ws["hid"], act=1)
-            lin(ws["hid"], L["l2w"], L["l2b"], out=ws["t1"], resid=q)
+            if B * T >= 32:      # 2048 -> 256 on few rows: eight K ranges side by side (psam_small_linear_splitk)
+                ops.small_linear_splitk(ws["hid"], L["l2w"], L["l2b"], q, ws["t1"], ws["parts"], 8)
+            else:
+                lin(ws["hid"], L["l2w"], L["l2b"], out=ws["t1"], resid=q)
             ops.layernorm(ws["t1"], L["n"][2][0], L["n"][2][1], LN_EPS, out=q, out_dtype=torch.float32)
             ia = L["i2t"]
             img_proj("qw", ia, ws["p0"], True)
