@@ -679,6 +679,8 @@ class ProtoSAM(nn.Module):
         key = (str(dev), H, B)
         cache = self.__dict__.setdefault("_coarse_bufs", {})
         if key not in cache:
+            while len(cache) >= 6:                   # (one set of buffers per batch size seen: keep the most recent few)
+                cache.pop(next(iter(cache)))
             cache[key] = dict(fg_sum=torch.zeros(B, dtype=torch.int32, device=dev),
                               prob=torch.empty((B, 2, H, H), dtype=torch.float32, device=dev),
                               pred=torch.empty((B, H, H), dtype=torch.uint8, device=dev),
