@@ -189,6 +189,11 @@ int psam_small_attention(const void* q, const float* k, const float* v, void* ou
 /* token -> image cross attention over Nk <= 4096 keys; K, V fp32 (kv_f32 = 1) or half.  transformer.py:163-167, 98-103 */
 int psam_t2i_attention(const float* q, const void* K, const void* V, float* out, int B, int T, int Nk, int NH,
                        int kv_f32, void* stream);
+/* The same with the 4096 keys of every (prompt set, head) split over S workgroups (1 <= S <= 16; one slice at a time a launch is 8-16
+ * workgroups of latency-bound waves otherwise) and a second small launch that merges the partial (max, sum, weighted values) in the
+ * order of the split index: `part` fp32 scratch of >= B * NH * S * T * 18 elements. Same reference lines as psam_t2i_attention. */
+int psam_t2i_attention_split(const float* q, const void* K, const void* V, float* out, int B, int T, int Nk, int NH,
+                             int kv_f32, int S, float* part, void* stream);
 /* out = (a [+ a2[m % a2_mod]]) w^T + bias [+ resid], all fp32 on the exact-fp32 MFMA: the decoder's projections of the
  * 4096 image tokens (keys [+ key_pe]) and ConvTranspose2d #1 as a GEMM. K % 32 == 0, N % 64 == 0, lds % 4 == 0.
  * transformer.py:163-167,176-180,98-103,218-240 (k_proj / v_proj / q_proj / out_proj); mask_decoder.py:54,137 */

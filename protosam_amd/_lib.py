@@ -49,6 +49,7 @@ SIGNATURES = {
     "psam_small_linear": [c_void_p] * 6 + [c_int] * 4 + [c_longlong] * 4 + [c_int] * 3 + [c_void_p],
     "psam_small_attention": [c_void_p] * 4 + [c_int] * 10 + [c_void_p],
     "psam_t2i_attention": [c_void_p] * 4 + [c_int] * 5 + [c_void_p],
+    "psam_t2i_attention_split": [c_void_p] * 4 + [c_int] * 6 + [c_void_p] * 2,
     "psam_gemm_f32": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p],
     "psam_gemm_f32_heads": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p],
     "psam_small_linear_splitk": [c_void_p] * 6 + [c_int] * 6 + [c_void_p],

@@ -486,9 +486,10 @@ __global__ __launch_bounds__(256) void t2i_attention_kernel(const float* __restr
 template <typename KT>
 __global__ __launch_bounds__(1024) void t2i_attention_all_kernel(const float* __restrict__ q, const KT* __restrict__ K,
                                                                 const KT* __restrict__ V, float* __restrict__ out, int T,
-                                                                int Nk, int NH, int head_major) {
+                                                                int Nk, int NH, int head_major, int S,
+                                                                float* __restrict__ part) {
   constexpr int HD = 16;
-  const int h = blockIdx.x, b = blockIdx.y;
+  const int h = blockIdx.x, b = blockIdx.y, z = blockIdx.z;
   const int tid = threadIdx.x, t = tid >> 6, kl = tid & 63;
   const int C = NH * HD;
   const bool active = t < T;
@@ -507,8 +508,13 @@ __global__ __launch_bounds__(1024) void t2i_attention_all_kernel(const float* __
   const int rs = head_major ? HD : C;
   const KT* kp = head_major ? K + ((size_t)b * NH + h) * Nk * HD : K + (size_t)b * Nk * C + h * HD;
   const KT* vp = head_major ? V + ((size_t)b * NH + h) * Nk * HD : V + (size_t)b * Nk * C + h * HD;
+  // S > 1 (psam_t2i_attention_split): workgroup z of the S that share (b, h) takes the keys [z * chunk, (z + 1) * chunk) - with one or
+  // two prompt sets a launch is 8 ... 16 workgroups whose waves each walk 4096 keys in 64 dependent round trips (67 us, latency);
+  // split, every wave has a few and the chip has ~256 workgroups
+  const int chunk = S > 1 ? ((Nk + S * 64 - 1) / (S * 64)) * 64 : Nk;
+  const int k0 = z * chunk, k1 = min(Nk, k0 + chunk);
 #pragma unroll 4
-  for (int key = kl; key < Nk; key += 64) {
+  for (int key = k0 + kl; key < k1; key += 64) {
     float kv[HD], vv[HD];
     load16<KT>(kp + (size_t)key * rs, kv);
     load16<KT>(vp + (size_t)key * rs, vv);
@@ -526,34 +532,91 @@ __global__ __launch_bounds__(1024) void t2i_attention_all_kernel(const float* __
   for (int off = 32; off >= 1; off >>= 1) {     // the 64 key lanes of a token are one wave
     const float m2 = __shfl_xor(m, off), l2 = __shfl_xor(l, off);
     const float mn = fmaxf(m, m2);
-    const float a1 = expf(m - mn), a2 = expf(m2 - mn);
+    const float a1 = m == -INFINITY ? 0.f : expf(m - mn), a2 = m2 == -INFINITY ? 0.f : expf(m2 - mn);   // (a lane without keys: split ranges)
     l = l * a1 + l2 * a2;
 #pragma unroll
     for (int d = 0; d < HD; ++d) o[d] = o[d] * a1 + __shfl_xor(o[d], off) * a2;
     m = mn;
   }
+  if (S <= 1) {
+    if (active && kl == 0) {
+      float* op = out + ((size_t)b * T + t) * C + h * HD;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) op[d] = o[d] / l;
+    }
+    return;
+  }
+  // partial (m, l, o[16]) of this key range -> part[(b, h)][z][t]; t2i_combine_kernel merges the S partials in the order of z.
+  // (A single-launch form - the last workgroup of (b, h) to arrive combines, found through a device-scope counter - was measured first:
+  // its release / acquire fences write back and invalidate the XCD's L2 in every workgroup: 27 prompt sets 2350 -> 2800 us per decoder
+  // call, two sets 737 -> 710 only.)
   if (active && kl == 0) {
-    float* op = out + ((size_t)b * T + t) * C + h * HD;
+    float* pp = part + ((((size_t)b * NH + h) * S + z) * T + t) * 18;
+    pp[0] = m; pp[1] = l;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) pp[2 + d] = o[d];
+  }
+}
+
+// one wave per (b, h, t): lane z < S holds the partial of key range z; fixed-order butterfly; out[b][t][h * 16 ..]
+__global__ __launch_bounds__(256) void t2i_combine_kernel(const float* __restrict__ part, float* __restrict__ out, int B, int T, int NH,
+                                                          int S) {
+  constexpr int HD = 16;
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6), kl = threadIdx.x & 63;
+  if (w >= B * NH * T) return;
+  const int t = w % T, bh = w / T, h = bh % NH, b = bh / NH;
+  const bool have = kl < S;
+  const float* pp = part + (((size_t)bh * S + (have ? kl : 0)) * T + t) * 18;
+  float m = have ? pp[0] : -INFINITY, l = have ? pp[1] : 0.f, o[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) o[d] = have ? pp[2 + d] : 0.f;
+#pragma unroll
+  for (int off = 8; off >= 1; off >>= 1) {       // S <= 16
+    const float m2 = __shfl_xor(m, off), l2 = __shfl_xor(l, off);
+    const float mn = fmaxf(m, m2);
+    const float a1 = m == -INFINITY ? 0.f : expf(m - mn), a2 = m2 == -INFINITY ? 0.f : expf(m2 - mn);
+    l = l * a1 + l2 * a2;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[d] = o[d] * a1 + __shfl_xor(o[d], off) * a2;
+    m = mn;
+  }
+  if (kl == 0) {
+    float* op = out + ((size_t)b * T + t) * (NH * HD) + h * HD;
 #pragma unroll
     for (int d = 0; d < HD; ++d) op[d] = o[d] / l;
   }
 }
 
 // kv_f32 = 1: K / V are fp32 (outputs of psam_gemm_f32, the default decoder path); 0: fp16 (outputs of psam_gemm_f16).
+static int t2i_launch(const float* q, const void* K, const void* V, float* out, int B, int T, int Nk, int NH, int kv_f32, int S,
+                      float* part, void* stream);
 extern "C" int psam_t2i_attention(const float* q, const void* K, const void* V, float* out, int B, int T, int Nk, int NH,
                                   int kv_f32, void* stream) {
+  return t2i_launch(q, K, V, out, B, T, Nk, NH, kv_f32, 1, nullptr, stream);
+}
+// The same with the keys of every (prompt set, head) split over S workgroups (1 <= S <= 16) and a second small launch that merges the
+// partials in the order of the split index: `part` fp32 scratch of at least B * NH * S * T * 18 elements.
+extern "C" int psam_t2i_attention_split(const float* q, const void* K, const void* V, float* out, int B, int T, int Nk, int NH,
+                                        int kv_f32, int S, float* part, void* stream) {
+  if (S < 1 || S > 16 || T > 16 || Nk < 64 || (S > 1 && !part)) return PSAM_ERR_ARG;
+  return t2i_launch(q, K, V, out, B, T, Nk, NH, kv_f32, S, part, stream);
+}
+static int t2i_launch(const float* q, const void* K, const void* V, float* out, int B, int T, int Nk, int NH, int kv_f32, int S,
+                      float* part, void* stream) {
   if (B <= 0 || T <= 0 || Nk <= 0 || Nk > 4096) return PSAM_ERR_ARG;
   const int head_major = (kv_f32 >> 1) & 1;      // bit 1: K / V head-major [B][NH][Nk][16] (psam_gemm_f32_heads)
   kv_f32 &= 1;
   if (head_major && !(T <= 16 && Nk >= 64)) return PSAM_ERR_ARG;
   static const int all_tokens = [] { const char* e = getenv("PSAM_T2I_ALL"); return e ? atoi(e) : 1; }();      // (0: the round-1 kernel, A/B)
-  if ((all_tokens || head_major) && T <= 16 && Nk >= 64) {
+  if ((all_tokens || head_major || S > 1) && T <= 16 && Nk >= 64) {
     if (kv_f32)
-      hipLaunchKernelGGL(t2i_attention_all_kernel<float>, dim3(NH, B), dim3(64 * T), 0, (hipStream_t)stream, q, (const float*)K,
-                         (const float*)V, out, T, Nk, NH, head_major);
+      hipLaunchKernelGGL(t2i_attention_all_kernel<float>, dim3(NH, B, S), dim3(64 * T), 0, (hipStream_t)stream, q, (const float*)K,
+                         (const float*)V, out, T, Nk, NH, head_major, S, part);
     else
-      hipLaunchKernelGGL(t2i_attention_all_kernel<half_t>, dim3(NH, B), dim3(64 * T), 0, (hipStream_t)stream, q, (const half_t*)K,
-                         (const half_t*)V, out, T, Nk, NH, head_major);
+      hipLaunchKernelGGL(t2i_attention_all_kernel<half_t>, dim3(NH, B, S), dim3(64 * T), 0, (hipStream_t)stream, q, (const half_t*)K,
+                         (const half_t*)V, out, T, Nk, NH, head_major, S, part);
+    if (S > 1)
+      hipLaunchKernelGGL(t2i_combine_kernel, dim3((B * NH * T + 3) / 4), dim3(256), 0, (hipStream_t)stream, part, out, B, T, NH, S);
     return psam_launch_status();
   }
   if (kv_f32)

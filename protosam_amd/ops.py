@@ -674,12 +674,32 @@ def small_attention(q, k, v, out, B, Tq, Tk, NH, hd, ldq, ldk, ldv, ldo):
     return out
 
 
-def t2i_attention(q, K, V, out, B, T, Nk, NH, head_major=False):
-    """head_major: K / V are [B][NH][Nk][16] (gemm_f32(..., heads=(Nk, 16))) instead of token-major [B][Nk][NH * 16]."""
+def t2i_split(B, NH, T, Nk, n_cu=256):
+    """into how many key ranges a token-to-image attention launch is split (PSAM_T2I_SPLIT: "auto", or a number to force): the unsplit
+    launch has B * NH workgroups whose waves each walk all keys, 64 dependent round trips"""
+    mode = _os.environ.get("PSAM_T2I_SPLIT", "auto")
+    if T > 16 or Nk < 512 or mode == "0":
+        return 1
+    if mode != "auto" and mode != "1":
+        return max(1, min(16, Nk // 256, int(mode)))
+    return max(1, min(16, Nk // 256, n_cu // (B * NH)))
+
+
+def t2i_attention(q, K, V, out, B, T, Nk, NH, head_major=False, split=None):
+    """head_major: K / V are [B][NH][Nk][16] (gemm_f32(..., heads=(Nk, 16))) instead of token-major [B][Nk][NH * 16].
+    split = (S, part): the keys in S ranges per (prompt set, head), merged by a second small launch - part fp32 scratch of at least
+    B * NH * S * T * 18 elements."""
     _req(q, torch.float32, "q"); _req(K, K.dtype, "K"); _req(V, K.dtype, "V"); _req(out, torch.float32, "out")
     assert K.dtype in (torch.float16, torch.float32)
-    st = _lib.lib().psam_t2i_attention(_ptr(q), _ptr(K), _ptr(V), _ptr(out), B, T, Nk, NH,
-                                      (1 if K.dtype == torch.float32 else 0) | (2 if head_major else 0), _stream())
+    flags = (1 if K.dtype == torch.float32 else 0) | (2 if head_major else 0)
+    if split is not None and split[0] > 1:
+        S, part = split
+        _req(part, torch.float32, "part")
+        assert part.numel() >= B * NH * S * T * 18
+        st = _lib.lib().psam_t2i_attention_split(_ptr(q), _ptr(K), _ptr(V), _ptr(out), B, T, Nk, NH, flags, S, _ptr(part), _stream())
+        _lib.check(st, "psam_t2i_attention_split")
+        return out
+    st = _lib.lib().psam_t2i_attention(_ptr(q), _ptr(K), _ptr(V), _ptr(out), B, T, Nk, NH, flags, _stream())
     _lib.check(st, "psam_t2i_attention")
     return out
 

@@ -9,6 +9,8 @@ margin under the 1e-3 parity bound (with fp16 operands this stage alone measured
 `t2i_attention`; the rest of the upscaling and the hyper-network product are fused in `upscale_tail` so
 `upscaled_embedding` [B,32,256,256] is never materialised.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -115,7 +117,7 @@ class MaskDecoder(nn.Module):
                 p0=e((M, 128), pdt), p1=e((M, 128), pdt), u1=e((M, 256)),
                 q=e((B * T, 256)), tq128=e((B * T, 128)), ta128=e((B * T, 128)), tq=e((B * T, 256)), tk=e((B * T, 256)), tv=e((B * T, 256)), ta=e((B * T, 256)),
                 t1=e((B * T, 256)), hid=e((B * T, 2048)), parts=e((8, B * T, 256)), h1=e((B, 4, 256)), h2=e((B, 4, 256)), hyper=e((B, 4, 32)),
-                i1=e((B, 256)), i2=e((B, 256)), iou=e((B, 4)), masks=e((B, 4, 256, 256)))
+                i1=e((B, 256)), i2=e((B, 256)), iou=e((B, 4)), masks=e((B, 4, 256, 256)), t2i_part=e((16 * B * 8 * T * 18,)))
         return self._ws[key]
 
     # ---- the decoder ---------------------------------------------------------------------------------------------
@@ -150,12 +152,14 @@ class MaskDecoder(nn.Module):
                 ops.gemm_f32(keys, ap[w_name], ap[w_name[0] + "b"], out=out, a2=pe_tok if with_pe else None, a2_mod=Nk, heads=heads)
 
         hm = (not h16) and T <= 16 and Nk >= 64       # K / V of the token-to-image attention head-major (contiguous 64-byte key rows)
+        t2i_s = ops.t2i_split(B, NH, T, Nk) if NH == 8 else 1     # key ranges per (prompt set, head): few prompt sets leave the CUs idle
 
         def t2i(ap, resid_ln):
             lin(q, ap["qw"], ap["qb"], out=ws["tq128"], x2=tok2)
             img_proj("kw", ap, ws["p0"], True, heads=(Nk, 128 // NH) if hm else None)
             img_proj("vw", ap, ws["p1"], False, heads=(Nk, 128 // NH) if hm else None)
-            ops.t2i_attention(ws["tq128"], ws["p0"], ws["p1"], ws["ta128"], B, T, Nk, NH, head_major=hm)
+            ops.t2i_attention(ws["tq128"], ws["p0"], ws["p1"], ws["ta128"], B, T, Nk, NH, head_major=hm,
+                              split=(t2i_s, ws["t2i_part"]))
             lin(ws["ta128"], ap["ow"], ap["ob"], out=ws["t1"], resid=q)
             ops.layernorm(ws["t1"], resid_ln[0], resid_ln[1], LN_EPS, out=q, out_dtype=torch.float32)
 

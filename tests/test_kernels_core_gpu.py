@@ -666,3 +666,44 @@ def test_gemm_fp32_residual_without_gamma(dev, M, N, K, ln):
             torch.testing.assert_close(z, a.float() @ w.float().t() + bias, rtol=1e-5, atol=2e-4)
     finally:
         ops.gemm_set_tile(0)
+
+
+@pytest.mark.parametrize("B,T,Nk,hm,kdt", [(1, 7, 4096, True, torch.float32), (2, 9, 4096, True, torch.float32), (3, 16, 4096, False, torch.float32),
+                                            (2, 8, 1024, True, torch.float32), (1, 7, 576, False, torch.float16), (27, 8, 4096, True, torch.float32)])
+def test_t2i_attention_key_split(dev, B, T, Nk, hm, kdt):
+    """token-to-image attention of the two-way transformer (transformer.py:228-230 on the 4096 image tokens): the kernel against fp64
+    softmax(q k^T / 4) v per head, and its key-split form (psam_t2i_attention_split: S workgroups per (prompt set, head), partials
+    merged in the order of the split index by a second launch) against the unsplit launch."""
+    from protosam_amd import ops
+    NH, HD = 8, 16
+    q = _rand((B * T, 128), dev, 1.5, 81)
+    k = _rand((B, Nk, 128), dev, 1.0, 82)
+    v = _rand((B, Nk, 128), dev, 1.0, 83)
+    k[0, 5] *= 6.0                                   # a dominant key
+    qh = q.double().view(B, T, NH, HD).permute(0, 2, 1, 3)
+    kh = k.double().view(B, Nk, NH, HD).permute(0, 2, 1, 3)
+    vh = v.double().view(B, Nk, NH, HD).permute(0, 2, 1, 3)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) / 4.0, -1) @ vh).permute(0, 2, 1, 3).reshape(B * T, 128)
+    if kdt == torch.float16:
+        ref16 = k.half(), v.half()
+        kh = ref16[0].double().view(B, Nk, NH, HD).permute(0, 2, 1, 3)
+        vh = ref16[1].double().view(B, Nk, NH, HD).permute(0, 2, 1, 3)
+        ref = (torch.softmax(qh @ kh.transpose(-1, -2) / 4.0, -1) @ vh).permute(0, 2, 1, 3).reshape(B * T, 128)
+    lay = (lambda x: x.view(B, Nk, NH, HD).permute(0, 2, 1, 3).contiguous()) if hm else (lambda x: x.contiguous())
+    K, V = lay(k.to(kdt)), lay(v.to(kdt))
+    base = torch.full((B * T, 128), float("nan"), device=dev)
+    ops.t2i_attention(q, K, V, base, B, T, Nk, NH, head_major=hm)
+    torch.testing.assert_close(base.double(), ref, rtol=2e-5, atol=2e-5)
+    for S in (2, 5, 16, ops.t2i_split(B, NH, T, Nk)):
+        if S < 2 or Nk // S < 32:
+            continue
+        part = torch.full((B * NH * S * T * 18,), float("nan"), device=dev)
+        outs = []
+        for _ in range(3):
+            out = torch.full((B * T, 128), float("nan"), device=dev)
+            ops.t2i_attention(q, K, V, out, B, T, Nk, NH, head_major=hm, split=(S, part))
+            outs.append(out)
+        for out in outs:
+            assert torch.equal(out, outs[0])
+            torch.testing.assert_close(out, base, rtol=1e-5, atol=2e-6)
+    assert ops.t2i_split(1, 8, 7, 4096) == 16 and ops.t2i_split(27, 8, 8, 4096) == 1 and ops.t2i_split(16, 8, 8, 4096) == 2
