@@ -26,24 +26,37 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float* __restri
 #pragma unroll
   for (int i = 0; i < KV; ++i) w[i] = wr[lane + 64 * i];
   const float bias = b ? b[(size_t)g * bg + n] : 0.f;
-  for (int m = 0; m < M; ++m) {
-    const float* xr = x + (size_t)g * xg + (size_t)m * ldx;
-    float s = 0.f;
-    if (x2) {  // fused `queries + query_pe` (transformer.py:157,163,177,98)
-      const float* x2r = x2 + (size_t)g * xg + (size_t)m * ldx;
+  // RB rows at a time (round 5: one row per iteration was a chain of M dependent load -> 6-step butterfly -> store round trips, 8.7 us for
+  // the 18 rows of a one-slice call): their loads are in flight together, the butterflies interleave, lane r stores row r
+  constexpr int RB = KV <= 4 ? 8 : 2;
+  for (int m0 = 0; m0 < M; m0 += RB) {
+    float s[RB];
 #pragma unroll
-      for (int i = 0; i < KV; ++i) s += (xr[lane + 64 * i] + x2r[lane + 64 * i]) * w[i];
-    } else {
+    for (int r = 0; r < RB; ++r) {
+      const int m = min(m0 + r, M - 1);
+      const float* xr = x + (size_t)g * xg + (size_t)m * ldx;
+      float a = 0.f;
+      if (x2) {  // fused `queries + query_pe` (transformer.py:157,163,177,98)
+        const float* x2r = x2 + (size_t)g * xg + (size_t)m * ldx;
 #pragma unroll
-      for (int i = 0; i < KV; ++i) s += xr[lane + 64 * i] * w[i];
+        for (int i = 0; i < KV; ++i) a += (xr[lane + 64 * i] + x2r[lane + 64 * i]) * w[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < KV; ++i) a += xr[lane + 64 * i] * w[i];
+      }
+      s[r] = a;
     }
-    s = wave_sum(s);
-    if (lane == 0) {
-      s += bias;
-      if (act == 1) s = fmaxf(s, 0.f);
-      const size_t o = (size_t)g * yg + (size_t)m * ldy + n;
-      if (resid) s += resid[o];
-      y[o] = s;
+#pragma unroll
+    for (int r = 0; r < RB; ++r) s[r] = wave_sum(s[r]);
+    float mine = s[0];
+#pragma unroll
+    for (int r = 1; r < RB; ++r) mine = lane == r ? s[r] : mine;
+    if (lane < RB && m0 + lane < M) {
+      mine += bias;
+      if (act == 1) mine = fmaxf(mine, 0.f);
+      const size_t o = (size_t)g * yg + (size_t)(m0 + lane) * ldy + n;
+      if (resid) mine += resid[o];
+      y[o] = mine;
     }
   }
 }

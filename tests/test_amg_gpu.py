@@ -168,7 +168,8 @@ def test_sam_wrapper_forward(dev, amg_setup):
 
 
 @pytest.mark.parametrize("M,N,K,G", [(7, 256, 256, 1), (45, 128, 256, 1), (1792, 256, 256, 1), (1792, 2048, 256, 1),
-                                     (1792, 256, 2048, 1), (100, 4, 256, 1), (256, 32, 256, 4), (33, 70, 128, 1)])
+                                     (1792, 256, 2048, 1), (100, 4, 256, 1), (256, 32, 256, 4), (33, 70, 128, 1),
+                                     (18, 256, 256, 1), (9, 2048, 256, 1), (17, 256, 128, 1), (5, 256, 2048, 1), (31, 130, 64, 1), (8, 32, 256, 4)])
 def test_small_linear_both_paths(dev, M, N, K, G):
     """fp32 token-side linear: the one-wave-per-column kernel (M < 32) and the fp32-MFMA tile kernel (M >= 32) against a
     float64 matmul, with the fused x + x2, ReLU, residual and grouped (hyper-network) forms."""
