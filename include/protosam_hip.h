@@ -167,7 +167,7 @@ int psam_split_f16(const float* x, void* hi, void* lo, long long n, int write_hi
  * {area, sum_x, sum_y, min_x, min_y, max_x, max_y, conf, best_x, best_y, best_p, 0}. */
 int psam_ccl(const void* pred, const float* pfg, int H, int W, int cap, int* labels, int* parent, int* counters,
              int* roots, int* acc_i, void* acc_u, double* acc_d, const int* fg_sum, double* tab, void* stream);
-/* psam_ccl for B images in one chain of seven launches (blockIdx.z = image): pred u8 [B,H,W], pfg with `pfg_stride` floats between
+/* psam_ccl for B images in one chain of six launches (blockIdx.z = image): pred u8 [B,H,W], pfg with `pfg_stride` floats between
  * images, every scratch array B times the single-image size (contiguous per image), fg_sum int32 [B] or NULL, tab fp64
  * [B][8 + 12*cap]. Replaces the per-slice loop over util/utils.py:468-541 of a batch of slices. */
 int psam_ccl_batch(const void* pred, const float* pfg, long long pfg_stride, int B, int H, int W, int cap, int* labels, int* parent,

@@ -100,23 +100,22 @@ __global__ __launch_bounds__(256) void ccl_merge_kernel(const uint8_t* __restric
   }
 }
 
+// flatten: parent[i] := the root of i, and the roots are collected. One pass (round 5; rounds 1-4 ran a read-only find here and a second
+// kernel that wrote the roots back): after the merge kernel the ROOTS are final, and a thread that meets a parent another thread has
+// already flattened reads either the old ancestor or the root - both on the path to the same root.
 __global__ void ccl_flatten_kernel(int n, int* __restrict__ parent, int* __restrict__ roots, int cap, int* counters, CclStride st) {
   parent += blockIdx.z * st.parent; roots += blockIdx.z * st.roots; counters += blockIdx.z * st.counters;
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  if (parent[i] < 0) return;
+  const int p0 = parent[i];
+  if (p0 < 0) return;
   const int r = uf_find(parent, i);
   if (r == i) {
     int k = atomicAdd(&counters[0], 1);
     if (k < cap) roots[k] = i;
+  } else if (r != p0) {
+    parent[i] = r;
   }
-}
-// second flatten pass (after all roots are final) so that parent[i] is the root itself
-__global__ void ccl_compress_kernel(int n, int* __restrict__ parent, CclStride st) {
-  parent += blockIdx.z * st.parent;
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || parent[i] < 0) return;
-  parent[i] = uf_find(parent, i);
 }
 
 // one block: rank the (<= cap) collected roots ascending, label them 1..n, clear the accumulators
@@ -312,7 +311,6 @@ static int ccl_launch(const void* pred, const float* pfg, int H, int W, int cap,
   hipLaunchKernelGGL(ccl_init_kernel, dim3((W + 255) / 256, H, Z), dim3(256), 0, s, pr, H, W, parent, counters, st);
   hipLaunchKernelGGL(ccl_merge_kernel, dim3((W + 255) / 256, H, Z), dim3(256), 0, s, pr, H, W, parent, st);
   hipLaunchKernelGGL(ccl_flatten_kernel, dim3((n + 255) / 256, 1, Z), dim3(256), 0, s, n, parent, roots, cap, counters, st);
-  hipLaunchKernelGGL(ccl_compress_kernel, dim3((n + 255) / 256, 1, Z), dim3(256), 0, s, n, parent, st);
   hipLaunchKernelGGL(ccl_rank_kernel, dim3(1, 1, Z), dim3(256), cap * sizeof(int), s, roots, cap, counters, labels, acc_i,
                      (unsigned long long*)acc_u, acc_d, st);
   hipLaunchKernelGGL(ccl_stats_kernel, dim3((W + 255) / 256, (H + STAT_ROWS - 1) / STAT_ROWS, Z), dim3(256), 0, s, parent, H, W, pfg, labels,
@@ -329,7 +327,7 @@ extern "C" int psam_ccl(const void* pred, const float* pfg, int H, int W, int ca
   return ccl_launch(pred, pfg, H, W, cap, labels, parent, counters, roots, acc_i, acc_u, acc_d, fg_sum, tab, 1, st, (hipStream_t)stream);
 }
 
-// B images in one launch chain (seven launches for the whole batch instead of seven per image; validation_protosam.py walks slices,
+// B images in one launch chain (six launches for the whole batch instead of six per image; validation_protosam.py walks slices,
 // ProtoSAM.forward_batch batches them): pred u8 [B,H,W] contiguous, pfg fp32 with `pfg_stride` floats between images (channel 1 of a
 // [B,2,H,W] probability map: 2*H*W), every scratch array B times the single-image size, contiguous per image; fg_sum int32 [B] or
 // NULL; tab fp64 [B][8 + 12*cap].

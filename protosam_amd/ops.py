@@ -978,7 +978,7 @@ def ccl(pred_u8, pfg, ws, fg_sum=None, slot=0):
 
 def ccl_batch(pred_u8, prob, ws, fg_sum=None):
     """pred uint8 [B,H,W], prob fp32 [B,2,H,W] (foreground = channel 1) -> ws.labels_b[b], ws.tabs[b] for every image in ONE chain of
-    seven launches (psam_ccl_batch)."""
+    six launches (psam_ccl_batch)."""
     B = pred_u8.shape[0]
     assert pred_u8.dtype == torch.uint8 and pred_u8.is_cuda and pred_u8.is_contiguous() and B <= ws.slots
     _req(prob, torch.float32, "prob")

@@ -500,7 +500,7 @@ class ProtoSAM(nn.Module):
         bufs["fg_event"].record()
         # 2. connected components + per-component statistics; the tables go to pinned host memory asynchronously
         cw = self._ccl
-        ops.ccl_batch(pred[:B], output_p[:B], cw, fg_sum=bufs["fg_sum"])        # one chain of seven launches for the batch
+        ops.ccl_batch(pred[:B], output_p[:B], cw, fg_sum=bufs["fg_sum"])        # one chain of six launches for the batch
         for b in range(B):
             if self.use_neg_points:
                 nk = bufs.setdefault("neg_keys", torch.empty((B, MAX_NEG_COMPONENTS + 1), dtype=torch.int64, device=dev))
