@@ -643,3 +643,21 @@ def test_graph_replay_equals_eager_and_follows_new_weights(dev):
     finally:
         ops.gemm_set_tile(0)
     assert torch.equal(t1_g, t1_e)
+    # (iv) the split-K form of the fp32-residual GEMM shares ONE workspace per device, ordered between streams by a host-tracked event a
+    # replayed graph knows nothing of: it is never taken inside a capture. Without the half-tile kernels the one-slice fc2 / proj shapes
+    # are split-K candidates; two graph replays on two streams (DINOv2 on one, the SAM encoder on the other) must equal the eager
+    # single-stream run of the unsplit kernels.
+    ops.gemm_set_option("half_tiles", 0)
+    old_ov = model.overlap_streams
+    try:
+        model.overlap_streams = "1"
+        _with_env("PSAM_HIPGRAPH", "auto", run)
+        h_pred, h_low = _with_env("PSAM_HIPGRAPH", "auto", run)
+        model.overlap_streams = "0"
+        ops.gemm_set_option("splitk", 0)
+        he_pred, he_low = _with_env("PSAM_HIPGRAPH", "0", run)
+    finally:
+        model.overlap_streams = old_ov
+        ops.gemm_set_option("splitk", 1)
+        ops.gemm_set_option("half_tiles", 1)
+    assert torch.equal(h_low, he_low) and torch.equal(h_pred, he_pred)
