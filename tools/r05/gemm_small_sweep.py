@@ -27,10 +27,12 @@ def timeit(fn, n=20):
 
 
 SHAPES = []
-for M in (1297, 2594, 4096, 5330, 8192):
+MS = [int(v) for v in os.environ["MS"].split(",")] if os.environ.get("MS") else (1297, 2594, 4096, 5330, 8192)   # MS=20752: sixteen DINOv2 slices
+for M in MS:
     SHAPES += [(M, 2304, 768, 0), (M, 768, 768, 2), (M, 3072, 768, 1), (M, 768, 3072, 2)]
-SHAPES += [(4096, 256, 768, 2), (4096, 256, 2304, 2), (1297, 3072, 1024, 0), (1297, 1024, 1024, 2), (1297, 4096, 1024, 1), (1297, 1024, 4096, 2),
-           (4096, 3840, 1280, 0), (4096, 1280, 1280, 2), (4096, 5120, 1280, 1), (4096, 1280, 5120, 2)]
+if not os.environ.get("MS"):
+    SHAPES += [(4096, 256, 768, 2), (4096, 256, 2304, 2), (1297, 3072, 1024, 0), (1297, 1024, 1024, 2), (1297, 4096, 1024, 1), (1297, 1024, 4096, 2),
+               (4096, 3840, 1280, 0), (4096, 1280, 1280, 2), (4096, 5120, 1280, 1), (4096, 1280, 5120, 2)]
 for (M, N, K, epi) in SHAPES:
     a = torch.randn(M, K, device=dev).half()
     w = (torch.randn(N, K, device=dev) * 0.05).half()
