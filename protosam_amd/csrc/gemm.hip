@@ -1411,9 +1411,12 @@ static bool asm_eligible(const GemmArgs& p, int epilogue, int lnf) {
     const bool cons = p.ln_mr || p.ln_s, prod = p.out16 || p.stats;
     if (!f || g_asm_variant != 0 || (cons && prod)) return false;
     if (cons && (!f[6 + epilogue] || !p.ln_mr || !p.ln_s || !p.bias || (reinterpret_cast<uintptr_t>(p.ln_mr) & 15) || (reinterpret_cast<uintptr_t>(p.ln_s) & 15))) return false;
-    if (prod && (!f[8] || !p.out16 || !p.stats || p.resid != p.out || p.ldr != p.ldo)) return false;
+    if (prod && (!f[8] || !p.out16 || !p.stats)) return false;
   }
-  if (p.head_hd || p.out_seg || p.resid_mod || epilogue > EPI_F32) return false;
+  if (p.head_hd || p.out_seg || epilogue > EPI_F32) return false;
+  // resid_mod (residual row = output row % resid_mod: the position table of a patch embedding, image_encoder.py:107-108): the fp32
+  // epilogue of the 256-tile kernels masks the row of a tile's origin - a power of two that whole tiles divide
+  if (p.resid_mod && (epilogue != EPI_F32 || !p.resid || p.resid_mod < 256 || (p.resid_mod & (p.resid_mod - 1)) != 0 || g_asm_variant != 0)) return false;
   if (p.N % 256 || p.K % 64 || p.K < 128 || p.M < 1) return false;
   if ((p.lda % 8) || (p.ldw % 8) || (reinterpret_cast<uintptr_t>(p.A) & 15) || (reinterpret_cast<uintptr_t>(p.W) & 15)) return false;
   const unsigned long long lim = 0xffffffffull;
@@ -1434,7 +1437,7 @@ static bool asm2_eligible(const GemmArgs& p, int epilogue, int lnf) {
   if (epilogue > EPI_F32 || (p.N % 128)) return false;
   GemmArgs q = p;
   q.N = 256;   // (the 256-column rule of the first family does not apply)
-  if (lnf || !asm_eligible(q, epilogue, 0)) return false;
+  if (lnf || p.resid_mod || !asm_eligible(q, epilogue, 0)) return false;
   if ((unsigned long long)p.N * p.ldw * 2 > 0xffffffffull) return false;
   const int e = epilogue == EPI_F16 ? PSAM_ASM2_E_F16 : epilogue == EPI_GELU_F16 ? PSAM_ASM2_E_GELU : PSAM_ASM2_E_F32;
   return p.K / 64 >= e + 1 && p.K / 64 >= 3;
@@ -1451,7 +1454,7 @@ static int launch_asm(const GemmArgs& p, int epilogue, hipStream_t s, int family
   a.A = p.A; a.W = p.W; a.bias = p.bias; a.out = p.out; a.resid = p.resid; a.gamma = p.gamma; a.tab = t->dev;
   a.M = p.M; a.N = p.N; a.K = p.K; a.lda = p.lda; a.ldw = p.ldw; a.ldo = p.ldo; a.ldr = p.resid ? p.ldr : 0; a.G = t->grid;
   a.flags = p.gamma ? 1 : 0;
-  a.pad = 0;
+  a.pad = (family == 1 && p.resid_mod > 0) ? p.resid_mod - 1 : -1;      // (S_RMASK of gemm_asm_gen.py; the half-tile kernels ignore it)
   a.trace = nullptr;
   const bool ln_cons = family == 1 && p.ln_mr && p.ln_s, ln_prod = family == 1 && (p.out16 || p.stats);
   if (ln_cons) {   // folded LayerNorm, consumer: (mean, rstd) rows + -mean fragments in `resid`, the s fragments (behind the N floats) in `gamma`

@@ -707,3 +707,35 @@ def test_t2i_attention_key_split(dev, B, T, Nk, hm, kdt):
             assert torch.equal(out, outs[0])
             torch.testing.assert_close(out, base, rtol=1e-5, atol=2e-6)
     assert ops.t2i_split(1, 8, 7, 4096) == 16 and ops.t2i_split(27, 8, 8, 4096) == 1 and ops.t2i_split(16, 8, 8, 4096) == 2
+
+
+@pytest.mark.parametrize("M,N,K,mod", [(3 * 512 + 100, 512, 768, 512), (2 * 4096, 1280, 768, 4096), (1024 + 7, 256, 128, 256)])
+@pytest.mark.parametrize("ln", [False, True])
+def test_gemm_position_table_residual_on_the_assembly_tile(dev, M, N, K, mod, ln):
+    """The patch embedding's epilogue (image_encoder.py:107-108: x = patch_embed(img) + pos_embed): residual row = output row % resid_mod, a
+    [resid_mod, N] table shared by all images, out of place - on the 256-tile assembly kernel (tile 15, the row of a tile's origin masked:
+    resid_mod a power of two >= 256) with and without the folded-LayerNorm producer outputs, against the fp32 product and bit-for-bit
+    against the HIP 256-tile kernel (tile 11), ragged last tile included."""
+    from protosam_amd import ops
+    a = _rand((M, K), dev, 1.0, 91).half()
+    w = _rand((N, K), dev, 0.05, 92).half()
+    bias = _rand((N,), dev, 0.5, 93)
+    pos = (_rand((mod, N), dev, 2.0, 94) + 0.25).contiguous()
+    ref = a.float() @ w.float().t() + bias + pos.repeat((M + mod - 1) // mod, 1)[:M]
+    outs = []
+    try:
+        for tile in (15, 11):
+            ops.gemm_set_tile(tile)
+            x = torch.full((M, N), float("nan"), device=dev)
+            kw = {}
+            if ln:
+                kw = dict(out16=torch.empty((M, N), dtype=torch.float16, device=dev), stats=torch.full((M, N // 64, 2), float("nan"), device=dev))
+            ops.gemm(a, w, bias, out=x, epilogue=ops.EPI_F32, resid=pos, resid_mod=mod, **kw)
+            torch.testing.assert_close(x, ref, rtol=1e-5, atol=2e-4)
+            if ln:
+                assert torch.equal(kw["out16"], x.half())
+                torch.testing.assert_close(kw["stats"][..., 0].sum(1), x.sum(1), rtol=1e-4, atol=2e-2)
+            outs.append(x)
+        assert torch.equal(outs[0], outs[1])
+    finally:
+        ops.gemm_set_tile(0)
