@@ -7,6 +7,10 @@ O=gpurun_out; mkdir -p $O
 timeout 2400 python3 -m pytest tests -q -m gpu > $O/${TAG}_pytest.log 2>&1; echo "pytest rc $?" >> $O/${TAG}_pytest.log
 tail -4 $O/${TAG}_pytest.log
 timeout 600 python3 __graft_entry__.py smoke 2>&1 | tail -2
+# the per-shape GEMM traffic first: bench.py takes `roofline.traffic` from profiles/r05_gemm_traffic_by_shape.json only when its source
+# hashes match the library being run (copy the fresh file into profiles/ of the work tree afterwards as well)
+bash tools/gemm_traffic_by_shape.sh 0 > /dev/null 2>&1
+cp gpurun_out/gemm_traffic_by_shape.json profiles/r05_gemm_traffic_by_shape.json
 bash tools/final_profile.sh $TAG > /dev/null 2>&1
 python3 - <<PY
 import json
@@ -19,7 +23,6 @@ for k,v in j["other_configs"].items():
 print(j["cpu_baseline"])
 print(j["parity_vs_cpu_oracle"]["worst_max_abs_dprob_low_res"], j["parity_vs_cpu_oracle"]["min_dice_final_mask"])
 PY
-bash tools/gemm_traffic_by_shape.sh 0 > /dev/null 2>&1
 python3 -c "
 import json; d=json.load(open('gpurun_out/gemm_traffic_by_shape.json'))
 for k,v in d['shapes'].items(): print(k, {a: v[a] for a in v if 'ratio' in a or 'bytes' in a})
