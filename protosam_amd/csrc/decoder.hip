@@ -65,6 +65,10 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float* __restri
 // per block on the fp32 MFMA (v_mfma_f32_32x32x2f32), W as the A operand so each lane ends up with 4 consecutive output
 // columns of one row (16 B stores). x (+ x2) and W tiles are staged through LDS in 32-wide k slabs.
 #define SLM_LD 33
+// VEC: every row of x (+ x2) and W starts on a 16-byte boundary - the k slab is requested as two float4 per operand and thread. (The
+// element-wise form compiled to sixteen single-dword loads per slab with a branch and, for x + x2, a full vmcnt(0) wait per element:
+// 23-31 us per call of the 243-row token-side linears of a 16-slice step whatever their grid.)
+template <bool VEC>
 __global__ __launch_bounds__(256) void small_linear_mfma_kernel(const float* __restrict__ x, const float* __restrict__ x2,
                                                                 const float* __restrict__ W, const float* __restrict__ b,
                                                                 const float* __restrict__ resid, float* __restrict__ y,
@@ -85,6 +89,25 @@ __global__ __launch_bounds__(256) void small_linear_mfma_kernel(const float* __r
   // 2048 -> 256 projection walked its 64 slabs at that pace (186 us for 0.25 GFLOP)
   float xv[8], wv[8];
   auto fetch = [&](int k0) {
+    if (VEC) {
+      float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, w0 = a0, w1 = a0;
+      if (xin) {
+        a0 = *reinterpret_cast<const float4*>(xr + k0);
+        a1 = *reinterpret_cast<const float4*>(xr + k0 + 4);
+        if (x2r) {
+          const float4 p0 = *reinterpret_cast<const float4*>(x2r + k0), p1 = *reinterpret_cast<const float4*>(x2r + k0 + 4);
+          a0.x += p0.x; a0.y += p0.y; a0.z += p0.z; a0.w += p0.w;
+          a1.x += p1.x; a1.y += p1.y; a1.z += p1.z; a1.w += p1.w;
+        }
+      }
+      if (win) {
+        w0 = *reinterpret_cast<const float4*>(wr + k0);
+        w1 = *reinterpret_cast<const float4*>(wr + k0 + 4);
+      }
+      xv[0] = a0.x; xv[1] = a0.y; xv[2] = a0.z; xv[3] = a0.w; xv[4] = a1.x; xv[5] = a1.y; xv[6] = a1.z; xv[7] = a1.w;
+      wv[0] = w0.x; wv[1] = w0.y; wv[2] = w0.z; wv[3] = w0.w; wv[4] = w1.x; wv[5] = w1.y; wv[6] = w1.z; wv[7] = w1.w;
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       xv[i] = xin ? xr[k0 + i] : 0.f;
@@ -148,8 +171,13 @@ extern "C" int psam_small_linear_splitk(const float* x, const float* W, const fl
   if (M <= 0 || N <= 0 || ks < 2 || (K % (64 * ks)) != 0 || !parts) return PSAM_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   const int kr = K / ks;
-  hipLaunchKernelGGL(small_linear_mfma_kernel, dim3((M + 63) / 64, (N + 63) / 64, ks), dim3(256), 0, s, x, (const float*)nullptr, W,
-                     (const float*)nullptr, (const float*)nullptr, parts, M, N, kr, (long long)kr, (long long)kr, 0LL, (long long)M * N, ldx, N, 0, K);
+  const bool vec = ((ldx | K | kr) & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W)) & 15) == 0;
+  if (vec)
+    hipLaunchKernelGGL(small_linear_mfma_kernel<true>, dim3((M + 63) / 64, (N + 63) / 64, ks), dim3(256), 0, s, x, (const float*)nullptr, W,
+                       (const float*)nullptr, (const float*)nullptr, parts, M, N, kr, (long long)kr, (long long)kr, 0LL, (long long)M * N, ldx, N, 0, K);
+  else
+    hipLaunchKernelGGL(small_linear_mfma_kernel<false>, dim3((M + 63) / 64, (N + 63) / 64, ks), dim3(256), 0, s, x, (const float*)nullptr, W,
+                       (const float*)nullptr, (const float*)nullptr, parts, M, N, kr, (long long)kr, (long long)kr, 0LL, (long long)M * N, ldx, N, 0, K);
   hipLaunchKernelGGL(sum_planes_kernel, dim3((M * N + 255) / 256), dim3(256), 0, s, parts, ks, b, resid, y, M, N, ldy);
   return psam_launch_status();
 }
@@ -161,8 +189,15 @@ extern "C" int psam_small_linear(const float* x, const float* x2, const float* W
   if (G <= 0 || M <= 0 || N <= 0 || (K % 64) != 0) return PSAM_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   if (M >= 32 && (K % 32) == 0) {
-    hipLaunchKernelGGL(small_linear_mfma_kernel, dim3((M + 63) / 64, (N + 63) / 64, G), dim3(256), 0, s, x, x2, W, b,
-                       resid, y, M, N, K, xg, wg, bg, yg, ldx, ldy, act, K);
+    static const int vec_on = [] { const char* e = getenv("PSAM_SMALL_LINEAR_VEC"); return e ? atoi(e) : 1; }();      // (0: element-wise loads, A/B)
+    const bool vec = vec_on && ((ldx | K) & 3) == 0 && ((xg | wg) & 3) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(x2)) & 15) == 0;
+    if (vec)
+      hipLaunchKernelGGL(small_linear_mfma_kernel<true>, dim3((M + 63) / 64, (N + 63) / 64, G), dim3(256), 0, s, x, x2, W, b,
+                         resid, y, M, N, K, xg, wg, bg, yg, ldx, ldy, act, K);
+    else
+      hipLaunchKernelGGL(small_linear_mfma_kernel<false>, dim3((M + 63) / 64, (N + 63) / 64, G), dim3(256), 0, s, x, x2, W, b,
+                         resid, y, M, N, K, xg, wg, bg, yg, ldx, ldy, act, K);
     return psam_launch_status();
   }
   dim3 grid((N + 3) / 4, G), block(256);
