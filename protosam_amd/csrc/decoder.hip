@@ -135,6 +135,26 @@ __global__ __launch_bounds__(256) void small_linear_mfma_kernel(const float* __r
   // acc[r]: n = n0 + wn*32 + (r&3) + 8*(r>>2) + 4*lk ; m = m0 + wm*32 + lr
   const int m = m0 + wm * 32 + lr;
   if (m >= M) return;
+  if (VEC && (N & 3) == 0) {      // (the launcher checked: bias / resid / y rows on 16-byte boundaries) four columns per 16-byte access
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = n0 + wn * 32 + 8 * q + 4 * lk;
+      if (n >= N) break;
+      float4 v = make_float4(acc[q * 4 + 0], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]);
+      if (b) {
+        const float4 bb = *reinterpret_cast<const float4*>(b + (size_t)g * bg + n);
+        v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+      }
+      if (act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      const size_t o = (size_t)g * yg + (size_t)m * ldy + n;
+      if (resid) {
+        const float4 r = *reinterpret_cast<const float4*>(resid + o);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+      }
+      *reinterpret_cast<float4*>(y + o) = v;
+    }
+    return;
+  }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int n = n0 + wn * 32 + 8 * q + 4 * lk;
@@ -171,7 +191,8 @@ extern "C" int psam_small_linear_splitk(const float* x, const float* W, const fl
   if (M <= 0 || N <= 0 || ks < 2 || (K % (64 * ks)) != 0 || !parts) return PSAM_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   const int kr = K / ks;
-  const bool vec = ((ldx | K | kr) & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W)) & 15) == 0;
+  const bool vec = ((ldx | K | kr) & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(parts)) & 15) == 0 &&
+                   (((long long)M * N) & 3) == 0;      // (the planes of `parts` are the groups' outputs, rows of N floats)
   if (vec)
     hipLaunchKernelGGL(small_linear_mfma_kernel<true>, dim3((M + 63) / 64, (N + 63) / 64, ks), dim3(256), 0, s, x, (const float*)nullptr, W,
                        (const float*)nullptr, (const float*)nullptr, parts, M, N, kr, (long long)kr, (long long)kr, 0LL, (long long)M * N, ldx, N, 0, K);
@@ -191,7 +212,9 @@ extern "C" int psam_small_linear(const float* x, const float* x2, const float* W
   if (M >= 32 && (K % 32) == 0) {
     static const int vec_on = [] { const char* e = getenv("PSAM_SMALL_LINEAR_VEC"); return e ? atoi(e) : 1; }();      // (0: element-wise loads, A/B)
     const bool vec = vec_on && ((ldx | K) & 3) == 0 && ((xg | wg) & 3) == 0 &&
-                     ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(x2)) & 15) == 0;
+                     ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(x2)) & 15) == 0 &&
+                     ((N & 3) != 0 || (((ldy | yg | bg) & 3) == 0 &&      // (N % 4 == 0: the epilogue moves four columns per access)
+                                       ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(resid)) & 15) == 0));
     if (vec)
       hipLaunchKernelGGL(small_linear_mfma_kernel<true>, dim3((M + 63) / 64, (N + 63) / 64, G), dim3(256), 0, s, x, x2, W, b,
                          resid, y, M, N, K, xg, wg, bg, yg, ldx, ldy, act, K);
