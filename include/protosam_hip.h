@@ -204,6 +204,16 @@ int psam_gemm_f32(const float* a, const float* a2, int a2_mod, const float* w, c
  * with bit 1 of kv_f32 set. M % nk == 0, N % hd == 0, hd % 4 == 0; no residual. */
 int psam_gemm_f32_heads(const float* a, const float* a2, int a2_mod, const float* w, const float* bias, float* out, int M, int N, int K,
                         int lda, int ldw, int nk, int hd, void* stream);
+
+/* psam_gemm_f32 / psam_gemm_f32_heads at fp32 accuracy on the fp16 matrix pipe (three v_mfma_f32_32x32x16_f16 products on (hi, lo) fp16
+ * halves, fp32 accumulation; the dropped lo x lo term is 2^-22 of a product): out[M,N] = (a [+ a2[m % a2_mod]]) @ (wh + wl)^T + bias
+ * [+ resid], the product times acc_scale. a / a2 / bias / resid / out fp32; wh / wl fp16 [N, ldw]: the halves of the fp32 weight times a
+ * power of two 2^s (so that the lo half of a small weight stays a normal fp16), split once by the caller (wh = half(w 2^s), wl =
+ * half(w 2^s - wh)); acc_scale = 2^-s. nk > 0: head-major output [M / nk][N / hd][nk][hd], no residual. K % 32 == 0, N % 64 == 0,
+ * every pointer 16-byte aligned. The image-token side of the two-way transformer (modeling/transformer.py:163-167,176-180,98-103,228-230)
+ * and the first transposed convolution of the upscaling (modeling/mask_decoder.py:137) as a GEMM. */
+int psam_gemm_f32x3(const float* a, const float* a2, int a2_mod, const void* wh, const void* wl, const float* bias, const float* resid,
+                    float* out, int M, int N, int K, int lda, int ldw, int ldo, int nk, int hd, float acc_scale, void* stream);
 /* y = [LayerNorm](x[src row] + add_vec); emits fp32 y, half y, half (y + pe[row % pe_mod]). With in_mod > 0 the input
  * is one [in_mod,256] embedding per image and prompt row/in_mod reads image img_of_prompt[prompt] (null: image 0).
  * mask_decoder.py:126-127; transformer.py:164,178,180 */

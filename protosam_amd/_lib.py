@@ -52,6 +52,7 @@ SIGNATURES = {
     "psam_t2i_attention_split": [c_void_p] * 4 + [c_int] * 6 + [c_void_p] * 2,
     "psam_gemm_f32": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p],
     "psam_gemm_f32_heads": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p],
+    "psam_gemm_f32x3": [c_void_p, c_void_p, c_int] + [c_void_p] * 5 + [c_int] * 8 + [c_float, c_void_p],
     "psam_small_linear_splitk": [c_void_p] * 6 + [c_int] * 6 + [c_void_p],
     "psam_ln_pe": [c_void_p] * 8 + [c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p],
     "psam_dense_pe": [c_void_p, c_int, c_int, c_void_p, c_void_p],

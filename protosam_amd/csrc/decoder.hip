@@ -346,6 +346,140 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   }
 }
 
+// gemm_f32x3: the same product at fp32 accuracy on the fp16 matrix pipe. a = ah + al and w = wh + wl (h = fp16(.), l = fp16(. - h): 22
+// significant bits each), out = sum_k ah wh + ah wl + al wh in fp32 accumulation - the dropped al wl is 2^-22 of a term, like the
+// rounding of the split itself (measured against a float64 product: tests/test_sam_gpu.py). Three v_mfma_f32_32x32x16_f16 (3 x 16 k per
+// 32 cycles) replace eight v_mfma_f32_32x32x2_f32 (8 x 2 k per 64 cycles each): the matrix time of a tile drops 5x and the launch is
+// bound by its bytes (the fp32 form: 82 us for 170 MB at 27 prompt sets, 0.45 of the fp32-MFMA rate). The image-token operand is split in
+// registers on its way to LDS (never in HBM), the weights are split once by the caller (psam_split_f16). 64 x BN tiles, k slabs of 32,
+// W as the MFMA's A operand (a lane ends up with 4 consecutive output columns of one row, as gemm_f32_kernel).
+#define G3_LD 40      // halfs per LDS row: 80 bytes - the 16-byte fragment reads of 32 consecutive rows touch every bank once
+template <int BN>
+__global__ __launch_bounds__(256) void gemm_f32x3_kernel(const float* __restrict__ a, const float* __restrict__ a2, int a2_mod,
+                                                         const half_t* __restrict__ wh, const half_t* __restrict__ wl,
+                                                         const float* __restrict__ bias, const float* resid,
+                                                         float* out, int M, int N, int K, int lda, int ldw, int ldo,
+                                                         int hm_nk, int hm_hd, float acc_scale) {      // (resid may be out: the in-place residual update)
+  constexpr int BM = 64, NI = BN / 64;                 // 32x32 blocks per wave along n (waves 2 x 2: 32 rows x BN / 2 columns each)
+  constexpr int WV = BN * 32 / 8 / 256;                // 16-byte pieces of a W slab (hi or lo) per thread
+  __shared__ __attribute__((aligned(16))) half_t Ah[BM * G3_LD], Al[BM * G3_LD], Wh[BN * G3_LD], Wl[BN * G3_LD];
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, lr = lane & 31, lk = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  f32x16 acc[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  const int arow = t >> 2, ac = (t & 3) * 8;           // this thread's 8 consecutive k of one A row
+  const int am = m0 + arow;
+  const float* ap = a + (size_t)(am < M ? am : 0) * lda + ac;
+  const float* a2p = a2 ? a2 + (size_t)((am < M ? am : 0) % a2_mod) * lda + ac : nullptr;
+  float4 av0, av1;
+  half8_t wvh[WV], wvl[WV];
+  auto load_slab = [&](int k0) {
+    av0 = make_float4(0.f, 0.f, 0.f, 0.f); av1 = av0;
+    if (am < M) {
+      av0 = *reinterpret_cast<const float4*>(ap + k0);
+      av1 = *reinterpret_cast<const float4*>(ap + k0 + 4);
+      if (a2p) {
+        const float4 p0 = *reinterpret_cast<const float4*>(a2p + k0), p1 = *reinterpret_cast<const float4*>(a2p + k0 + 4);
+        av0.x += p0.x; av0.y += p0.y; av0.z += p0.z; av0.w += p0.w;
+        av1.x += p1.x; av1.y += p1.y; av1.z += p1.z; av1.w += p1.w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WV; ++i) {
+      const int idx = t + 256 * i, row = idx >> 2, c8 = (idx & 3) * 8;
+      wvh[i] = *reinterpret_cast<const half8_t*>(wh + (size_t)(n0 + row) * ldw + k0 + c8);   // N % BN == 0
+      wvl[i] = *reinterpret_cast<const half8_t*>(wl + (size_t)(n0 + row) * ldw + k0 + c8);
+    }
+  };
+  load_slab(0);
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    __syncthreads();   // every wave is done reading the previous slab
+    {
+      const float v[8] = {av0.x, av0.y, av0.z, av0.w, av1.x, av1.y, av1.z, av1.w};
+      half8_t h, l;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        h[i] = (half_t)v[i];
+        l[i] = (half_t)(v[i] - (float)h[i]);
+      }
+      *reinterpret_cast<half8_t*>(Ah + arow * G3_LD + ac) = h;
+      *reinterpret_cast<half8_t*>(Al + arow * G3_LD + ac) = l;
+    }
+#pragma unroll
+    for (int i = 0; i < WV; ++i) {
+      const int idx = t + 256 * i, row = idx >> 2, c8 = (idx & 3) * 8;
+      *reinterpret_cast<half8_t*>(Wh + row * G3_LD + c8) = wvh[i];
+      *reinterpret_cast<half8_t*>(Wl + row * G3_LD + c8) = wvl[i];
+    }
+    __syncthreads();
+    if (k0 + 32 < K) load_slab(k0 + 32);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int xo = (wm * 32 + lr) * G3_LD + ks * 16 + lk * 8;
+      const half8_t xh = *reinterpret_cast<const half8_t*>(Ah + xo), xl = *reinterpret_cast<const half8_t*>(Al + xo);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int wo = (wn * (BN / 2) + j * 32 + lr) * G3_LD + ks * 16 + lk * 8;
+        const half8_t fh = *reinterpret_cast<const half8_t*>(Wh + wo), fl = *reinterpret_cast<const half8_t*>(Wl + wo);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl, xh, acc[j], 0, 0, 0);     // (the two small products first)
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, xl, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, xh, acc[j], 0, 0, 0);
+      }
+    }
+  }
+  // acc[j][r]: m = m0 + wm*32 + lr ; n = n0 + wn*BN/2 + j*32 + (r&3) + 8*(r>>2) + 4*lk
+  const int m = m0 + wm * 32 + lr;
+  if (m >= M) return;
+#pragma unroll
+  for (int j = 0; j < NI; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = n0 + wn * (BN / 2) + j * 32 + 8 * q + 4 * lk;
+      float4 v = make_float4(acc[j][4 * q] * acc_scale, acc[j][4 * q + 1] * acc_scale, acc[j][4 * q + 2] * acc_scale, acc[j][4 * q + 3] * acc_scale);
+      if (bias) {
+        const float4 b = *reinterpret_cast<const float4*>(bias + n);
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+      }
+      if (resid) {
+        const float4 r = *reinterpret_cast<const float4*>(resid + (size_t)m * ldo + n);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+      }
+      if (hm_nk > 0) {   // head-major: out[image = m / nk][head = n / hd][m % nk][n % hd] (psam_gemm_f32_heads)
+        const size_t o = ((size_t)(m / hm_nk) * (N / hm_hd) + n / hm_hd) * hm_nk * hm_hd + (size_t)(m % hm_nk) * hm_hd + n % hm_hd;
+        *reinterpret_cast<float4*>(out + o) = v;
+      } else {
+        *reinterpret_cast<float4*>(out + (size_t)m * ldo + n) = v;
+      }
+    }
+}
+
+// acc_scale: the weights may be split after a scaling by a power of two (wh + wl = w * 2^s: a weight of 0.05 has a SUBNORMAL fp16 lo half
+// - absolute resolution 2^-25 instead of 2^-22 relative; times 256 it is normal down to |w| = 5e-4) - acc_scale = 2^-s undoes it, exactly.
+// out[M,N] = acc_scale * (a [+ a2[m % a2_mod]]) @ (wh + wl)^T + bias [+ resid]: a / bias / resid / out fp32, wh / wl the fp16 halves of the fp32
+// weight (psam_split_f16). nk > 0: head-major output [M / nk][N / hd][nk][hd] (no residual), as psam_gemm_f32_heads.
+extern "C" int psam_gemm_f32x3(const float* a, const float* a2, int a2_mod, const void* wh, const void* wl, const float* bias,
+                               const float* resid, float* out, int M, int N, int K, int lda, int ldw, int ldo, int nk, int hd,
+                               float acc_scale, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || (K % 32) || (N % 64) || (lda % 4) || (ldw % 8) || (ldo % 4) || (a2 && a2_mod <= 0) || !wh || !wl)
+    return PSAM_ERR_ARG;
+  if (nk > 0 && (hd <= 0 || (hd % 4) || (N % hd) || (M % nk) || resid)) return PSAM_ERR_ARG;
+  if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(a2) | reinterpret_cast<uintptr_t>(wh) | reinterpret_cast<uintptr_t>(wl) |
+       reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(resid) | reinterpret_cast<uintptr_t>(out)) & 15)
+    return PSAM_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (N % 128 == 0)
+    hipLaunchKernelGGL((gemm_f32x3_kernel<128>), dim3((M + 63) / 64, N / 128), dim3(256), 0, s, a, a2, a2_mod, (const half_t*)wh,
+                       (const half_t*)wl, bias, resid, out, M, N, K, lda, ldw, ldo, nk, hd, acc_scale);
+  else
+    hipLaunchKernelGGL((gemm_f32x3_kernel<64>), dim3((M + 63) / 64, N / 64), dim3(256), 0, s, a, a2, a2_mod, (const half_t*)wh,
+                       (const half_t*)wl, bias, resid, out, M, N, K, lda, ldw, ldo, nk, hd, acc_scale);
+  return psam_launch_status();
+}
+
 static int gemm_f32_launch(const float* a, const float* a2, int a2_mod, const float* w, const float* bias,
                            const float* resid, float* out, int M, int N, int K, int lda, int ldw, int ldo, int hm_nk, int hm_hd, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || (K % 32) || (N % 64) || (lda % 4) || (ldw % 4) || (ldo % 4) || (a2 && a2_mod <= 0))

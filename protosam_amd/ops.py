@@ -632,11 +632,14 @@ def split_f16(x, hi=None, lo=None, write_hi=True):
     return hi, lo
 
 
-def split_weight_f16(w):
-    """fp32 weight -> (hi, lo) fp16 pair (one-time packing)."""
-    w = w.detach().float()
+def split_weight_f16(w, scale=1.0):
+    """fp32 weight -> (hi, lo) fp16 pair of w * scale (one-time packing; scale a power of two: gemm_f32x3 undoes it)."""
+    w = w.detach().float() * scale
     hi = w.half()
     return hi.contiguous(), (w - hi.float()).half().contiguous()
+
+
+X3_WEIGHT_SCALE = 256.0      # gemm_f32x3: weights are split as w * 2^8 (a lo half is a normal fp16 down to |w| = 5e-4; |w| < 255)
 
 
 # ---- SAM prompt encoder / mask decoder -----------------------------------------------------------------------
@@ -746,6 +749,34 @@ def gemm_f32(a, w, bias=None, out=None, resid=None, a2=None, a2_mod=0, heads=Non
     st = _lib.lib().psam_gemm_f32(_ptr(a), _ptr(a2), a2_mod, _ptr(w), _ptr(bias), _ptr(resid), _ptr(out), M, N, K,
                                  a.stride(0), w.stride(0), out.stride(0), _stream())
     _lib.check(st, "psam_gemm_f32")
+    return out
+
+
+def gemm_f32x3(a, w_split, bias=None, out=None, resid=None, a2=None, a2_mod=0, heads=None):
+    """gemm_f32 at fp32 accuracy on the fp16 matrix pipe: w_split = split_weight_f16(w) - the (hi, lo) fp16 halves of the fp32 weight;
+    a (fp32) is split on chip, three MFMA products per k step, fp32 accumulation (psam_gemm_f32x3). heads = (nk, hd) as gemm_f32.
+    w_split may carry a third element: the power of two the weight was scaled by before the split (default 1)."""
+    wh, wl = w_split[0], w_split[1]
+    wscale = float(w_split[2]) if len(w_split) > 2 else 1.0
+    _req(a, torch.float32, "a"); _req(wh, torch.float16, "wh"); _req(wl, torch.float16, "wl"); _req(bias, torch.float32, "bias")
+    _req(resid, torch.float32, "resid"); _req(a2, torch.float32, "a2")
+    assert a.dim() == 2 and wh.dim() == 2 and wh.shape == wl.shape and wh.shape[1] == a.shape[1] and wh.stride(0) == wl.stride(0)
+    M, K = a.shape
+    N = wh.shape[0]
+    assert a2 is None or (a2.stride(0) == a.stride(0) and a2_mod > 0)
+    nk, hd = heads if heads is not None else (0, 0)
+    if heads is not None:
+        assert resid is None and out is not None and out.dtype == torch.float32 and out.is_contiguous() and out.numel() >= M * N
+        ldo = N
+    else:
+        if out is None:
+            out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+        _req(out, torch.float32, "out")
+        assert out.shape == (M, N) and (resid is None or (resid.shape == (M, N) and resid.stride(0) == out.stride(0)))
+        ldo = out.stride(0)
+    st = _lib.lib().psam_gemm_f32x3(_ptr(a), _ptr(a2), a2_mod, _ptr(wh), _ptr(wl), _ptr(bias), _ptr(resid), _ptr(out), M, N, K,
+                                   a.stride(0), wh.stride(0), ldo, nk, hd, 1.0 / wscale, _stream())
+    _lib.check(st, "psam_gemm_f32x3")
     return out
 
 

@@ -53,6 +53,9 @@ class MaskDecoder(nn.Module):
         self._cache = None
         self._ws = {}
         self.image_side_fp16 = False   # True: fp16-operand MFMA GEMMs on the image side (faster for >= 256 prompt sets, ~1e-3)
+        # the image side's fp32 products as three fp16 MFMA products on (hi, lo) halves (ops.gemm_f32x3: fp32 accuracy to 2^-22 per term,
+        # the fp16 matrix pipe instead of the 16x slower fp32 one); PSAM_DECODER_X3=0 / `image_side_x3 = False`: the exact-fp32 MFMA kernel
+        self.image_side_x3 = os.environ.get("PSAM_DECODER_X3", "1") != "0"
 
     def _apply(self, fn, *a, **k):
         self._cache, self._ws = None, {}
@@ -70,6 +73,7 @@ class MaskDecoder(nn.Module):
         mods = {"qw": a.q_proj, "kw": a.k_proj, "vw": a.v_proj, "ow": a.out_proj}
         for nm in image_side:  # projections applied to the 4096 image tokens run as fp16 MFMA GEMMs
             d[nm + "16"] = f16(mods[nm].weight)
+            d[nm + "x3"] = ops.split_weight_f16(mods[nm].weight, ops.X3_WEIGHT_SCALE) + (ops.X3_WEIGHT_SCALE,)      # (hi, lo, scale) for ops.gemm_f32x3
         return d
 
     def _packed(self):
@@ -91,6 +95,7 @@ class MaskDecoder(nn.Module):
         # ConvTranspose2d weight [in, out, kh, kw]: GEMM row (dy*2+dx)*64 + co  <-  W[:, co, dy, dx]
         pk["up1_w16"] = f16(up0.weight.permute(2, 3, 1, 0).reshape(4 * 64, 256))
         pk["up1_w"] = f32(up0.weight.permute(2, 3, 1, 0).reshape(4 * 64, 256))
+        pk["up1_wx3"] = ops.split_weight_f16(pk["up1_w"], ops.X3_WEIGHT_SCALE) + (ops.X3_WEIGHT_SCALE,)
         pk["up1_b"] = f32(up0.bias).repeat(4).contiguous()
         pk["up_lnw"], pk["up_lnb"] = f32(ln.weight), f32(ln.bias)
         pk["up2_w"] = f32(up3.weight.permute(0, 2, 3, 1).reshape(64, 4 * 32))  # [c, (dy2*2+dx2)*32 + c2]
@@ -140,6 +145,7 @@ class MaskDecoder(nn.Module):
         tok2 = tokens.reshape(B * T, 256).contiguous()  # query_pe (transformer.py:88-96)
         lin = ops.small_linear
         h16 = self.image_side_fp16
+        x3 = self.image_side_x3 and not h16
         ops.ln_pe(feat_tok, pe_tok, B * Nk, y32=keys, y16=k16, ype16=kpe16, add_vec=dense_vec, in_mod=Nk, pe_mod=Nk,
                   img_of_prompt=img_of_prompt)
 
@@ -148,6 +154,8 @@ class MaskDecoder(nn.Module):
             written head-major [B][NH][Nk][hd] for the token-to-image attention kernel"""
             if h16:
                 ops.gemm(kpe16 if with_pe else k16, ap[w_name + "16"], ap[w_name[0] + "b"], out=out, epilogue=ops.EPI_F16)
+            elif x3:
+                ops.gemm_f32x3(keys, ap[w_name + "x3"], ap[w_name[0] + "b"], out=out, a2=pe_tok if with_pe else None, a2_mod=Nk, heads=heads)
             else:
                 ops.gemm_f32(keys, ap[w_name], ap[w_name[0] + "b"], out=out, a2=pe_tok if with_pe else None, a2_mod=Nk, heads=heads)
 
@@ -191,6 +199,8 @@ class MaskDecoder(nn.Module):
                                 256, 256, 128)
             if h16:
                 ops.gemm(ws["p1"], ia["ow16"], ia["ob"], out=keys, epilogue=ops.EPI_F32, resid=keys)
+            elif x3:
+                ops.gemm_f32x3(ws["p1"], ia["owx3"], ia["ob"], out=keys, resid=keys)
             else:
                 ops.gemm_f32(ws["p1"], ia["ow"], ia["ob"], out=keys, resid=keys)
             ops.ln_pe(keys, pe_tok, B * Nk, y32=keys, y16=k16, ype16=kpe16, w=L["n"][3][0], b=L["n"][3][1], pe_mod=Nk,
@@ -200,6 +210,8 @@ class MaskDecoder(nn.Module):
         # output upscaling + hyper-networks (mask_decoder.py:137-144) and IoU head (:147)
         if h16:
             ops.gemm(k16, pk["up1_w16"], pk["up1_b"], out=ws["u1"], epilogue=ops.EPI_F32)
+        elif x3:
+            ops.gemm_f32x3(keys, pk["up1_wx3"], pk["up1_b"], out=ws["u1"])
         else:
             ops.gemm_f32(keys, pk["up1_w"], pk["up1_b"], out=ws["u1"])
         hx = hs[:, 1:5]

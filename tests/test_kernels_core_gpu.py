@@ -739,3 +739,49 @@ def test_gemm_position_table_residual_on_the_assembly_tile(dev, M, N, K, mod, ln
         assert torch.equal(outs[0], outs[1])
     finally:
         ops.gemm_set_tile(0)
+
+
+@pytest.mark.parametrize("M,N,K,mode", [(2 * 4096, 128, 256, "pe_heads"), (8192 + 37, 256, 128, "resid"), (1000, 64, 32, "plain"),
+                                        (3 * 4096, 256, 256, "plain"), (4096, 128, 256, "tiny")])
+def test_gemm_f32x3_matches_fp32_accuracy(dev, M, N, K, mode):
+    """psam_gemm_f32x3 (three fp16 MFMA products on (hi, lo) halves, fp32 accumulation) against a float64 product of the fp32 operands:
+    within a few 2^-22 of the sum of |a| |w| terms - the accuracy class of the exact-fp32 MFMA kernel it replaces on the decoder's image
+    side, three orders of magnitude tighter than fp16 operands - with the fused position add, head-major output, in-place residual,
+    a ragged last tile, and operands whose lo halves are fp16 subnormals."""
+    from protosam_amd import ops
+    scale = 1e-3 if mode == "tiny" else 1.0
+    a = (_rand((M, K), dev, 2.0, 101) * scale).contiguous()
+    w = (_rand((N, K), dev, 0.08, 102) * scale).contiguous()
+    bias = _rand((N,), dev, 0.5, 103) * scale * scale
+    ws = ops.split_weight_f16(w, 256.0) + (256.0,)
+    a2 = _rand((4096, K), dev, 1.0, 104).contiguous() if mode == "pe_heads" else None
+    ad = a.double() + (a2.double().repeat(M // 4096, 1) if a2 is not None else 0)
+    ref = ad @ w.double().t() + bias.double()
+    mag = ad.abs() @ w.double().abs().t() + bias.double().abs()            # sum of the terms' magnitudes: the scale of the rounding error
+    if mode == "resid":
+        x = _rand((M, N), dev, 1.0, 105).contiguous()
+        ref = ref + x.double()
+        out = x.clone()
+        ops.gemm_f32x3(a, ws, bias, out=out, resid=out)
+        exact = ops.gemm_f32(a, w, bias, out=x.clone(), resid=x)
+    elif mode == "pe_heads":
+        nk, hd = 4096, 16
+        out = torch.full((M * N,), float("nan"), device=dev)
+        ops.gemm_f32x3(a, ws, bias, out=out, a2=a2, a2_mod=4096, heads=(nk, hd))
+        out = out.view(M // nk, N // hd, nk, hd).permute(0, 2, 1, 3).reshape(M, N)
+        exact = ops.gemm_f32(a, w, bias, a2=a2, a2_mod=4096)
+    else:
+        out = torch.full((M, N), float("nan"), device=dev)
+        ops.gemm_f32x3(a, ws, bias, out=out)
+        exact = ops.gemm_f32(a, w, bias)
+    # operand resolution of the split: 2^-22 relative, or 2^-25 absolute where the lo half is an fp16 subnormal (|a| < 1/8; |w| < 2^-11
+    # after the weights' scaling by 2^8)
+    floor = 2.0 ** -25 * w.double().abs().sum(1)[None, :] + 2.0 ** -33 * ad.abs().sum(1)[:, None]
+    assert bool(((out.double() - ref).abs() <= 6 * 2.0 ** -22 * mag + 2 * floor).all())
+    err = ((out.double() - ref).abs() / mag).max().item()
+    err_exact = ((exact.double() - ref).abs() / mag).max().item()
+    err_f16 = (((a.half().float() + (a2.half().float().repeat(M // 4096, 1) if a2 is not None else 0)).double() @ w.half().double().t()
+                + bias.double() + (x.double() if mode == "resid" else 0) - ref).abs() / mag).max().item()
+    if mode != "tiny":
+        assert err < 8 * 2.0 ** -22, (err, err_exact, err_f16)
+    assert err < err_f16 / (10 if mode == "tiny" else 100), (err, err_f16)
