@@ -755,13 +755,24 @@ def main():
     check_amg(gold)
     check_rotate(gold)
     import tempfile
+    modules = {}
     with tempfile.TemporaryDirectory() as tmpdir:
         check_orchestration(gold, tmpdir)
+        if args.write_golden:
+            # the container modules' own forwards and the helper methods by name (tests/test_module_forwards_gpu.py)
+            from oracle import make_module_goldens
+            make_module_goldens.record(modules, tmpdir)
     if args.write_golden:
         os.makedirs(GOLD, exist_ok=True)
-        path = os.path.join(GOLD, "reference_outputs.npz")
-        np.savez_compressed(path, **gold)
-        print(f"wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB, {len(gold)} arrays)")
+        for fname, arrays in (("reference_outputs.npz", gold), ("reference_modules.npz", modules)):
+            path = os.path.join(GOLD, fname)
+            if os.path.exists(path):        # leave a file whose arrays are all unchanged alone (no churn in the history)
+                old = np.load(path)
+                if set(old.files) == set(arrays) and all(np.array_equal(old[k], np.asarray(arrays[k])) for k in arrays):
+                    print(f"{path}: unchanged ({len(arrays)} arrays)")
+                    continue
+            np.savez_compressed(path, **arrays)
+            print(f"wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB, {len(arrays)} arrays)")
     print("ALL CHECKS PASSED")
 
 

@@ -1659,7 +1659,8 @@ static int gemm_dispatch(const void* A, const void* W, const float* bias, void* 
   const bool lnf = ln_prod || ln_cons;
   // tile 13: 64x64 tiles where the 128x128 tiles would leave more than half of the CUs idle (gemm_f16_s64_kernel); psam_gemm_set_option("small", 0)
   // / PSAM_GEMM_SMALL=0 keeps the larger tiles; psam_gemm_set_tile(13) forces it
-  if ((tsel == 13 || (tsel == 1 && g_tile_override <= 0 && gemm_option(OPT_SMALL) && (int)grid.x * 2 <= num_cus())) && !lnf && K >= 64 &&
+  // (its epilogue has no head-major plane addressing: psam_gemm_f16_heads stays on the 128-tile kernel)
+  if ((tsel == 13 || (tsel == 1 && g_tile_override <= 0 && gemm_option(OPT_SMALL) && (int)grid.x * 2 <= num_cus())) && !lnf && !head_hd && K >= 64 &&
       epilogue != EPI_RELU_F16 && (epilogue == EPI_F32 || (ldo % 4) == 0)) {
     switch (epilogue) {
       case EPI_F16: launch_s64<EPI_F16>(p, s); break;

@@ -634,9 +634,25 @@ def split_f16(x, hi=None, lo=None, write_hi=True):
 
 def split_weight_f16(w, scale=1.0):
     """fp32 weight -> (hi, lo) fp16 pair of w * scale (one-time packing; scale a power of two: gemm_f32x3 undoes it)."""
-    w = w.detach().float() * scale
+    w = w.detach().float()
+    # |w * scale| must stay inside fp16 (hi = inf, lo = -inf, NaN products otherwise): halve the scale until it does
+    amax = float(w.abs().max()) if w.numel() else 0.0
+    if not amax < float("inf"):
+        raise ValueError("split_weight_f16: non-finite weight")
+    if amax * scale >= 6.0e4:
+        raise ValueError(f"split_weight_f16: max |w| = {amax:.4g} times the scale {scale:g} overflows fp16; use `split_scale_for(w)`")
+    w = w * scale
     hi = w.half()
     return hi.contiguous(), (w - hi.float()).half().contiguous()
+
+
+def split_scale_for(w, want=256.0):
+    """the largest power of two <= `want` that keeps max |w| * scale below the fp16 range (gemm_f32x3's weight scale)"""
+    amax = float(w.detach().abs().max()) if w.numel() else 0.0
+    s = float(want)
+    while s > 2.0 ** -14 and amax * s >= 6.0e4:
+        s *= 0.5
+    return s
 
 
 X3_WEIGHT_SCALE = 256.0      # gemm_f32x3: weights are split as w * 2^8 (a lo half is a normal fp16 down to |w| = 5e-4; |w| < 255)
@@ -681,9 +697,9 @@ def t2i_split(B, NH, T, Nk, n_cu=256):
     """into how many key ranges a token-to-image attention launch is split (PSAM_T2I_SPLIT: "auto", or a number to force): the unsplit
     launch has B * NH workgroups whose waves each walk all keys, 64 dependent round trips"""
     mode = _os.environ.get("PSAM_T2I_SPLIT", "auto")
-    if T > 16 or Nk < 512 or mode == "0":
+    if T > 16 or Nk < 512 or mode in ("0", "1"):        # (a forced count of 1 is one range: no split)
         return 1
-    if mode != "auto" and mode != "1":
+    if mode != "auto":
         return max(1, min(16, Nk // 256, int(mode)))
     return max(1, min(16, Nk // 256, n_cu // (B * NH)))
 
@@ -694,6 +710,8 @@ def t2i_attention(q, K, V, out, B, T, Nk, NH, head_major=False, split=None):
     B * NH * S * T * 18 elements."""
     _req(q, torch.float32, "q"); _req(K, K.dtype, "K"); _req(V, K.dtype, "V"); _req(out, torch.float32, "out")
     assert K.dtype in (torch.float16, torch.float32)
+    if q.shape[-1] != NH * 16:     # the kernels (and the head-major K / V layout) are written for 16-wide heads: C = NH * 16
+        raise ValueError(f"psam_t2i_attention: head size {q.shape[-1]}/{NH} is not 16 (SAM: 128 channels, 8 heads)")
     flags = (1 if K.dtype == torch.float32 else 0) | (2 if head_major else 0)
     if split is not None and split[0] > 1:
         S, part = split

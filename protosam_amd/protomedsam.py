@@ -55,6 +55,85 @@ class ProtoMedSAM(nn.Module):
         else:
             self.medsam = sam_model_registry[model_type](checkpoint=checkpoint_path).eval()
 
+    # ---- the reference's helper methods by name (ProtoMedSAM.py:31-120,224-249); `forward` does their work inside fused kernels ----
+    @torch.no_grad()
+    def medsam_inference(self, img_embed, box_1024, H, W, query_label=None):
+        """ProtoMedSAM.py:31-66: box prompts [B,4] (XYXY in the 1024 frame) on ONE image embedding [1,256,64,64] -> (uint8 masks as
+        numpy - `squeeze()`d like the reference: [H,W] for one box - , conf numpy [B,C]); sigmoid BEFORE the bilinear resize, 0.5
+        threshold. With `query_label` the decoder returns its three masks and the one with the best IoU against the label is kept
+        (`get_best_mask`), as [1,H,W]."""
+        sam = self.medsam
+        box_torch = torch.as_tensor(box_1024, dtype=torch.float, device=img_embed.device)
+        if len(box_torch.shape) == 2:
+            box_torch = box_torch[:, None, :]                                           # (B, 1, 4)
+        sparse, dense = sam.prompt_encoder(points=None, boxes=box_torch, masks=None)
+        low, conf = sam.mask_decoder(image_embeddings=img_embed, image_pe=sam.prompt_encoder.get_dense_pe(),
+                                     sparse_prompt_embeddings=sparse, dense_prompt_embeddings=dense,
+                                     multimask_output=True if query_label is not None else False)
+        if H != W:
+            raise NotImplementedError("medsam_inference: square outputs (psam_mask_union)")
+        low = low.contiguous()
+        n, C = low.shape[:2]
+        segs = torch.stack([ops.mask_union(low[i:i + 1], c, int(H), int(H), 3, 0.5) for i in range(n) for c in range(C)])
+        medsam_seg = segs.view(n, C, H, W).squeeze().to(torch.uint8).cpu().numpy()
+        if query_label is not None:
+            medsam_seg = self.get_best_mask(medsam_seg, query_label)[None, :]
+        return medsam_seg, conf.cpu().detach().numpy()
+
+    def get_iou(self, pred, label):
+        """ProtoMedSAM.py:68-77 (numpy uint8 [h,w] each)."""
+        tp = np.logical_and(pred, label).sum()
+        fp = np.logical_and(pred, 1 - label).sum()
+        fn = np.logical_and(1 - pred, label).sum()
+        return tp / (tp + fp + fn)
+
+    def get_best_mask(self, masks, labels):
+        """ProtoMedSAM.py:79-92: masks numpy [B,h,w], labels tensor [1,H,W] -> the mask with the largest IoU (None when every IoU is 0)."""
+        np_labels = labels[0].clone().detach().cpu().numpy()
+        best_iou, best_mask = 0, None
+        for mask in masks:
+            iou = self.get_iou(mask, np_labels)
+            if iou > best_iou:
+                best_iou, best_mask = iou, mask
+        return best_mask
+
+    def get_bbox(self, pred):
+        """ProtoMedSAM.py:94-106: [xmin, ymin, xmax, ymax] of the non-zero pixels of pred [H,W] (tensor or numpy), None when empty."""
+        if isinstance(pred, np.ndarray):
+            pred = torch.from_numpy(pred)
+        if pred.max() == 0:
+            return None
+        indices = torch.nonzero(pred)
+        ymin, xmin = indices.min(dim=0)[0]
+        ymax, xmax = indices.max(dim=0)[0]
+        return np.array([int(xmin), int(ymin), int(xmax), int(ymax)])
+
+    def get_bbox_per_cc(self, conn_components):
+        """ProtoMedSAM.py:109-120: one XYXY box per label 1 ... n-1 of a cv2-style `(n, labels, stats, centroids)` tuple
+        (protosam_amd.utils.cca / get_connected_components)."""
+        return np.array([self.get_bbox(torch.as_tensor(np.asarray(conn_components[1]) == i).to(torch.uint8))
+                         for i in range(1, conn_components[0])])
+
+    @torch.no_grad()
+    def segment_all(self, query_image, query_label):
+        """ProtoMedSAM.py:224-249: the whole-image box [0,0,W,H] as the prompt, three masks, the one closest to `query_label` kept.
+        query_image [1,3,1024,1024] on the device (the reference hands it to the image encoder as it is)."""
+        H, W = query_image.shape[-2:]
+        sam = self.medsam
+        S = sam.image_encoder.img_size
+        if (H, W) != (S, S):
+            raise ValueError(f"segment_all: the image encoder takes {S} x {S} images, got {(H, W)}")      # (the reference's encoder asserts)
+        bbox = np.array([[0, 0, W, H]])
+        bufs = self._work(query_image.device)
+        q = query_image.float().contiguous()
+        ops.minmax(q, 1, mm=bufs["mm"])                                                  # (x - min) / (max - min), :230
+        ops.sam_patchify(q, bufs["mm"], S, sam.image_encoder.patch_size, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), False, out=bufs["patches"])
+        g = sam.image_encoder.grid
+        emb = sam.image_encoder.encode_patches(bufs["patches"], 1).view(1, g, g, -1).permute(0, 3, 1, 2)
+        medsam_seg, conf = self.medsam_inference(emb, bbox, H, W, query_label)
+        medsam_seg = torch.tensor(medsam_seg, device=query_image.device)
+        return medsam_seg.view(H, W), [conf]
+
     def _work(self, dev):
         if not self._bufs:
             self._bufs = dict(fg_sum=torch.zeros(1, dtype=torch.int32, device=dev),

@@ -23,6 +23,22 @@ class PatchEmbed(nn.Module):
         super().__init__()
         self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=kernel_size, stride=stride, padding=padding)
 
+    @torch.no_grad()
+    def forward(self, x):
+        """image_encoder.py:402-406: x [B,3,H,W] -> [B,H/P,W/P,embed_dim] (conv with stride = kernel as im2col + `psam_gemm_f16`;
+        square images and a square, unpadded kernel - SAM's configuration)."""
+        B, C, H, W = x.shape
+        P = self.proj.kernel_size[0]
+        if self.proj.kernel_size != (P, P) or self.proj.stride != (P, P) or self.proj.padding != (0, 0) or H != W or H % P:
+            raise NotImplementedError("PatchEmbed.forward: square image, square kernel = stride, no padding (build_sam.py:66-81)")
+        D = self.proj.out_channels
+        K = C * P * P
+        patches = ops.patchify_bilinear(x.float().contiguous(), H, P, (K + 63) // 64 * 64)       # (same size: the identity resample)
+        w = torch.zeros((D, patches.shape[1]), dtype=torch.float16, device=x.device)
+        w[:, :K] = self.proj.weight.detach().reshape(D, K).half()
+        out = ops.gemm(patches, w, f32(self.proj.bias), epilogue=ops.EPI_F32)
+        return out.view(B, H // P, W // P, D)
+
 
 class Attention(nn.Module):
     def __init__(self, dim, num_heads=8, qkv_bias=True, use_rel_pos=False, rel_pos_zero_init=True, input_size=None):
@@ -38,6 +54,47 @@ class Attention(nn.Module):
             self.rel_pos_h = nn.Parameter(torch.zeros(2 * input_size[0] - 1, head_dim))
             self.rel_pos_w = nn.Parameter(torch.zeros(2 * input_size[1] - 1, head_dim))
 
+    def _attend(self, qkv, B, g, ws, rpack, pad_row, out=None, relq=None, rel_bufs=None):
+        """The attention of one block on the packed projection qkv fp16 [B*g*g, 3*dim] of a g x g token map: ws > 0 the 14 x 14 windows
+        (zero padding and un-partition as index math, image_encoder.py:254-300), else global; decomposed rel-pos inside the kernels
+        where they compute it themselves, through `psam_relpos` elsewhere (:303-372). -> fp16 [B*g*g, dim]."""
+        H = self.num_heads
+        N = g * g
+        hd = qkv.shape[-1] // (3 * H)
+        hm = ops.QKV_HEAD_MAJOR
+        if ws > 0:
+            if ops.FUSE_WINDOW_RELPOS:   # the query-side rel-pos terms are computed inside the attention kernel
+                return ops.attention(qkv, B, N, H, hd, self.scale, out=out, mode=2, rpack=rpack, pad_row=pad_row, gh=g, gw=g, ws=ws,
+                                     head_major=hm)
+            relq = ops.relpos(qkv, rpack, B, N, H, hd, g, ws, True, self.scale, relq=relq, head_major=hm)
+            return ops.attention(qkv, B, N, H, hd, self.scale, out=out, mode=2, relq=relq, pad_row=pad_row, gh=g, gw=g, ws=ws,
+                                 head_major=hm)
+        if ops.attention_fused_relpos(B, N, H, hd, g, g):   # rel_h / rel_w computed inside the attention kernel (round 5)
+            return ops.attention(qkv, B, N, H, hd, self.scale, out=out, mode=1, rpack=rpack, gh=g, gw=g)
+        relh, relw = rel_bufs() if rel_bufs is not None else (None, None)
+        relh, relw = ops.relpos(qkv, rpack, B, N, H, hd, g, g, False, self.scale, rel_h=relh, rel_w=relw, head_major=hm)
+        return ops.attention(qkv, B, N, H, hd, self.scale, out=out, mode=1, rel_h=relh, rel_w=relw, gh=g, gw=g, head_major=hm)
+
+    @torch.no_grad()
+    def forward(self, x):
+        """image_encoder.py:235-251 for the map a GLOBAL block hands over: x [B,64,64,dim] -> [B,64,64,dim] fp32 (qkv GEMM, fused
+        attention with the decomposed rel-pos of `rel_pos_h / rel_pos_w`, proj GEMM). The 14 x 14 windows of a windowed block never
+        exist as tensors here (`Block.forward` runs them as index math inside the kernel), so a [B*nW,14,14,dim] input has no kernel."""
+        B, gh, gw, D = x.shape
+        if not self.use_rel_pos or gh != gw or gh != 64 or self.rel_pos_h.shape[0] != 2 * gh - 1:
+            raise NotImplementedError("Attention.forward: the 64 x 64 token map of a global block with its 127-row rel-pos tables; "
+                                      "windowed blocks run through Block.forward")
+        x16 = x.reshape(B * gh * gw, D).half().contiguous()
+        hd = D // self.num_heads
+        rpack = ops.pack_rel_tables(_rel_table(self.rel_pos_h, gh), _rel_table(self.rel_pos_w, gw), False, hd)
+        if ops.QKV_HEAD_MAJOR:
+            qkv = ops.gemm_heads(x16, f16(self.qkv.weight), f32(self.qkv.bias), hd)
+        else:
+            qkv = ops.gemm(x16, f16(self.qkv.weight), f32(self.qkv.bias), epilogue=ops.EPI_F16)
+        att = self._attend(qkv, B, gh, 0, rpack, None)
+        out = ops.gemm(att.view(B * gh * gw, D), f16(self.proj.weight), f32(self.proj.bias), epilogue=ops.EPI_F32)
+        return out.view(B, gh, gw, D)
+
 
 class Block(nn.Module):
     def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=True, norm_layer=nn.LayerNorm, act_layer=nn.GELU,
@@ -50,6 +107,60 @@ class Block(nn.Module):
         self.norm2 = norm_layer(dim)
         self.mlp = MLPBlock(embedding_dim=dim, mlp_dim=int(dim * mlp_ratio), act=act_layer)
         self.window_size = window_size
+        self._pk = None
+
+    def _apply(self, fn, *a, **k):
+        self._pk = None
+        return super()._apply(fn, *a, **k)
+
+    def _load_from_state_dict(self, *a, **k):   # also reached by a parent's recursive load
+        self._pk = None
+        return super()._load_from_state_dict(*a, **k)
+
+    def _packed(self, grid):
+        """One-time weight packing of the block for a grid x grid token map (fp16 GEMM operands, fp32 biases / LayerNorm parameters,
+        the rel-pos table pack, and the LayerNorm-folded forms of qkv / lin1 for `ImageEncoderViT.fold_ln`)."""
+        if self._pk is None or self._pk["grid"] != grid:
+            a = self.attn
+            D = a.qkv.in_features
+            K = self.window_size or grid
+            d = dict(grid=grid, ws=self.window_size, n1w=f32(self.norm1.weight), n1b=f32(self.norm1.bias), n2w=f32(self.norm2.weight),
+                     n2b=f32(self.norm2.bias), qkv_w=f16(a.qkv.weight), qkv_b=f32(a.qkv.bias), pad_row=f16(a.qkv.bias),
+                     proj_w=f16(a.proj.weight), proj_b=f32(a.proj.bias),
+                     rpack=ops.pack_rel_tables(_rel_table(a.rel_pos_h, K), _rel_table(a.rel_pos_w, K), self.window_size > 0,
+                                               D // a.num_heads),
+                     l1w=f16(self.mlp.lin1.weight), l1b=f32(self.mlp.lin1.bias), l2w=f16(self.mlp.lin2.weight),
+                     l2b=f32(self.mlp.lin2.bias))
+            # LayerNorm folded into the consuming GEMM (ops.fold_layernorm): W' = half(W * ln_w), row sums of W', bias + W . ln_b
+            d["qkv_wf"], d["qkv_s"], d["qkv_t"] = ops.fold_layernorm(a.qkv.weight, a.qkv.bias, self.norm1.weight, self.norm1.bias)
+            d["l1wf"], d["l1s"], d["l1t"] = ops.fold_layernorm(self.mlp.lin1.weight, self.mlp.lin1.bias, self.norm2.weight,
+                                                               self.norm2.bias)
+            self._pk = d
+        return self._pk
+
+    @torch.no_grad()
+    def forward(self, x):
+        """image_encoder.py:174-193: x [B,64,64,dim] -> [B,64,64,dim] fp32: x + attn(norm1(x)) (14 x 14 windows with zero padding when
+        window_size > 0), then x + mlp(norm2(x)). The same launches as one block of `ImageEncoderViT._encode_patches` with the LayerNorms
+        as passes of their own."""
+        B, gh, gw, D = x.shape
+        if gh != gw or gh != 64 or not isinstance(self.mlp.act, nn.GELU):
+            raise NotImplementedError("Block.forward: SAM's 64 x 64 token map and GELU MLP (build_sam.py:66-81)")
+        bp = self._packed(gh)
+        M = B * gh * gw
+        hd = D // self.attn.num_heads
+        xr = x.reshape(M, D).float().clone()                                  # the residual stream (the input stays untouched)
+        ln = ops.layernorm(xr, bp["n1w"], bp["n1b"], self.norm1.eps)
+        if ops.QKV_HEAD_MAJOR:
+            qkv = ops.gemm_heads(ln, bp["qkv_w"], bp["qkv_b"], hd)
+        else:
+            qkv = ops.gemm(ln, bp["qkv_w"], bp["qkv_b"], epilogue=ops.EPI_F16)
+        att = self.attn._attend(qkv, B, gh, bp["ws"], bp["rpack"], bp["pad_row"])
+        ops.gemm(att.view(M, D), bp["proj_w"], bp["proj_b"], out=xr, epilogue=ops.EPI_F32, resid=xr)
+        ops.layernorm(xr, bp["n2w"], bp["n2b"], self.norm2.eps, out=ln)
+        hid = ops.gemm(ln, bp["l1w"], bp["l1b"], epilogue=ops.EPI_GELU_F16)
+        ops.gemm(hid, bp["l2w"], bp["l2b"], out=xr, epilogue=ops.EPI_F32, resid=xr)
+        return xr.view(B, gh, gw, D)
 
 
 def _rel_table(rel_pos, K):
@@ -127,21 +238,7 @@ class ImageEncoderViT(nn.Module):
         pk = dict(patch_w=f16(self.patch_embed.proj.weight.reshape(D, -1)), patch_b=f32(self.patch_embed.proj.bias),
                   pos=f32(self.pos_embed.reshape(self.grid * self.grid, D)), blocks=[])
         for blk in self.blocks:
-            a = blk.attn
-            pk["blocks"].append(dict(
-                ws=blk.window_size, n1w=f32(blk.norm1.weight), n1b=f32(blk.norm1.bias), n2w=f32(blk.norm2.weight),
-                n2b=f32(blk.norm2.bias), qkv_w=f16(a.qkv.weight), qkv_b=f32(a.qkv.bias), pad_row=f16(a.qkv.bias),
-                proj_w=f16(a.proj.weight), proj_b=f32(a.proj.bias),
-                rpack=ops.pack_rel_tables(_rel_table(a.rel_pos_h, blk.window_size or self.grid),
-                                          _rel_table(a.rel_pos_w, blk.window_size or self.grid), blk.window_size > 0,
-                                          D // self.num_heads),
-                l1w=f16(blk.mlp.lin1.weight), l1b=f32(blk.mlp.lin1.bias), l2w=f16(blk.mlp.lin2.weight),
-                l2b=f32(blk.mlp.lin2.bias)))
-            # LayerNorm folded into the consuming GEMM (ops.fold_layernorm): W' = half(W * ln_w), row sums of W', bias + W . ln_b
-            d = pk["blocks"][-1]
-            d["qkv_wf"], d["qkv_s"], d["qkv_t"] = ops.fold_layernorm(a.qkv.weight, a.qkv.bias, blk.norm1.weight, blk.norm1.bias)
-            d["l1wf"], d["l1s"], d["l1t"] = ops.fold_layernorm(blk.mlp.lin1.weight, blk.mlp.lin1.bias, blk.norm2.weight,
-                                                               blk.norm2.bias)
+            pk["blocks"].append(blk._packed(self.grid))
         pk["neck0"], pk["neck0_lo"] = ops.split_weight_f16(self.neck[0].weight.reshape(oc, D))
         pk["neck2"], pk["neck2_lo"] = ops.split_weight_f16(self.neck[2].weight.permute(0, 2, 3, 1).reshape(oc, 9 * oc))  # [out, (ky,kx,cin)]
         pk["raw"] = {}       # (mean, std) -> patch-embed weights for raw uint8 pixel values (see _patch_raw)
@@ -182,10 +279,19 @@ class ImageEncoderViT(nn.Module):
                                relq=torch.zeros((B, H, N, 2, 32), dtype=torch.float16, device=dev),
                                n0=e((M, oc), torch.float32), n1=e((M, oc), torch.float16),
                                col=e((M, 9 * oc), torch.float16), n2=e((M, oc), torch.float32),
-                               ln_lo=e((M, D), torch.float16), n1f=e((M, oc), torch.float32), n1_lo=e((M, oc), torch.float16),
-                               col_lo=e((M, 9 * oc), torch.float16),
                                out=e((B, N, oc), torch.float32))
         return self._ws[B]
+
+    def _split_buffers(self, ws, M):
+        """The lo halves of the split-fp16 neck (`split_fp16`; ~570 MB at 16 slices of ViT-H, col_lo alone 302 MB): allocated when that
+        path first runs, like `_rel_buffers`."""
+        if "ln_lo" not in ws:
+            D, oc, dev = self.embed_dim, self.out_chans, self.pos_embed.device
+            ws["ln_lo"] = torch.empty((M, D), dtype=torch.float16, device=dev)
+            ws["n1f"] = torch.empty((M, oc), dtype=torch.float32, device=dev)
+            ws["n1_lo"] = torch.empty((M, oc), dtype=torch.float16, device=dev)
+            ws["col_lo"] = torch.empty((M, 9 * oc), dtype=torch.float16, device=dev)
+        return ws
 
     def _rel_buffers(self, ws, B, H, N):
         """fp32 [B,H,N,64] x 2 of the two-kernel global rel-pos path (268 MB each at 16 slices of ViT-H): only allocated when that path
@@ -236,7 +342,7 @@ class ImageEncoderViT(nn.Module):
                 ops.gemm(patches, pw_hi, pb, out=x, epilogue=ops.EPI_F32, resid=pk["pos"], resid_mod=N, **fk)
         else:
             ops.gemm(patches, pk["patch_w"], pk["patch_b"], out=x, epilogue=ops.EPI_F32, resid=pk["pos"], resid_mod=N, **fk)
-        for bp in pk["blocks"]:
+        for blk, bp in zip(self.blocks, pk["blocks"]):
             if fold:
                 ops.ln_finalize(stats, M, D, LN_EPS, mr=mr)
                 ops.gemm(x16, bp["qkv_wf"], bp["qkv_t"], out=ws["qkv"], epilogue=ops.EPI_F16, ln_mr=mr, ln_s=bp["qkv_s"])
@@ -246,23 +352,8 @@ class ImageEncoderViT(nn.Module):
             else:
                 ops.layernorm(x, bp["n1w"], bp["n1b"], LN_EPS, out=ws["ln"])
                 ops.gemm(ws["ln"], bp["qkv_w"], bp["qkv_b"], out=ws["qkv"], epilogue=ops.EPI_F16)
-            if bp["ws"] > 0:
-                if ops.FUSE_WINDOW_RELPOS:   # the query-side rel-pos terms are computed inside the attention kernel
-                    ops.attention(ws["qkv"], B, N, H, hd, hd ** -0.5, out=ws["att"], mode=2, rpack=bp["rpack"],
-                                  pad_row=bp["pad_row"], gh=g, gw=g, ws=bp["ws"], head_major=ops.QKV_HEAD_MAJOR)
-                else:
-                    ops.relpos(ws["qkv"], bp["rpack"], B, N, H, hd, g, bp["ws"], True, hd ** -0.5, relq=ws["relq"],
-                               head_major=ops.QKV_HEAD_MAJOR)
-                    ops.attention(ws["qkv"], B, N, H, hd, hd ** -0.5, out=ws["att"], mode=2, relq=ws["relq"],
-                                  pad_row=bp["pad_row"], gh=g, gw=g, ws=bp["ws"], head_major=ops.QKV_HEAD_MAJOR)
-            elif ops.attention_fused_relpos(B, N, H, hd, g, g):   # rel_h / rel_w computed inside the attention kernel (round 5)
-                ops.attention(ws["qkv"], B, N, H, hd, hd ** -0.5, out=ws["att"], mode=1, rpack=bp["rpack"], gh=g, gw=g)
-            else:
-                relh, relw = self._rel_buffers(ws, B, H, N)
-                ops.relpos(ws["qkv"], bp["rpack"], B, N, H, hd, g, g, False, hd ** -0.5, rel_h=relh,
-                           rel_w=relw, head_major=ops.QKV_HEAD_MAJOR)
-                ops.attention(ws["qkv"], B, N, H, hd, hd ** -0.5, out=ws["att"], mode=1, rel_h=relh,
-                              rel_w=relw, gh=g, gw=g, head_major=ops.QKV_HEAD_MAJOR)
+            blk.attn._attend(ws["qkv"], B, g, bp["ws"], bp["rpack"], bp["pad_row"], out=ws["att"], relq=ws["relq"],
+                             rel_bufs=lambda: self._rel_buffers(ws, B, H, N))
             ops.gemm(ws["att"], bp["proj_w"], bp["proj_b"], out=x, epilogue=ops.EPI_F32, resid=x, **fk)
             if fold:
                 ops.ln_finalize(stats, M, D, LN_EPS, mr=mr)
@@ -276,6 +367,7 @@ class ImageEncoderViT(nn.Module):
         xh = ws["ln"]
         if self.split_fp16 and "neck" in self._split_parts:
             # (hi, lo) pairs of the activations and of the weights: hi W_hi + lo W_hi + hi W_lo, accumulated in the fp32 output
+            self._split_buffers(ws, M)
             ops.split_f16(x, hi=xh, lo=ws["ln_lo"], write_hi=not fold)
             ops.gemm(xh, pk["neck0"], None, out=ws["n0"], epilogue=ops.EPI_F32)
             ops.gemm(ws["ln_lo"], pk["neck0"], None, out=ws["n0"], epilogue=ops.EPI_F32, resid=ws["n0"])

@@ -1,13 +1,11 @@
 """SAM mask decoder on the HIP kernels (names of models/segment_anything/modeling/mask_decoder.py:16-176).
 
-`predict_masks_tokens` restates mask_decoder.py:112-149 + transformer.py:62-106,151-182 for a batch of B prompt sets on
-ONE image. Token side (T <= 16 tokens/prompt): fp32 `small_linear` / `small_attention`. Image side (4096 tokens):
-k/v/q projections, the i2t out-projection and ConvTranspose(2,2) #1 are GEMMs on the exact-fp32 MFMA (`psam_gemm_f32`,
-`keys + pe` added on the operand load) - 3.2 GFLOP per prompt set, ~25 us - so that `sigmoid(low_res_masks)` keeps a
-margin under the 1e-3 parity bound (with fp16 operands this stage alone measured 0.8e-3 .. 1.2e-3; that path is kept behind
-`image_side_fp16 = True` for throughput experiments with hundreds of prompt sets). Token->image attention is
-`t2i_attention`; the rest of the upscaling and the hyper-network product are fused in `upscale_tail` so
-`upscaled_embedding` [B,32,256,256] is never materialised.
+`predict_masks_tokens` restates mask_decoder.py:112-149 for a batch of B prompt sets on one or several images: the two-way
+transformer (`TwoWayTransformer.run_tokens`, transformer.py) and then ConvTranspose(2,2) #1 as a GEMM at fp32 accuracy
+(`psam_gemm_f32x3` / `psam_gemm_f32`) - with fp16 operands the image side alone measured 0.8e-3 .. 1.2e-3 on
+`sigmoid(low_res_masks)`; that path is kept behind `image_side_fp16 = True` for throughput experiments with hundreds of prompt
+sets. The rest of the upscaling and the hyper-network product are fused in `upscale_tail` so `upscaled_embedding` [B,32,256,256]
+is never materialised.
 """
 import os
 
@@ -17,8 +15,6 @@ import torch.nn as nn
 from ... import ops
 from .common import LayerNorm2d, f16, f32
 from .transformer import TwoWayTransformer  # noqa: F401
-
-LN_EPS = 1e-5  # nn.LayerNorm default (transformer.py:133-144)
 
 
 class MLP(nn.Module):
@@ -66,36 +62,18 @@ class MaskDecoder(nn.Module):
         return super()._load_from_state_dict(*a, **k)
 
     # ---- packing -----------------------------------------------------------------------------------------------
-    @staticmethod
-    def _attn_pack(a, image_side):
-        d = dict(qw=f32(a.q_proj.weight), qb=f32(a.q_proj.bias), kw=f32(a.k_proj.weight), kb=f32(a.k_proj.bias),
-                 vw=f32(a.v_proj.weight), vb=f32(a.v_proj.bias), ow=f32(a.out_proj.weight), ob=f32(a.out_proj.bias))
-        mods = {"qw": a.q_proj, "kw": a.k_proj, "vw": a.v_proj, "ow": a.out_proj}
-        for nm in image_side:  # projections applied to the 4096 image tokens run as fp16 MFMA GEMMs
-            d[nm + "16"] = f16(mods[nm].weight)
-            d[nm + "x3"] = ops.split_weight_f16(mods[nm].weight, ops.X3_WEIGHT_SCALE) + (ops.X3_WEIGHT_SCALE,)      # (hi, lo, scale) for ops.gemm_f32x3
-        return d
-
     def _packed(self):
+        """The decoder's own weights (the two-way transformer packs its own: transformer.py)."""
         if self._cache is not None:
             return self._cache
-        tr = self.transformer
-        pk = dict(layers=[])
-        for L in tr.layers:
-            pk["layers"].append(dict(
-                sa=self._attn_pack(L.self_attn, ()), t2i=self._attn_pack(L.cross_attn_token_to_image, ("kw", "vw")),
-                i2t=self._attn_pack(L.cross_attn_image_to_token, ("qw", "ow")),
-                n=[(f32(n.weight), f32(n.bias)) for n in (L.norm1, L.norm2, L.norm3, L.norm4)],
-                l1w=f32(L.mlp.lin1.weight), l1b=f32(L.mlp.lin1.bias), l2w=f32(L.mlp.lin2.weight),
-                l2b=f32(L.mlp.lin2.bias), skip_pe=L.skip_first_layer_pe))
-        pk["final"] = self._attn_pack(tr.final_attn_token_to_image, ("kw", "vw"))
-        pk["nf"] = (f32(tr.norm_final_attn.weight), f32(tr.norm_final_attn.bias))
+        pk = {}
         pk["out_tok"] = torch.cat([f32(self.iou_token.weight), f32(self.mask_tokens.weight)], 0).contiguous()
         up0, ln, up3 = self.output_upscaling[0], self.output_upscaling[1], self.output_upscaling[3]
         # ConvTranspose2d weight [in, out, kh, kw]: GEMM row (dy*2+dx)*64 + co  <-  W[:, co, dy, dx]
         pk["up1_w16"] = f16(up0.weight.permute(2, 3, 1, 0).reshape(4 * 64, 256))
         pk["up1_w"] = f32(up0.weight.permute(2, 3, 1, 0).reshape(4 * 64, 256))
-        pk["up1_wx3"] = ops.split_weight_f16(pk["up1_w"], ops.X3_WEIGHT_SCALE) + (ops.X3_WEIGHT_SCALE,)
+        sc = ops.split_scale_for(pk["up1_w"], ops.X3_WEIGHT_SCALE)
+        pk["up1_wx3"] = ops.split_weight_f16(pk["up1_w"], sc) + (sc,)
         pk["up1_b"] = f32(up0.bias).repeat(4).contiguous()
         pk["up_lnw"], pk["up_lnb"] = f32(ln.weight), f32(ln.bias)
         pk["up2_w"] = f32(up3.weight.permute(0, 2, 3, 1).reshape(64, 4 * 32))  # [c, (dy2*2+dx2)*32 + c2]
@@ -108,21 +86,13 @@ class MaskDecoder(nn.Module):
         return pk
 
     def _workspace(self, B, T, Nk, dev):
-        h = self.image_side_fp16
-        key = (B, T, h)
+        key = (B, T, Nk)
         if key not in self._ws:
-            while len(self._ws) >= 4:          # every distinct number of prompt sets has its own ~13 MB-per-set workspace:
-                self._ws.pop(next(iter(self._ws)))   # keep the four most recently created ones
+            while len(self._ws) >= 4:          # (the transformer keeps the large per-shape buffers; these are ~1 MB per prompt set)
+                self._ws.pop(next(iter(self._ws)))
             e = lambda shape, dt=torch.float32: torch.empty(shape, dtype=dt, device=dev)  # noqa: E731
-            M = B * Nk
-            pdt = torch.float16 if h else torch.float32
-            self._ws[key] = dict(
-                keys=e((M, 256)), k16=e((M, 256), torch.float16) if h else None,
-                kpe16=e((M, 256), torch.float16) if h else None,
-                p0=e((M, 128), pdt), p1=e((M, 128), pdt), u1=e((M, 256)),
-                q=e((B * T, 256)), tq128=e((B * T, 128)), ta128=e((B * T, 128)), tq=e((B * T, 256)), tk=e((B * T, 256)), tv=e((B * T, 256)), ta=e((B * T, 256)),
-                t1=e((B * T, 256)), hid=e((B * T, 2048)), parts=e((8, B * T, 256)), h1=e((B, 4, 256)), h2=e((B, 4, 256)), hyper=e((B, 4, 32)),
-                i1=e((B, 256)), i2=e((B, 256)), iou=e((B, 4)), masks=e((B, 4, 256, 256)), t2i_part=e((16 * B * 8 * T * 18,)))
+            self._ws[key] = dict(u1=e((B * Nk, 256)), h1=e((B, 4, 256)), h2=e((B, 4, 256)), hyper=e((B, 4, 32)), i1=e((B, 256)),
+                                 i2=e((B, 256)), iou=e((B, 4)), masks=e((B, 4, 256, 256)))
         return self._ws[key]
 
     # ---- the decoder ---------------------------------------------------------------------------------------------
@@ -140,76 +110,16 @@ class MaskDecoder(nn.Module):
         if T > 16:
             raise NotImplementedError("more than 11 sparse prompt tokens per prompt set")
         ws = self._workspace(B, T, Nk, tokens.device)
-        NH = self.transformer.num_heads
-        keys, k16, kpe16, q = ws["keys"], ws["k16"], ws["kpe16"], ws["q"]
-        tok2 = tokens.reshape(B * T, 256).contiguous()  # query_pe (transformer.py:88-96)
         lin = ops.small_linear
         h16 = self.image_side_fp16
         x3 = self.image_side_x3 and not h16
-        ops.ln_pe(feat_tok, pe_tok, B * Nk, y32=keys, y16=k16, ype16=kpe16, add_vec=dense_vec, in_mod=Nk, pe_mod=Nk,
-                  img_of_prompt=img_of_prompt)
-
-        def img_proj(w_name, ap, out, with_pe, heads=None):
-            """image-token projection: (keys [+ key_pe]) @ W^T + b (transformer.py:228-230 of the 4096-token operand); heads = (Nk, hd):
-            written head-major [B][NH][Nk][hd] for the token-to-image attention kernel"""
-            if h16:
-                ops.gemm(kpe16 if with_pe else k16, ap[w_name + "16"], ap[w_name[0] + "b"], out=out, epilogue=ops.EPI_F16)
-            elif x3:
-                ops.gemm_f32x3(keys, ap[w_name + "x3"], ap[w_name[0] + "b"], out=out, a2=pe_tok if with_pe else None, a2_mod=Nk, heads=heads)
-            else:
-                ops.gemm_f32(keys, ap[w_name], ap[w_name[0] + "b"], out=out, a2=pe_tok if with_pe else None, a2_mod=Nk, heads=heads)
-
-        hm = (not h16) and T <= 16 and Nk >= 64       # K / V of the token-to-image attention head-major (contiguous 64-byte key rows)
-        t2i_s = ops.t2i_split(B, NH, T, Nk) if NH == 8 else 1     # key ranges per (prompt set, head): few prompt sets leave the CUs idle
-
-        def t2i(ap, resid_ln):
-            lin(q, ap["qw"], ap["qb"], out=ws["tq128"], x2=tok2)
-            img_proj("kw", ap, ws["p0"], True, heads=(Nk, 128 // NH) if hm else None)
-            img_proj("vw", ap, ws["p1"], False, heads=(Nk, 128 // NH) if hm else None)
-            ops.t2i_attention(ws["tq128"], ws["p0"], ws["p1"], ws["ta128"], B, T, Nk, NH, head_major=hm,
-                              split=(t2i_s, ws["t2i_part"]))
-            lin(ws["ta128"], ap["ow"], ap["ob"], out=ws["t1"], resid=q)
-            ops.layernorm(ws["t1"], resid_ln[0], resid_ln[1], LN_EPS, out=q, out_dtype=torch.float32)
-
-        for li, L in enumerate(pk["layers"]):
-            sa = L["sa"]
-            x2 = None if L["skip_pe"] else tok2
-            if li == 0:
-                src = tok2          # queries = point_embedding (transformer.py:85)
-            else:
-                src = q
-            lin(src, sa["qw"], sa["qb"], out=ws["tq"], x2=x2)
-            lin(src, sa["kw"], sa["kb"], out=ws["tk"], x2=x2)
-            lin(src, sa["vw"], sa["vb"], out=ws["tv"])
-            ops.small_attention(ws["tq"], ws["tk"], ws["tv"], ws["ta"], B, T, T, NH, 256 // NH, 256, 256, 256, 256)
-            lin(ws["ta"], sa["ow"], sa["ob"], out=ws["t1"], resid=None if L["skip_pe"] else src)
-            ops.layernorm(ws["t1"], L["n"][0][0], L["n"][0][1], LN_EPS, out=q, out_dtype=torch.float32)
-            t2i(L["t2i"], L["n"][1])
-            lin(q, L["l1w"], L["l1b"], out=ws["hid"], act=1)
-            if B * T >= 32:      # 2048 -> 256 on few rows: eight K ranges side by side (psam_small_linear_splitk)
-                ops.small_linear_splitk(ws["hid"], L["l2w"], L["l2b"], q, ws["t1"], ws["parts"], 8)
-            else:
-                lin(ws["hid"], L["l2w"], L["l2b"], out=ws["t1"], resid=q)
-            ops.layernorm(ws["t1"], L["n"][2][0], L["n"][2][1], LN_EPS, out=q, out_dtype=torch.float32)
-            ia = L["i2t"]
-            img_proj("qw", ia, ws["p0"], True)
-            lin(q, ia["kw"], ia["kb"], out=ws["tk"][:, :128], x2=tok2)
-            lin(q, ia["vw"], ia["vb"], out=ws["tv"][:, :128])
-            ops.small_attention(ws["p0"], ws["tk"][:, :128], ws["tv"][:, :128], ws["p1"], B, Nk, T, NH, 128 // NH, 128,
-                                256, 256, 128)
-            if h16:
-                ops.gemm(ws["p1"], ia["ow16"], ia["ob"], out=keys, epilogue=ops.EPI_F32, resid=keys)
-            elif x3:
-                ops.gemm_f32x3(ws["p1"], ia["owx3"], ia["ob"], out=keys, resid=keys)
-            else:
-                ops.gemm_f32(ws["p1"], ia["ow"], ia["ob"], out=keys, resid=keys)
-            ops.ln_pe(keys, pe_tok, B * Nk, y32=keys, y16=k16, ype16=kpe16, w=L["n"][3][0], b=L["n"][3][1], pe_mod=Nk,
-                      eps=LN_EPS)
-        t2i(pk["final"], pk["nf"])
+        # the two-way transformer (mask_decoder.py:131, transformer.py:62-106)
+        q, keys, tws = self.transformer.run_tokens(feat_tok, pe_tok, tokens, dense_vec, img_of_prompt=img_of_prompt,
+                                                   image_side_fp16=h16, image_side_x3=x3)
         hs = q.view(B, T, 256)
         # output upscaling + hyper-networks (mask_decoder.py:137-144) and IoU head (:147)
         if h16:
-            ops.gemm(k16, pk["up1_w16"], pk["up1_b"], out=ws["u1"], epilogue=ops.EPI_F32)
+            ops.gemm(tws["k16"], pk["up1_w16"], pk["up1_b"], out=ws["u1"], epilogue=ops.EPI_F32)
         elif x3:
             ops.gemm_f32x3(keys, pk["up1_wx3"], pk["up1_b"], out=ws["u1"])
         else:

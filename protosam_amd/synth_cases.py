@@ -190,3 +190,57 @@ def cfg5_inputs():
     from protosam_amd.synth import synth_pair_multi
     s_img, s_masks, q_img, _ = synth_pair_multi(1024, seed=CFG5_SEED)
     return s_img, s_masks, q_img
+
+
+# ---- stand-alone module forwards (tests/golden/reference_modules.npz, oracle/make_module_goldens.py) --------------------
+MODULE_SEED = 606
+MODULE_DIM, MODULE_HEADS = 768, 12          # SAM ViT-B's block width (head size 64)
+
+
+def _randn(shape, seed, scale=1.0):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def module_block_input():
+    """[1,64,64,768]: what `ImageEncoderViT` hands to a block (image_encoder.py:112-113)."""
+    return _randn((1, 64, 64, MODULE_DIM), 31)
+
+
+def module_mlp_input():
+    return _randn((300, MODULE_DIM), 32)
+
+
+def module_ln2d_input():
+    return _randn((2, 256, 16, 16), 33, 2.0) + 0.5
+
+
+def module_patch_input():
+    return _randn((1, 3, 1024, 1024), 34)
+
+
+def module_transformer_inputs():
+    """image_embedding [2,256,64,64], image_pe [2,256,64,64] (one grid repeated, mask_decoder.py:128), point_embedding [2,7,256]"""
+    pe = _randn((1, 256, 64, 64), 36).expand(2, -1, -1, -1).contiguous()
+    return _randn((2, 256, 64, 64), 35), pe, _randn((2, 7, 256), 37)
+
+
+def module_sam_forward_input():
+    """`Sam.forward`'s batched_input (sam.py:54-131): a square image with points + boxes, a 768 x 1024 one (zero padding, un-padded at
+    'image_size') with points only; both with the 'image_size' key `SamBatched.forward` reads (sam.py:283)."""
+    a = torch.from_numpy(predictor_image((1024, 1024), seed=3)).permute(2, 0, 1).float().contiguous()
+    b = torch.from_numpy(predictor_image((768, 1024), seed=4)).permute(2, 0, 1).float().contiguous()
+    return [
+        dict(image=a, original_size=(512, 512), image_size=(1024, 1024),
+             point_coords=torch.tensor([[[400.0, 500.0], [520.5, 480.0]], [[200.0, 700.0], [100.0, 90.0]]]),
+             point_labels=torch.tensor([[1, 1], [1, 0]], dtype=torch.int),
+             boxes=torch.tensor([[300.0, 350.0, 700.0, 800.0], [50.0, 600.0, 400.0, 900.0]])),
+        dict(image=b, original_size=(384, 512), image_size=(768, 1024),
+             point_coords=torch.tensor([[[360.0, 300.0], [540.0, 180.0]]]), point_labels=torch.tensor([[1, 0]], dtype=torch.int)),
+    ]
+
+
+def module_segment_all_inputs():
+    """query image [1,3,1024,1024] and a label [1,1024,1024] for `ProtoMedSAM.segment_all` (ProtoMedSAM.py:224-249)."""
+    from protosam_amd.synth import synth_pair
+    _, _, q_img, q_gt = synth_pair(1024, seed=7)
+    return q_img, q_gt.reshape(1, 1024, 1024).float()

@@ -62,3 +62,46 @@ def test_two_file_nifti(tmp_path):
     gzip.open(trunc, "wb").write(bytes(raw[:-4]))
     with pytest.raises(ValueError):
         read_nifti(str(trunc))
+
+
+def test_module_level_caches_follow_loads():
+    """The blocks / two-way transformer parts pack their own weights (their stand-alone `forward`s use the packs too): a parent's
+    load_state_dict and `.to()` must drop every one of them."""
+    from protosam_amd.segment_anything import sam_model_registry
+    sam = sam_model_registry["vit_b"](encoder_depth=1)
+    blk = sam.image_encoder.blocks[0]
+    tb = sam.mask_decoder.transformer.layers[0]
+    blk._pk, tb._cache, tb.self_attn._cache = {"grid": 64}, "stale", {(): "stale"}
+    sam.load_state_dict(sam.state_dict())
+    assert blk._pk is None and tb._cache is None and tb.self_attn._cache == {}
+    blk._pk, tb._cache, tb._ws, sam.mask_decoder.transformer._ws = {"grid": 64}, "stale", {1: 2}, {1: 2}
+    sam.float()                                                  # any _apply (.to / .cuda / .half)
+    assert blk._pk is None and tb._cache is None and tb._ws == {} and sam.mask_decoder.transformer._ws == {}
+
+
+def test_split_weight_scale_stays_inside_fp16():
+    """ops.split_weight_f16 refuses a scale that would push a weight past the fp16 range (hi = inf, lo = -inf, NaN products in
+    psam_gemm_f32x3); ops.split_scale_for picks the largest power of two <= 2^8 that fits."""
+    from protosam_amd import ops
+    w = torch.tensor([[0.05, -0.3], [300.0, 1e-4]])
+    with pytest.raises(ValueError):
+        ops.split_weight_f16(w, 256.0)
+    s = ops.split_scale_for(w, 256.0)
+    assert s == 128.0
+    hi, lo = ops.split_weight_f16(w, s)
+    assert torch.isfinite(hi.float()).all() and torch.isfinite(lo.float()).all()
+    back = (hi.double() + lo.double()) / s
+    assert (back - w.double()).abs().max() <= w.abs().max().item() * 2.0 ** -20
+    assert ops.split_scale_for(torch.tensor([0.1, -0.2]), 256.0) == 256.0
+    with pytest.raises(ValueError):
+        ops.split_weight_f16(torch.tensor([float("inf")]))
+
+
+def test_t2i_split_mode_one_means_one_range(monkeypatch):
+    from protosam_amd import ops
+    monkeypatch.setenv("PSAM_T2I_SPLIT", "1")
+    assert ops.t2i_split(1, 8, 7, 4096) == 1
+    monkeypatch.setenv("PSAM_T2I_SPLIT", "4")
+    assert ops.t2i_split(1, 8, 7, 4096) == 4
+    monkeypatch.setenv("PSAM_T2I_SPLIT", "auto")
+    assert ops.t2i_split(1, 8, 7, 4096) == 16 and ops.t2i_split(27, 8, 7, 4096) == 1

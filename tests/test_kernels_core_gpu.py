@@ -458,6 +458,31 @@ def test_head_major_qkv_layout(dev):
     assert torch.equal(ops.attention(tokm, B, N, H, hd, scale), ops.attention(hm, B, N, H, hd, scale, head_major=True))
 
 
+@pytest.mark.parametrize("M", [200, 512, 1297])
+@pytest.mark.parametrize("tile", [0, 13, 12, 1])
+def test_head_major_qkv_small_launches(dev, M, tile):
+    """psam_gemm_f16_heads on launches small enough for the 64x64 / deep-ring kernels (a low-resolution DINOv2 call): the automatic
+    choice and a forced tile 13 / 12 must still write [3*H, M, hd] planes (tile 13's epilogue has no plane addressing: the dispatch keeps
+    such launches on the 128-tile kernel)."""
+    from protosam_amd import ops
+    H, hd = 12, 64
+    D = H * hd
+    x = _rand((M, D), dev, 1.0, 141).half()
+    w = _rand((3 * D, D), dev, 0.05, 142).half()
+    bias = _rand((3 * D,), dev, 0.5, 143)
+    ops.gemm_set_tile(1)
+    try:
+        tokm = ops.gemm(x, w, bias, epilogue=ops.EPI_F16)
+    finally:
+        ops.gemm_set_tile(0)
+    ops.gemm_set_tile(tile)
+    try:
+        hm = ops.gemm_heads(x, w, bias, hd)
+    finally:
+        ops.gemm_set_tile(0)
+    assert torch.equal(hm, tokm.view(M, 3 * H, hd).permute(1, 0, 2).contiguous())
+
+
 def test_window_attention_fused_relpos(dev):
     """mode 2 with the rel-pos query terms computed in-kernel (rpack) equals the two-kernel path (psam_relpos -> relq)."""
     from protosam_amd import ops
