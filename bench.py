@@ -193,10 +193,58 @@ class PowerSampler:
                 "source": "amdgpu hwmon power1_input / freq1_input, 20 ms period, over the timed steps"}
 
 
-def main():
-    args = parse_args()
+class DeviceRuntime:
+    """What a rank's body needs from the machine. This one is the product's: an MI355X per rank, RCCL (`nccl`) between them, HIP events
+    on the launch stream. tests/test_runner_dist_cpu.py substitutes a host runtime (gloo, stubbed `run_slices`) so that the N > 1 body -
+    argument handling, step indexing, the all-gather, the reductions, the JSON line, the teardown - runs at world 2 without a GPU."""
+    backend = "nccl"
+
+    def device(self, local_rank):
+        import torch
+        torch.cuda.set_device(local_rank)
+        return torch.device(f"cuda:{local_rank}")
+
+    def init_group(self, local_rank):
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group(self.backend, device_id=torch.device(f"cuda:{local_rank}"))
+
+    def sync(self):
+        import torch
+        torch.cuda.synchronize()
+
+    def event(self):
+        import torch
+        return torch.cuda.Event(enable_timing=True)
+
+    def kernel_timer(self):
+        from protosam_amd import ops
+        return ops.KernelTimer()
+
+    def power_sampler(self, local_rank):
+        return PowerSampler(local_rank)
+
+    def build(self, args, dev):
+        """-> (model, alp_sd, vol, svol, slab, vol_d, sup_imgs, sup_masks): seeded weights and volumes, resident on `dev`"""
+        from protosam_amd.runner import build_protosam, support_set
+        from protosam_amd.synth import synth_volume
+        model, alp_sd = build_protosam(dev, sam_type=args.sam, image_size=512, seed=1234, sam_depth=args.cpu_sam_depth,
+                                       cache_support=not args.no_support_cache)
+        vol, lab = synth_volume(args.slices, 512, seed=0, kind="ct")
+        svol, slab = synth_volume(args.slices, 512, seed=1, kind="ct")
+        sup_imgs, sup_masks = support_set(svol.to(dev), slab.to(dev))
+        return model, alp_sd, vol, svol, slab, vol.to(dev), sup_imgs, sup_masks
+
+    def run_slices(self, *a, **k):
+        from protosam_amd.runner import run_slices
+        return run_slices(*a, **k)
+
+
+def main(argv=None, runtime=None):
+    args = parse_args(argv)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args))
+    rt = runtime or DeviceRuntime()
 
     import torch
     import torch.distributed as dist
@@ -205,42 +253,56 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        rt.init_group(local_rank)
+        # the ranks of one node share its host cores: the prompt logic between the kernels is single-threaded, and a rank that spins
+        # os.cpu_count() intra-op threads for the few host-side torch ops would only steal them from its neighbours
+        torch.set_num_threads(max(1, (os.cpu_count() or 1) // world))
     if world != args.gpus and rank == 0:
         log(f"note: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
+    dev = rt.device(local_rank)
 
     from protosam_amd import ops, protosam as psmod
-    from protosam_amd.runner import build_protosam, gather_masks, part_assign, run_slices, support_set
-    from protosam_amd.synth import synth_volume
+    from protosam_amd.runner import gather_masks, part_assign
 
     t0 = time.time()
-    model, alp_sd = build_protosam(dev, sam_type=args.sam, image_size=512, seed=1234, sam_depth=args.cpu_sam_depth,
-                                   cache_support=not args.no_support_cache)
-    vol, lab = synth_volume(args.slices, 512, seed=0, kind="ct")
-    svol, slab = synth_volume(args.slices, 512, seed=1, kind="ct")
-    vol_d = vol.to(dev)
-    sup_imgs, sup_masks = support_set(svol.to(dev), slab.to(dev))
+    model, alp_sd, vol, svol, slab, vol_d, sup_imgs, sup_masks = rt.build(args, dev)
     if rank == 0:
         log(f"built model + volume in {time.time() - t0:.1f}s (world {world})")
+    ranks_seen = [0]
+    if world > 1:
+        # every rank's id through the same collective the masks take (RCCL all-gather on the device): the job really has `world`
+        # distinct ranks talking to each other before anything is timed
+        ids = torch.empty(world, dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(ids, torch.tensor([rank], dtype=torch.int32, device=dev))
+        ranks_seen = sorted(int(v) for v in ids.cpu())
+        if ranks_seen != list(range(world)):
+            raise SystemExit(f"rank {rank}: the all-gather of rank ids returned {ranks_seen}, expected 0..{world - 1}")
 
     # The headline is measured with the two encoders on ONE stream: `roofline` prices every GEMM launch with its own pair of HIP events
     # (and must agree with rocprofv3's per-kernel durations), which concurrent kernels of a second stream would blur. The library's
     # default ("auto": SAM encoder beside DINOv2 + ALP on a second stream once the calls are dense) is reported as a leg of its own.
-    model.overlap_streams = "0"
+    if model is not None:
+        model.overlap_streams = "0"
     strong = args.scaling == "strong"
     if strong and args.slices % world:
         raise SystemExit("--scaling strong needs --slices divisible by the number of ranks")
     B = args.slices // world if strong else args.batch
     out = torch.zeros((B, 512, 512), dtype=torch.uint8, device=dev)
     parts = [[z for z in range(args.slices) if part_assign(z, args.slices) == pt] for pt in range(3)]
+    ag_events = []                                # (start, end) HIP events around the all-gather of a timed step (world > 1)
 
-    def step(s, micro=None, volume=None):
+    def step(s, micro=None, volume=None, timed=False):
         zs = strong_slices(args.slices, world, rank) if strong else step_slices(s, parts, B, world, rank)
-        masks, st = run_slices(model, vol_d if volume is None else volume, sup_imgs, sup_masks, zs, dev, out=out,
-                               batch=micro or args.micro)
-        full = gather_masks(masks, world)
+        masks, st = rt.run_slices(model, vol_d if volume is None else volume, sup_imgs, sup_masks, zs, dev, out=out,
+                                  batch=micro or args.micro)
+        if timed and world > 1:
+            e0, e1 = rt.event(), rt.event()
+            e0.record()
+            full = gather_masks(masks, world)
+            e1.record()
+            ag_events.append((e0, e1))
+        else:
+            full = gather_masks(masks, world)
         return zs, full, st
 
     # setup, not a step: build the three z-parts' support banks and size the workspaces once (the caller walks a scan part
@@ -248,45 +310,53 @@ def main():
     # nor the K timed ones depend on which part a step index happens to fall into
     if not args.no_support_cache:
         for pt in range(3):
-            run_slices(model, vol_d, sup_imgs, sup_masks, parts[pt][:1], dev, batch=1)
+            rt.run_slices(model, vol_d, sup_imgs, sup_masks, parts[pt][:1], dev, batch=1)
     for s in range(args.warmup):
         step(s)
-    torch.cuda.synchronize()
+    rt.sync()
     if world > 1:
         dist.barrier()
     # The GEMM launches are priced with their own pair of HIP events on every THIRD timed step (all steps launch the same shapes): a
     # pair per launch on every step cost the headline 1-2 % (3600 launches in six steps; 155.2 against 158.2 slices/s in the same
     # minute on one box), and `value` is the job's throughput, not the instrument's. `roofline.launches` counts the priced launches.
-    timer = ops.KernelTimer() if rank == 0 else None
+    timer = rt.kernel_timer() if rank == 0 else None
     timed_steps = [s for s in range(args.steps) if s % 3 == 0]
-    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    torch.cuda.synchronize()
+    step_ev = [rt.event() for _ in range(args.steps + 1)]
+    rt.sync()
     t1 = time.perf_counter()
     step_ev[0].record()
-    power = PowerSampler(local_rank) if rank == 0 else None
+    power = rt.power_sampler(local_rank) if rank == 0 else None
     if power:
         power.start()
     ncomp = []
+    full = None
     for s in range(args.steps):
         ops.GEMM_TIMER = timer if s in timed_steps else None
-        zs, full, st = step(args.warmup + s)
+        zs, full, st = step(args.warmup + s, timed=True)
         step_ev[s + 1].record()
         ncomp += st
-    torch.cuda.synchronize()
+    rt.sync()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t1
     power_clock = power.stop() if power else None
     ops.GEMM_TIMER = None
+    per_rank_ms, allgather_ms = None, None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        # per-rank wall time of the timed region (its max is the job's time) and each rank's mean all-gather time, on rank 0's line
+        mine = torch.tensor([elapsed, sum(a.elapsed_time(b) for a, b in ag_events) / max(len(ag_events), 1) * 1e-3],
+                            dtype=torch.float64, device=dev)
+        every = torch.empty((world, 2), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(every, mine.view(1, 2))
+        every = every.cpu()
+        per_rank_ms = [round(float(v) / args.steps * 1e3, 3) for v in every[:, 0]]
+        allgather_ms = [round(float(v) * 1e3, 3) for v in every[:, 1]]
+        elapsed = float(every[:, 0].max())
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
-        return
+        return {"rank": rank, "last_zs": zs, "last_gather": full}
 
     import numpy as np
     step_ms = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)]
@@ -325,6 +395,11 @@ def main():
         "metric": "query-slices/sec (512x512) end-to-end ProtoSAM infer",
         "value": round(value, 3), "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        # N > 1: which ranks answered the RCCL all-gather of rank ids, every rank's own wall time per step (`ms_per_step` is their
+        # maximum) and its mean time inside the step's all-gather of uint8 masks (HIP events around the collective: it includes
+        # waiting for the slowest rank's masks, so it is an upper bound of the transfer itself)
+        "ranks_seen": ranks_seen, "per_rank_ms_per_step": per_rank_ms, "allgather_ms_per_step": allgather_ms,
+        "host_threads_per_rank": torch.get_num_threads(),
         "ms_per_step_std": round(float(np.std(step_ms)), 3), "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"ProtoSAM.forward per 512x512 slice: DINOv2 ViT-B/14 + ALP + SAM {args.sam} "
@@ -344,6 +419,7 @@ def main():
             res["other_configs"] = other_configs(args, dev, torch, ops)
     cpu = parity = None
     if world == 1 and not args.no_cpu_baseline:
+        # (rank 0 at N = 1 only, after every timed region of the run)
         cpu, parity = cpu_baseline(model, alp_sd, vol, svol, slab, args, dev)
     res["cpu_baseline"] = cpu
     if parity is not None:
@@ -351,6 +427,7 @@ def main():
     print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    return {"rank": rank, "last_zs": zs, "last_gather": full, "line": res}
 
 
 def extras(args, model, step, ops, psmod, B, torch, dev):

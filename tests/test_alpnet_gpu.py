@@ -264,7 +264,9 @@ def test_conv_frontend_kernels(dev):
 
 def test_resnet101_encoder_and_config1_fewshot(dev):
     """BASELINE config 1's coarse model on the GPU: ResNet-101 (output stride 8) + localconv features and the ALPNet logits
-    of a 256x256 support / query pair, against the oracle's restatement (torchvision absent: parity unpinned)."""
+    of a 256x256 support / query pair, against the oracle's restatement (torchvision absent; oracle/resnet.py is pinned to
+    HuggingFace's ResNet-101 plus the stride-for-dilation identity: tests/test_oracle_resnet_cpu.py). 104 fp16-operand convolutions in a
+    row: the feature error is bounded relative to the map's largest value (measured 1.4e-3 of it)."""
     from oracle import alp as oalp, resnet as ores
     from protosam_amd.grid_proto_fewshot import FewShotSeg
     from protosam_amd.synth import synth_pair, synth_state_dict
@@ -284,7 +286,7 @@ def test_resnet101_encoder_and_config1_fewshot(dev):
     err = (got - ref).abs().max().item()
     cos = torch.nn.functional.cosine_similarity(got.flatten(1), ref.flatten(1)).min().item()
     print(f"ResNet-101 features: max abs err {err:.3e} on values up to {scale:.1f} (rms {ref.pow(2).mean().sqrt():.2f}), cos {cos:.6f}")
-    assert err < 1e-2 * scale and cos > 0.9999
+    assert err < 3e-3 * scale and cos > 0.99999
     out = alp([[s_img.to(dev)]], [[s_m.to(dev)]], [[(1 - s_m).to(dev)]], [q_img.to(dev)], isval=True, val_wsize=2)[0]
     logits_ref = oalp.fewshot_forward_resnet(lambda im: ores.encoder(im, enc_sd), s_img, s_m, q_img, 256)
     assert out.shape == (1, 2, 256, 256)

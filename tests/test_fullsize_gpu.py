@@ -19,11 +19,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-TOL = 1e-3
-# the predicted-IoU scores are not the quantity the north-star tolerance is stated on (the probability map is); they come out of a
-# three-layer MLP on the IoU token and follow the embedding's error with a larger gain: 1.45e-3 at worst over the eight whole-volume
-# records of round 5 (config 3, weights 777), 1.1e-3 on another
-SCORE_TOL = 2e-3
+TOL = 1e-3            # the north-star bound: on sigmoid(low_res_masks), and on the predicted-IoU scores `forward` returns beside the mask
 
 
 def _unpack(bits, S):
@@ -71,9 +67,7 @@ def test_config_full_depth_vs_oracle_record(dev, cfg):
                   f"Dice {d:.5f} ({flips} px)")
             worst = max(worst, perr)
             assert perr <= TOL, (cfg, fname, z, perr)
-            # BASELINE.md's Dice gate (0.999) - or at most 16 threshold-crossing pixels: on a 4 000-pixel mask 0.999 is NINE pixels,
-            # and a probability 5e-4 from the oracle's (inside the 1e-3 bound) moves about that many across 0.5 (measured: 7-14 px)
-            assert serr <= TOL and (d >= 0.999 or flips <= 16), (cfg, fname, z, d, flips)
+            assert serr <= TOL and d >= 0.999, (cfg, fname, z, d, flips)            # BASELINE.md's Dice gate
     print(f"config {cfg}: worst max |dprob(low_res)| {worst:.2e} (bound {TOL:.0e})")
 
 
@@ -157,6 +151,28 @@ def _prompt_difference(prompts, ref, tie_bits):
     return "tolerance"
 
 
+def _redecode_with_oracle_prompts(model, vol_d, z, ref_prompts):
+    """The HIP image encoder + prompt encoder + mask decoder of slice z fed the ORACLE's recorded prompts (`z<z>_prompts`: most confident
+    point, centroid, box per component) through `ProtoSAM.predict_w_points_bbox` - for a slice whose own most-confident point is another
+    one of the oracle's near-ties (an arg-max, not arithmetic), this is the like-for-like comparison of everything downstream of the
+    prompt choice. -> (sigmoid(low_res) [n,256,256], scores [n], final mask [S,S] bool)."""
+    from protosam_amd import ops
+    S = vol_d.shape[-1]
+    q = vol_d[z][None, None].expand(1, 3, S, S).contiguous().float()
+    qd = ops.bilinear_nchw(q, 1024, 1024)                                    # ProtoSAM.py:592-593, then :651-660
+    mm = ops.minmax(qd, 1)
+    u8 = torch.empty((1, 3, 1024, 1024), dtype=torch.uint8, device=qd.device)
+    sam = model.sam
+    ops.sam_patchify(qd, mm, 1024, 16, sam._mean_host, sam._std_host, True, u8out=u8)
+    img = u8[0].permute(1, 2, 0).cpu().numpy()
+    pts = ref_prompts[:, :4].astype(np.float64).reshape(-1, 2, 2)
+    boxes = ref_prompts[:, 4:8].astype(np.float64)
+    masks, scores = model.predict_w_points_bbox(pts, boxes, [None] * len(pts), img, None)
+    prob = torch.sigmoid(torch.from_numpy(np.asarray(model.last_stats["low_res"])))
+    union = np.logical_or.reduce(np.stack(masks))
+    return prob, np.asarray(scores), torch.from_numpy(union[::1024 // S, ::1024 // S].copy())      # 'nearest' to S x S (:674)
+
+
 # (config, weight seed, volume seed): the round-4 records (every slice, weights 1234, volume 0) and, round 5, two more weight draws and
 # one more volume per configuration (config 3: every slice; config 4: every 4th) - oracle/make_fullsize_goldens.py --wseed / --vseed
 VOLUME_VARIANTS = [(3, 1234, 0), (4, 1234, 0), (3, 777, 0), (3, 4242, 0), (3, 1234, 5), (4, 777, 0), (4, 4242, 0), (4, 1234, 5)]
@@ -178,9 +194,11 @@ def test_whole_volume_vs_oracle_masks(dev, cfg, wseed, vseed):
         saturates inside a confident region), where a component's box ends - are compared with the oracle's (`z<z>_prompts`). Equal
         prompts: the bounds above apply in full. A different most-confident point has to be one the oracle's own probabilities put
         within 1e-3 of the component's maximum (`z<z>_tie`), a box edge / centroid may move by one pixel (a border pixel of the coarse
-        mask at p = 0.5); such a slice decodes ANOTHER prompt, so only Dice >= 0.985 is asked of it, and at most one slice in four
-        may be of that kind (measured: 0 ... 5 of 32; the reference's own CPU and CUDA runs differ the same way - torch.topk leaves the
-        order of equal values unspecified)."""
+        mask at p = 0.5); such a slice's own result answers ANOTHER prompt than the record's (Dice >= 0.985 is asked of it, and at most
+        one slice in four may be of that kind - measured 0 ... 5 of 32; the reference's own CPU and CUDA runs differ the same way,
+        torch.topk leaves the order of equal values unspecified), so the slice is decoded AGAIN from the oracle's recorded prompts
+        (`_redecode_with_oracle_prompts`: the HIP encoder and decoder through `ProtoSAM.predict_w_points_bbox`) and THAT result is
+        held to the same bounds as every other slice: no slice of the eight records is exempt from the 1e-3."""
     from oracle.make_fullsize_goldens import volume_record_name
     from protosam_amd.metrics import dice
     from protosam_amd.runner import run_slices
@@ -188,6 +206,7 @@ def test_whole_volume_vs_oracle_masks(dev, cfg, wseed, vseed):
     model, vol_d, sup_imgs, sup_masks, n, _, _ = _volume_setup(dev, cfg, wseed, vseed)
     model.use_cca = False
     zs = [int(z) for z in gold["zs"]] if "zs" in gold.files else list(range(n))
+    redecoded = {}                               # z -> the re-decoding from the oracle's prompts (the same for both paths)
     for name, batch in (("per-slice", 1), ("batched", 16)):
         dices, worst_p, worst_s, flips, bad, amb_used, moved = [], 0.0, 0.0, 0, [], 0.0, []
         step = 16 if batch > 1 else 1            # (one call per slice on the per-slice path: its last_stats hold that slice's logits)
@@ -196,13 +215,13 @@ def test_whole_volume_vs_oracle_masks(dev, cfg, wseed, vseed):
             masks, st = run_slices(model, vol_d, sup_imgs, sup_masks, chunk, dev, batch=batch)
             masks = masks.cpu()
             per = model.last_stats
+            low = iou = sel = None               # (a call whose slices are all empty has no logits: nothing of an earlier call is reused)
             if "low_res" in per:
                 low, iou, sel = per["low_res"].cpu(), per["iou"].cpu(), per["sel"]
             for b, z in enumerate(chunk):
                 ref = _unpack(gold[f"z{z}_mask"], 512)
                 d = dice(masks[b].float(), ref)
                 f = int((masks[b].float() != ref).sum())
-                dices.append(d)
                 if f"z{z}_prompts" in gold.files:
                     stb = per["per_slice"][b] if batch > 1 else per
                     why = _prompt_difference(stb.get("prompts"), gold[f"z{z}_prompts"], gold[f"z{z}_tie"])
@@ -210,7 +229,24 @@ def test_whole_volume_vs_oracle_masks(dev, cfg, wseed, vseed):
                         assert why == "tolerance", (name, z, why)
                         assert d >= 0.985, (name, z, d)
                         moved.append(z)
+                        # ... and everything downstream of the prompt choice, from the ORACLE's prompts, under the full bounds
+                        if z not in redecoded:
+                            redecoded[z] = _redecode_with_oracle_prompts(model, vol_d, z, gold[f"z{z}_prompts"])
+                        p_re, s_re, m_re = redecoded[z]
+                        ref_scores = gold[f"z{z}_scores"]
+                        assert p_re.shape[0] == len(ref_scores) == st[b], (name, z, p_re.shape, len(ref_scores), st[b])
+                        d, f = dice(m_re.float(), ref), int((m_re.float() != ref).sum())
+                        dices.append(d)
+                        flips = max(flips, f)
+                        amb = int(gold[f"z{z}_amb"][0])
+                        amb_used = max(amb_used, f / max(amb, 1))
+                        if f > amb:
+                            bad.append((z, d, f, amb, "re-decoded"))
+                        refp = torch.from_numpy(gold[f"z{z}_prob4"].astype(np.float32) / 65535.0)
+                        worst_p = max(worst_p, (p_re[..., ::4, ::4] - refp).abs().max().item())
+                        worst_s = max(worst_s, float(np.abs(s_re - ref_scores).max()))
                         continue
+                dices.append(d)
                 flips = max(flips, f)
                 if f"z{z}_amb" in gold.files:
                     amb = int(gold[f"z{z}_amb"][0])
@@ -232,9 +268,10 @@ def test_whole_volume_vs_oracle_masks(dev, cfg, wseed, vseed):
               f"most flipped pixels {flips} (at most {amb_used:.2f} of a slice's tolerance-explained count), {below} slice(s) below 0.999, "
               f"max |dprob(low_res)| {worst_p:.2e}, scores {worst_s:.2e}")
         if moved:
-            print(f"    slices whose prompts moved within the tolerance band (another most-confident point among near-ties / a box edge by one pixel): {moved}")
+            print(f"    slices whose prompts moved within the tolerance band (another most-confident point among near-ties / a box edge by one pixel), "
+                  f"re-decoded from the oracle's prompts and included above: {moved}")
         assert len(moved) <= max(1, len(zs) // 4), (name, moved)
-        assert worst_p <= TOL and worst_s <= SCORE_TOL, (name, worst_p, worst_s)
+        assert worst_p <= TOL and worst_s <= TOL, (name, worst_p, worst_s)
         assert np.mean(dices) >= 0.999 and not bad, (name, np.mean(dices), bad)
 
 

@@ -156,3 +156,99 @@ def test_bench_strong_scaling_indexing_world2():
     assert sorted(z for r in res for z in r[2]) == list(range(64))
     import bench
     assert bench.strong_slices(64, 8, 3) == [3, 11, 19, 27, 35, 43, 51, 59]
+
+
+class _HostEvent:
+    def record(self):
+        import time
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
+
+
+class _NullTimer:
+    def summary(self):
+        return 0, 0.0, 0.0
+
+    def by_tag(self):
+        return {}
+
+
+def _fake_mask512(z):
+    g = torch.Generator().manual_seed(7000 + z)
+    return (torch.rand((512, 512), generator=g) > 0.5).to(torch.uint8)
+
+
+class HostRuntime:
+    """bench.DeviceRuntime's interface on the host: gloo instead of RCCL, wall-clock events, no model - `run_slices` hands back a
+    deterministic mask per slice index, so what the all-gather moved can be checked row by row."""
+    backend = "gloo"
+
+    def device(self, local_rank):
+        return torch.device("cpu")
+
+    def init_group(self, local_rank):
+        dist.init_process_group("gloo")
+
+    def sync(self):
+        pass
+
+    def event(self):
+        return _HostEvent()
+
+    def kernel_timer(self):
+        return _NullTimer()
+
+    def power_sampler(self, local_rank):
+        return None
+
+    def build(self, args, dev):
+        return None, {}, None, None, None, torch.zeros((args.slices, 1, 1)), [None] * 3, [None] * 3
+
+    def run_slices(self, model, vol, sup_imgs, sup_masks, zs, dev, out=None, batch=1):
+        if out is None:
+            out = torch.zeros((len(zs), 512, 512), dtype=torch.uint8)
+        for i, z in enumerate(zs):
+            out[i] = _fake_mask512(z)
+        return out[:len(zs)], [1 + (z % 2) for z in zs]
+
+
+def _bench_main_worker(rank, world, port, argv, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import bench
+    r = bench.main(argv, runtime=HostRuntime())
+    B = r["last_gather"].shape[0] // world
+    rows_ok = all(torch.equal(r["last_gather"][rank * B + i], _fake_mask512(z)) for i, z in enumerate(r["last_zs"]))
+    q.put((rank, r["last_zs"], rows_ok, r.get("line"), int(r["last_gather"].shape[0]), torch.get_num_threads(), dist.is_initialized()))
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_main_rank_body_world2(scaling):
+    """bench.main()'s rank body - everything between the launcher and the JSON line - at world 2 under gloo with a stubbed `run_slices`
+    (bench.DeviceRuntime -> HostRuntime): argument handling, the all-gather of rank ids, warm-up, the timed loop with the event pairs
+    around the all-gather, the per-rank reductions, rank 0's line and the teardown. What the first real 8-GPU run can then still find
+    is RCCL and the kernels, not bench.py."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    argv = ["--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4", "--micro", "4", "--slices", "24", "--scaling", scaling]
+    procs = [ctx.Process(target=_bench_main_worker, args=(r, 2, port, argv, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    B = 12 if scaling == "strong" else 4
+    (r0, zs0, ok0, line, rows0, thr0, init0), (r1, zs1, ok1, line1, rows1, thr1, init1) = res
+    assert ok0 and ok1 and rows0 == rows1 == 2 * B and line1 is None and not init0 and not init1       # (process groups destroyed)
+    assert not set(zs0) & set(zs1) and len(zs0) == len(zs1) == B
+    if scaling == "strong":
+        assert sorted(zs0 + zs1) == list(range(24))
+    assert thr0 == thr1 == max(1, (os.cpu_count() or 1) // 2)
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == [0, 1] and line["scaling"] == scaling and line["steps"] == 3
+    assert len(line["per_rank_ms_per_step"]) == 2 and len(line["allgather_ms_per_step"]) == 2
+    assert abs(max(line["per_rank_ms_per_step"]) - line["ms_per_step"]) < 1e-2
+    assert abs(line["value"] * line["ms_per_step"] * 1e-3 - 2 * B) < 1e-2 * 2 * B          # whole-job slices per step / max-over-ranks time
+    assert line["cpu_baseline"] is None and "per_slice_forward" not in line and line["config"]["slices_per_step_per_gpu"] == B
