@@ -520,6 +520,22 @@ def extras(args, model, step, ops, psmod, B, torch, dev):
                             "note": "headline configuration on a volume whose organ (with five satellite blobs) spans 44 % of "
                                     "the slices and whose outer 28 % are air: empty coarse masks skip SAM, organ slices carry "
                                     "4-6 prompt sets"}
+    # (b3) the SAM image encoder's Linear layers at the REFERENCE'S arithmetic width (ImageEncoderViT.gemm_x3: fp32 operands and results,
+    # three fp16 MFMA products on (hi, lo) halves per product; LayerNorm / GELU as fp32 passes; neck and patch embedding on their split
+    # forms; the attention products keep fp16 operands): what the fp16-operand headline buys, with its own parity figure
+    # (`parity_vs_cpu_oracle.reference_width`, same slices)
+    enc = model.sam.image_encoder
+    enc.gemm_x3 = True
+    try:
+        timed(1)
+        dt = timed(2)
+        out["reference_width"] = {"value": round(2 * B / dt, 2), "unit": "slices/s", "dtype": "f32 Linear layers (3 x f16 MFMA on hi / lo halves), f16 attention operands",
+                                  "note": "headline configuration with PSAM_ENCODER_X3=1: every Linear of the SAM ViT blocks through "
+                                          "psam_gemm_f32x3 (fp32 in, fp32 out), fp32 LayerNorm and GELU passes, split-fp16 neck and "
+                                          "exact-pixel patch embedding; DINOv2 and the decoder as in the headline (the decoder's image side "
+                                          "is already at fp32 accuracy). Not a tuned path: the x3 kernel is the decoder's 64 x 128-tile one"}
+    finally:
+        enc.gemm_x3 = False
     # (c) support re-encoded for every slice as the reference does (grid_proto_fewshot.py:181-184)
     alp = model.coarse_segmentation_model.model
     if alp.cache_support:
@@ -680,12 +696,8 @@ def cpu_baseline(model, alp_sd, vol, svol, slab, args, dev):
     msk_d = [m.to(dev) for m in sup_masks]
     vol_d = vol.to(dev)
     torch.set_num_threads(cores)
-    t_all, parities = 0.0, []
-    for z in zs_all:
-        taps = {}
-        t0 = time.perf_counter()
-        pred_ref, scores_ref = oracle_slice(z, taps)
-        t_all += time.perf_counter() - t0
+
+    def gpu_parity(z, pred_ref, scores_ref, taps):
         # GPU result for the same slice THROUGH THE TIMED PATH: a micro-batch of the slice's z-part, as the steps above run them
         part_z = [y for y in range(args.slices) if part_assign(y, args.slices) == part_assign(z, args.slices)]
         i = part_z.index(z)
@@ -702,7 +714,21 @@ def cpu_baseline(model, alp_sd, vol, svol, slab, args, dev):
             low_ref = torch.stack([l[0] for l in taps["low_res"]])
             p["max_abs_dprob_low_res"] = float((torch.sigmoid(low) - torch.sigmoid(low_ref)).abs().max())
             p["max_abs_dscore"] = float(np.abs(st["iou"][span[1]:span[1] + span[2], st["sel"]].cpu().numpy() - np.array(scores_ref)).max())
-        parities.append(p)
+        return p
+    t_all, parities, parities_x3 = 0.0, [], []
+    sam_enc = model.sam.image_encoder
+    for z in zs_all:
+        taps = {}
+        t0 = time.perf_counter()
+        pred_ref, scores_ref = oracle_slice(z, taps)
+        t_all += time.perf_counter() - t0
+        parities.append(gpu_parity(z, pred_ref, scores_ref, taps))
+        if not args.no_extras:        # the same slice with the SAM encoder's Linear layers at the reference's width (`reference_width`)
+            sam_enc.gemm_x3 = True
+            try:
+                parities_x3.append(gpu_parity(z, pred_ref, scores_ref, taps))
+            finally:
+                sam_enc.gemm_x3 = False
     log(f"cpu_baseline: {len(zs_all)} slices in {t_all:.1f}s on {cores} threads")
     cpu = {"value": round(len(zs_all) / t_all, 5), "unit": "slices/s", "cores": cores, "kind": "port",
            "sample": f"{len(zs_all)} slices (z = {zs_all}) of the same volume through the full CPU oracle pipeline "
@@ -721,6 +747,10 @@ def cpu_baseline(model, alp_sd, vol, svol, slab, args, dev):
     worst = max((p.get("max_abs_dprob_low_res", 0.0) for p in parities), default=0.0)
     parity = {"slices": parities, "worst_max_abs_dprob_low_res": worst, "bound": 1e-3,
               "min_dice_final_mask": min(p["dice_final_mask"] for p in parities)}
+    if parities_x3:
+        parity["reference_width"] = {"slices": parities_x3, "bound": 1e-3,
+                                     "worst_max_abs_dprob_low_res": max((p.get("max_abs_dprob_low_res", 0.0) for p in parities_x3), default=0.0),
+                                     "min_dice_final_mask": min(p["dice_final_mask"] for p in parities_x3)}
     return cpu, parity
 
 

@@ -157,6 +157,11 @@ int psam_normalize_chw(const void* x, int in_u8, int B, long long plane, const f
 /* im2col of the neck's 3x3/pad-1 conv on a token-major half map. image_encoder.py:98-104 */
 int psam_im2col3x3(const void* in, int B, int H, int W, int C, void* out, void* stream);
 int psam_cast_f16(const float* x, void* y, long long n, void* stream);
+/* The element-wise passes of the reference-width mode of the SAM image encoder (every Linear of a block through psam_gemm_f32x3, fp32 in
+ * and out): half -> fp32 (the attention output on its way to attn.proj, modeling/image_encoder.py:249; n % 8 == 0) and nn.GELU in its erf
+ * form, in place on fp32 (MLPBlock, modeling/common.py:25-26; n % 4 == 0). */
+int psam_cast_f32(const void* x, float* y, long long n, void* stream);
+int psam_gelu_f32(float* x, long long n, void* stream);
 /* fp32 -> fp16 pair hi = half(x), lo = half(x - hi) (write_hi = 0: hi is read, e.g. the copy a folded-LayerNorm GEMM wrote). Operands of
  * the split-fp16 GEMMs (hi W_hi + lo W_hi + hi W_lo) of the image encoder's neck: modeling/image_encoder.py:90-106. n % 8 == 0. */
 int psam_split_f16(const float* x, void* hi, void* lo, long long n, int write_hi, void* stream);

@@ -45,6 +45,8 @@ SIGNATURES = {
     "psam_minmax": [c_void_p, c_int, c_longlong, c_void_p, c_void_p],
     "psam_im2col3x3": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "psam_cast_f16": [c_void_p, c_void_p, c_longlong, c_void_p],
+    "psam_cast_f32": [c_void_p, c_void_p, c_longlong, c_void_p],
+    "psam_gelu_f32": [c_void_p, c_longlong, c_void_p],
     "psam_split_f16": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_void_p],
     "psam_small_linear": [c_void_p] * 6 + [c_int] * 4 + [c_longlong] * 4 + [c_int] * 3 + [c_void_p],
     "psam_small_attention": [c_void_p] * 4 + [c_int] * 10 + [c_void_p],

@@ -356,6 +356,39 @@ extern "C" int psam_cast_f16(const float* x, void* y, long long n, void* stream)
   return psam_launch_status();
 }
 
+// The two element-wise passes of the reference-width mode of the SAM image encoder (ImageEncoderViT.gemm_x3: every Linear of the blocks at
+// fp32 accuracy through psam_gemm_f32x3, whose operands and results are fp32): the attention output (fp16) back to fp32 for the
+// projection, and nn.GELU (erf form, modeling/common.py:13-26) between lin1 and lin2, in place. HBM-bound, 16 bytes per lane.
+__global__ void cast_f32_kernel(const half_t* __restrict__ x, float* __restrict__ y, size_t n8) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const half8_t h = reinterpret_cast<const half8_t*>(x)[i];
+  reinterpret_cast<float4*>(y)[2 * i] = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+  reinterpret_cast<float4*>(y)[2 * i + 1] = make_float4((float)h[4], (float)h[5], (float)h[6], (float)h[7]);
+}
+extern "C" int psam_cast_f32(const void* x, float* y, long long n, void* stream) {
+  if (n <= 0 || (n & 7)) return PSAM_ERR_ARG;
+  size_t n8 = (size_t)n / 8;
+  hipLaunchKernelGGL(cast_f32_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, y, n8);
+  return psam_launch_status();
+}
+__global__ void gelu_f32_kernel(float* __restrict__ x, size_t n4) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float4 v = reinterpret_cast<float4*>(x)[i];
+  v.x = 0.5f * v.x * (1.0f + erff(v.x * 0.70710678118654752440f));
+  v.y = 0.5f * v.y * (1.0f + erff(v.y * 0.70710678118654752440f));
+  v.z = 0.5f * v.z * (1.0f + erff(v.z * 0.70710678118654752440f));
+  v.w = 0.5f * v.w * (1.0f + erff(v.w * 0.70710678118654752440f));
+  reinterpret_cast<float4*>(x)[i] = v;
+}
+extern "C" int psam_gelu_f32(float* x, long long n, void* stream) {
+  if (n <= 0 || (n & 3)) return PSAM_ERR_ARG;
+  size_t n4 = (size_t)n / 4;
+  hipLaunchKernelGGL(gelu_f32_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n4);
+  return psam_launch_status();
+}
+
 // fp32 -> (hi, lo) fp16 pair: hi = half(x) (written when `hi_out`, else read: the folded-LayerNorm GEMM already wrote it), lo = half(x -
 // float(hi)). A GEMM on [hi | lo] against [W_hi | W_lo] (three products: hi W_hi + lo W_hi + hi W_lo) then carries ~22 mantissa bits of
 // both operands: used for the neck of the SAM image encoder, whose fp16-operand GEMMs alone were 4.0e-4 of the 6.4e-4 embedding error

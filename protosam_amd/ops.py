@@ -617,6 +617,27 @@ def cast_f16(x, out=None):
     return out
 
 
+def cast_f32(x, out=None):
+    """fp16 -> fp32 (the reference-width encoder mode: the attention output on its way to psam_gemm_f32x3)."""
+    _req(x, torch.float16, "x")
+    assert x.is_contiguous()
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    _req(out, torch.float32, "out")
+    st = _lib.lib().psam_cast_f32(_ptr(x), _ptr(out), x.numel(), _stream())
+    _lib.check(st, "psam_cast_f32")
+    return out
+
+
+def gelu_f32_(x):
+    """nn.GELU (erf form) in place on fp32 (the reference-width encoder mode, between lin1 and lin2)."""
+    _req(x, torch.float32, "x")
+    assert x.is_contiguous()
+    st = _lib.lib().psam_gelu_f32(_ptr(x), x.numel(), _stream())
+    _lib.check(st, "psam_gelu_f32")
+    return x
+
+
 def split_f16(x, hi=None, lo=None, write_hi=True):
     """fp32 x -> (hi = half(x), lo = half(x - hi)); write_hi=False: `hi` already holds half(x) (a folded-LayerNorm GEMM wrote it)."""
     _req(x, torch.float32, "x")

@@ -548,7 +548,7 @@ class ProtoSAM(nn.Module):
         mm, patches = bufs["mm"][:2 * B], bufs["patches"][:B * 4096]       # B may be a sub-batch (non-empty slices only)
         ops.minmax(q, B, mm=mm)
         enc = sam.image_encoder
-        if getattr(enc, "split_fp16", False):
+        if getattr(enc, "split_fp16", False) or getattr(enc, "gemm_x3", False):
             # the quantised pixel values themselves (0 ... 255 are exact in fp16); Sam.preprocess' (x - mean) / std lives in the patch-
             # embedding weights (ImageEncoderViT._patch_raw): no fp16 rounding of the normalised pixels
             ops.sam_patchify(q, mm, S, enc.patch_size, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), True, out=patches)

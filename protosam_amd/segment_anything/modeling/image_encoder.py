@@ -216,6 +216,12 @@ class ImageEncoderViT(nn.Module):
         # the 6.4e-4 embedding error; they are 2.5 % of the encoder's FLOPs. PSAM_SPLIT_FP16=0: plain fp16 operands (A/B).
         self.split_fp16 = os.environ.get("PSAM_SPLIT_FP16", "0") != "0"
         self._split_parts = os.environ.get("PSAM_SPLIT_PARTS", "neck,patch").split(",")     # (A/B of the two halves)
+        # Reference-width mode (round 6; PSAM_ENCODER_X3=1 / `gemm_x3 = True`): EVERY Linear of the blocks at fp32 accuracy - operands
+        # AND results fp32, three fp16 MFMA products on (hi, lo) halves (ops.gemm_f32x3, the decoder's image-side kernel), LayerNorm and
+        # GELU as fp32 passes, the neck and the patch embedding on their split forms; only the attention products (QK^T, PV) keep fp16
+        # operands. Not a throughput path (3x the matrix work on a kernel tuned for the decoder's shapes, fp32 activations in HBM): it
+        # is the "same arithmetic width as the reference" line of bench.py beside the fp16-operand headline, with its own parity figure.
+        self.gemm_x3 = os.environ.get("PSAM_ENCODER_X3", "0") != "0"
 
     def _apply(self, fn, *a, **k):
         self._packed, self._ws = None, {}
@@ -302,11 +308,43 @@ class ImageEncoderViT(nn.Module):
             ws["relw"] = torch.empty((B, H, N, 64), dtype=torch.float32, device=dev)
         return ws["relh"], ws["relw"]
 
+    def _pack_x3(self, pk):
+        """(hi, lo, scale) splits of the blocks' four Linear weights for ops.gemm_f32x3 (one-time, only when `gemm_x3` runs)."""
+        if "x3" not in pk:
+            def sp(w):
+                sc = ops.split_scale_for(w, ops.X3_WEIGHT_SCALE)
+                return ops.split_weight_f16(w, sc) + (sc,)
+            pk["x3"] = [dict(qkv=sp(b.attn.qkv.weight), proj=sp(b.attn.proj.weight), l1=sp(b.mlp.lin1.weight), l2=sp(b.mlp.lin2.weight))
+                        for b in self.blocks]
+        return pk["x3"]
+
+    def _encode_blocks_x3(self, pk, ws, B):
+        """The block stack with every Linear at fp32 accuracy (see `gemm_x3`): x fp32 [M, D] in ws["x"], updated in place."""
+        D, H, N, g = self.embed_dim, self.num_heads, self.grid * self.grid, self.grid
+        M = B * N
+        x = ws["x"]
+        if "ln32" not in ws:
+            e = lambda shape, dt: torch.empty(shape, dtype=dt, device=x.device)  # noqa: E731
+            ws["ln32"], ws["qkv32"], ws["hid32"] = e((M, D), torch.float32), e((M, 3 * D), torch.float32), e((M, 4 * D), torch.float32)
+        ln32, qkv32, hid32 = ws["ln32"], ws["qkv32"], ws["hid32"]
+        for blk, bp, xp in zip(self.blocks, pk["blocks"], self._pack_x3(pk)):
+            ops.layernorm(x, bp["n1w"], bp["n1b"], LN_EPS, out=ln32, out_dtype=torch.float32)
+            ops.gemm_f32x3(ln32, xp["qkv"], bp["qkv_b"], out=qkv32)
+            ops.cast_f16(qkv32, ws["qkv"])                                          # the attention kernels' operand format
+            blk.attn._attend(ws["qkv"], B, g, bp["ws"], bp["rpack"], bp["pad_row"], out=ws["att"], relq=ws["relq"],
+                             rel_bufs=lambda: self._rel_buffers(ws, B, H, N))
+            ops.cast_f32(ws["att"], ln32)
+            ops.gemm_f32x3(ln32, xp["proj"], bp["proj_b"], out=x, resid=x)
+            ops.layernorm(x, bp["n2w"], bp["n2b"], LN_EPS, out=ln32, out_dtype=torch.float32)
+            ops.gemm_f32x3(ln32, xp["l1"], bp["l1b"], out=hid32)
+            ops.gelu_f32_(hid32)
+            ops.gemm_f32x3(hid32, xp["l2"], bp["l2b"], out=x, resid=x)
+
     def encode_patches(self, patches, B, raw_norm=None):
         """One or two slices: a captured HIP graph of the forward's launches (ops.GraphCache; ~330 for ViT-H), else `_encode_patches`.
         raw_norm = (mean3, std3): `patches` hold RAW uint8 pixel values (exact in fp16) and the normalisation is folded into the
         patch-embedding weights (`split_fp16`)."""
-        if B <= 2 and ops.graph_wanted(patches, 2 * self.grid * self.grid):
+        if B <= 2 and not self.gemm_x3 and ops.graph_wanted(patches, 2 * self.grid * self.grid):
             gc = self.__dict__.setdefault("_graphs", ops.GraphCache("the SAM image encoder forward"))
             key = (tuple(patches.shape), B, str(patches.device), getattr(self, "_weights_epoch", 0), self.fold_ln,
                    getattr(self, "fold_min_fill", None), ops.dispatch_key(), self.split_fp16,
@@ -327,10 +365,10 @@ class ImageEncoderViT(nn.Module):
         D, H, N, g = self.embed_dim, self.num_heads, self.grid * self.grid, self.grid
         hd = D // H
         x = ws["x"]
-        fold = self.fold_ln and not ops.QKV_HEAD_MAJOR and D % 64 == 0
+        x3 = self.gemm_x3 and not ops.QKV_HEAD_MAJOR
+        fold = self.fold_ln and not ops.QKV_HEAD_MAJOR and D % 64 == 0 and not x3
         M = B * N
         fold = fold and ops.fold_pays(M, D, x.device, self.fold_min_fill)   # (small launches: separate passes are faster)
-        M = B * N
         x16, stats, mr = ws["ln"], ws["stats"], ws["mr"]
         fk = dict(out16=x16, stats=stats) if fold else {}
         if raw_norm is not None:     # exact uint8 pixel values against the split (hi + lo) weights of the folded normalisation
@@ -342,7 +380,9 @@ class ImageEncoderViT(nn.Module):
                 ops.gemm(patches, pw_hi, pb, out=x, epilogue=ops.EPI_F32, resid=pk["pos"], resid_mod=N, **fk)
         else:
             ops.gemm(patches, pk["patch_w"], pk["patch_b"], out=x, epilogue=ops.EPI_F32, resid=pk["pos"], resid_mod=N, **fk)
-        for blk, bp in zip(self.blocks, pk["blocks"]):
+        if x3:
+            self._encode_blocks_x3(pk, ws, B)
+        for blk, bp in zip(self.blocks if not x3 else (), pk["blocks"]):
             if fold:
                 ops.ln_finalize(stats, M, D, LN_EPS, mr=mr)
                 ops.gemm(x16, bp["qkv_wf"], bp["qkv_t"], out=ws["qkv"], epilogue=ops.EPI_F16, ln_mr=mr, ln_s=bp["qkv_s"])
@@ -365,7 +405,7 @@ class ImageEncoderViT(nn.Module):
         # neck (image_encoder.py:90-106): the residual stream goes through the 1x1-conv GEMM as fp16 (with `fold_ln` the last
         # lin2 epilogue already wrote that copy)
         xh = ws["ln"]
-        if self.split_fp16 and "neck" in self._split_parts:
+        if (self.split_fp16 and "neck" in self._split_parts) or x3:
             # (hi, lo) pairs of the activations and of the weights: hi W_hi + lo W_hi + hi W_lo, accumulated in the fp32 output
             self._split_buffers(ws, M)
             ops.split_f16(x, hi=xh, lo=ws["ln_lo"], write_hi=not fold)

@@ -250,3 +250,35 @@ def test_image_encoder_split_fp16_neck_and_patch_embedding(dev):
               f"split neck + exact-pixel patch embedding max {errs[True].max():.3e} mean {errs[True].mean():.3e}")
         assert errs[True].max() < bound
         assert errs[True].mean() <= errs[False].mean() * (0.25 if depth == 0 else 1.02)
+
+
+@pytest.mark.parametrize("model_type,depth", [("vit_b", 3), ("vit_h", 4)])
+def test_image_encoder_reference_width_mode(dev, model_type, depth):
+    """Round 6 (`gemm_x3`, PSAM_ENCODER_X3=1): every Linear of the blocks at fp32 accuracy (fp32 operands and results, psam_gemm_f32x3),
+    LayerNorm / GELU as fp32 passes, split neck + exact-pixel patch embedding; only QK^T / PV keep fp16 operands. Against the fp32 oracle
+    the embedding error has to drop well below the fp16-operand default's (what remains is the attention's operand rounding)."""
+    from oracle import sam_image_encoder as oenc
+    from protosam_amd import ops
+    sam, sd = _sam(dev, model_type, depth)
+    enc = sam.image_encoder
+    img = _image(6)
+    x = (img.float() - torch.tensor([123.675, 116.28, 103.53]).view(1, 3, 1, 1)) / torch.tensor(
+        [58.395, 57.12, 57.375]).view(1, 3, 1, 1)
+    ref = oenc.image_encoder(x, sd, model_type=model_type, depth=depth)
+    patches = ops.patchify_bilinear(img.float().to(dev).contiguous(), 1024, 16, 768)
+    errs = {}
+    for x3 in (False, True):
+        enc.gemm_x3 = x3
+        if x3:
+            tok = enc.encode_patches(patches, 1, raw_norm=(sam._mean_host, sam._std_host))
+        else:
+            tok = enc.forward_tokens(sam.preprocess(img.to(dev)))
+        errs[x3] = (tok.view(1, 64, 64, 256).permute(0, 3, 1, 2).cpu() - ref).abs()
+    enc.gemm_x3 = False
+    print(f"{model_type} depth {depth}: fp16 operands max {errs[False].max():.3e} mean {errs[False].mean():.3e}; reference-width GEMMs "
+          f"max {errs[True].max():.3e} mean {errs[True].mean():.3e} (ref rms {ref.pow(2).mean().sqrt():.3f})")
+    assert errs[True].mean() < 0.5 * errs[False].mean() and errs[True].max() < errs[False].max()
+    h = torch.randn((1000, 64), generator=torch.Generator().manual_seed(1)).half().to(dev)
+    assert torch.equal(ops.cast_f32(h), h.float())
+    g = torch.randn((1000, 64), generator=torch.Generator().manual_seed(2)).to(dev) * 3
+    torch.testing.assert_close(ops.gelu_f32_(g.clone()), torch.nn.functional.gelu(g), rtol=1e-6, atol=1e-6)
