@@ -199,15 +199,25 @@ class DeviceRuntime:
     argument handling, step indexing, the all-gather, the reductions, the JSON line, the teardown - runs at world 2 without a GPU."""
     backend = "nccl"
 
+    def __init__(self):
+        # PSAM_BENCH_BACKEND=gloo + PSAM_BENCH_SHARE_GPU=1: the whole N > 1 body with live models on a box with ONE GPU (every rank on
+        # cuda:0, collectives staged through the host) - a functional check of the multi-rank path, never a throughput number
+        self.backend = os.environ.get("PSAM_BENCH_BACKEND", "nccl")
+        self.share_gpu = os.environ.get("PSAM_BENCH_SHARE_GPU", "0") != "0"
+
     def device(self, local_rank):
         import torch
-        torch.cuda.set_device(local_rank)
-        return torch.device(f"cuda:{local_rank}")
+        idx = 0 if self.share_gpu else local_rank
+        torch.cuda.set_device(idx)
+        return torch.device(f"cuda:{idx}")
 
     def init_group(self, local_rank):
         import torch
         import torch.distributed as dist
-        dist.init_process_group(self.backend, device_id=torch.device(f"cuda:{local_rank}"))
+        if self.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{0 if self.share_gpu else local_rank}"))
+        else:
+            dist.init_process_group(self.backend)
 
     def sync(self):
         import torch
@@ -262,7 +272,7 @@ def main(argv=None, runtime=None):
     dev = rt.device(local_rank)
 
     from protosam_amd import ops, protosam as psmod
-    from protosam_amd.runner import gather_masks, part_assign
+    from protosam_amd.runner import all_gather_rows, gather_masks, part_assign
 
     t0 = time.time()
     model, alp_sd, vol, svol, slab, vol_d, sup_imgs, sup_masks = rt.build(args, dev)
@@ -272,8 +282,7 @@ def main(argv=None, runtime=None):
     if world > 1:
         # every rank's id through the same collective the masks take (RCCL all-gather on the device): the job really has `world`
         # distinct ranks talking to each other before anything is timed
-        ids = torch.empty(world, dtype=torch.int32, device=dev)
-        dist.all_gather_into_tensor(ids, torch.tensor([rank], dtype=torch.int32, device=dev))
+        ids = all_gather_rows(torch.tensor([rank], dtype=torch.int32, device=dev))
         ranks_seen = sorted(int(v) for v in ids.cpu())
         if ranks_seen != list(range(world)):
             raise SystemExit(f"rank {rank}: the all-gather of rank ids returned {ranks_seen}, expected 0..{world - 1}")
@@ -346,9 +355,7 @@ def main(argv=None, runtime=None):
         # per-rank wall time of the timed region (its max is the job's time) and each rank's mean all-gather time, on rank 0's line
         mine = torch.tensor([elapsed, sum(a.elapsed_time(b) for a, b in ag_events) / max(len(ag_events), 1) * 1e-3],
                             dtype=torch.float64, device=dev)
-        every = torch.empty((world, 2), dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(every, mine.view(1, 2))
-        every = every.cpu()
+        every = all_gather_rows(mine.view(1, 2)).cpu()
         per_rank_ms = [round(float(v) / args.steps * 1e3, 3) for v in every[:, 0]]
         allgather_ms = [round(float(v) * 1e3, 3) for v in every[:, 1]]
         elapsed = float(every[:, 0].max())
@@ -399,6 +406,7 @@ def main(argv=None, runtime=None):
         # maximum) and its mean time inside the step's all-gather of uint8 masks (HIP events around the collective: it includes
         # waiting for the slowest rank's masks, so it is an upper bound of the transfer itself)
         "ranks_seen": ranks_seen, "per_rank_ms_per_step": per_rank_ms, "allgather_ms_per_step": allgather_ms,
+        "collective_backend": (dist.get_backend() if world > 1 else None),
         "host_threads_per_rank": torch.get_num_threads(),
         "ms_per_step_std": round(float(np.std(step_ms)), 3), "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f16", "data": "synthetic",

@@ -108,8 +108,20 @@ def gather_masks(local, world):
     """One all-gather of the per-rank uint8 masks (RCCL on GPUs, gloo on CPU). [k,S,S] -> [world*k,S,S] (rank-major)."""
     if world == 1 or not dist.is_initialized():
         return local
+    return all_gather_rows(local)
+
+
+def all_gather_rows(local):
+    """dist.all_gather_into_tensor along dim 0. Device tensors go through RCCL as they are; under the gloo backend (the CPU tests, and
+    the two-ranks-on-one-GPU test of the real pipeline, where RCCL refuses two ranks on one device) they are staged through the host."""
+    world = dist.get_world_size()
+    local = local.contiguous()
+    if local.is_cuda and dist.get_backend() == "gloo":
+        host = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype)
+        dist.all_gather_into_tensor(host, local.cpu())
+        return host.to(local.device)
     full = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(full, local.contiguous())
+    dist.all_gather_into_tensor(full, local)
     return full
 
 
