@@ -54,6 +54,20 @@ int psam_gemm_f16_ln(const void* A, const void* W, const float* bias, void* out,
 int psam_ln_finalize(const float* stats, int M, int D, float eps, float* mr, void* stream);
 
 
+/* One slice through a residual Linear with FEW 256 x 256 tiles and a LONG K (SAM ViT-H mlp.lin2 of one image: 4096 x 1280 x 5120, 80 tiles
+ * for 256 CUs), and the LayerNorm that follows it in the block stack, as one split-K launch of the assembly tile + one reduce pass:
+ *   x[M,N] (fp32, in place) += A[M,K] . W[N,K]^T + bias;  out16 (optional half [M, ld16]) = LayerNorm(x; ln_w, ln_b, eps), or half(x) when
+ *   ln_w is null.
+ * `ks` K ranges per tile (ks * tiles workgroups side by side); ws: CALLER-OWNED fp32 scratch of >= ks * Mp * N elements, Mp = M rounded up
+ * to a multiple of 256 (the library keeps no
+ * state for this path: it may be captured into a graph); the ranges are summed in a fixed order (deterministic).
+ * psam_gemm_splitk_ranges returns the ks this device would use for the shape (0: the shape does not pay, or the assembly kernel is not
+ * loaded) - a count, not a status; psam_gemm_f16_splitk_ln takes exactly that ks (>= 2), N % 256 == 0, N <= 2048, K % 64 == 0.
+ * modeling/common.py:13-26 (MLPBlock.lin2) + image_encoder.py:174-193 (x = x + mlp(...), then the next block's norm1). */
+int psam_gemm_splitk_ranges(int M, int N, int K);
+int psam_gemm_f16_splitk_ln(const void* A, const void* W, const float* bias, float* x, int M, int N, int K, int lda, int ldw, int ldx,
+                            int ks, float* ws, const float* ln_w, const float* ln_b, float eps, void* out16, int ld16, void* stream);
+
 /* Tile override for psam_gemm_f16: 0 auto (default; also env PSAM_GEMM_TILE), 1 = 128x128x64 (HIP), 11 = 256x256x64 persistent
  * 8-wave kernel (HIP), 15 = assembly kernels (csrc/gemm_asm_gen.py, the default large tile), 16 = half-tile ping-pong assembly
  * kernels (csrc/gemm_asm2_gen.py, experimental); a tile that cannot take the call's layout falls back (16 -> 15 -> 11 -> 1). */

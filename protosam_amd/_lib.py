@@ -21,6 +21,9 @@ SIGNATURES = {
     "psam_gemm_f16_heads": [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p],
     "psam_gemm_f16_ln": [c_void_p] * 6 + [c_int] * 12 + [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "psam_ln_finalize": [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p],
+    "psam_gemm_splitk_ranges": [c_int, c_int, c_int],
+    "psam_gemm_f16_splitk_ln": [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int,
+                                c_void_p],
     "psam_gemm_set_tile": [c_int],
     "psam_gemm_asm_variant": [c_int],
     "psam_gemm_set_option": [ctypes.c_char_p, c_int],

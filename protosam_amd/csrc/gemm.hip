@@ -1491,6 +1491,160 @@ static int launch_asm(const GemmArgs& p, int epilogue, hipStream_t s, int family
   return PSAM_OK;
 }
 
+// ---- split-K on the assembly tile for ONE slice through a long-K residual GEMM (round 6) ---------------------------------------
+// One SAM ViT-H image through mlp.lin2 is 4096 x 1280 x 5120: 80 tiles of 256 x 256 for 256 CUs - the half-tile kernels reach 160
+// items (67 us, 0.6 of the chip). Here an item is (tile, K range): 80 x 3 = 240 workgroups side by side, each over 26-27 K-tiles of
+// psam_gemm_asm_f32_sk (the tile-15 k-loop; plain fp32 stores of the partial sums to plane r of a CALLER-OWNED workspace, so the path
+// is safe inside a captured graph: nothing is shared between streams or graphs), then ONE pass that finishes the residual update
+// AND the LayerNorm that follows it in the block stack: x += bias + sum_r plane_r (fixed order: deterministic), out16 = LN(x) - the
+// separate LayerNorm pass of the one-slice path disappears. modeling/common.py:13-26 + image_encoder.py:174-193.
+static const AsmTable* asm_table_splitk(int ntm, int ntn, int ks) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (ntm >= 4096 || ntn >= (1 << 16) || ks < 2 || ks > 8) return nullptr;
+  const unsigned long long key = (1ull << 63) | ((unsigned long long)eff_cus() << 52) | ((unsigned long long)ntm << 40) | ((unsigned long long)ntn << 20) |
+                                 ((unsigned long long)ks << 8) | (unsigned)dev;
+  auto it = g_asm_tabs.find(key);
+  if (it != g_asm_tabs.end()) return &it->second;
+  const int mode = pick_map_mode(ntm, ntn);
+  const int ntiles = tile_map_grid(ntm, ntn, mode);
+  std::vector<int> items;                                  // the ranges of a tile are neighbours: they share both operand panels' rows
+  for (int idx = 0; idx < ntiles; ++idx) {
+    int tm = 0, tn = 0;
+    if (!tile_map(idx, ntm, ntn, mode, tm, tn)) continue;
+    for (int r = 0; r < ks; ++r) items.push_back(tm | (r << 12) | (tn << 16));
+  }
+  const int total = (int)items.size();
+  const int G = total < eff_cus() ? total : eff_cus();
+  const size_t rows = (size_t)(total + G - 1) / G + 3;
+  std::vector<int> h(rows * G, -1);
+  for (int i = 0; i < total; ++i) h[(size_t)(i / G) * G + (i % G)] = items[i];
+  AsmTable t;
+  t.grid = G;
+  t.dev = nullptr;
+  if (hipMalloc((void**)&t.dev, h.size() * sizeof(int)) != hipSuccess) return nullptr;
+  if (hipMemcpy(t.dev, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  return &(g_asm_tabs[key] = t);
+}
+
+// x[M,N] (fp32, ldx) += bias + sum over the ks planes of ws ([ks][Mp][N] fp32, Mp = M rounded up to whole 256-row tiles) in the order r = 0, 1, ...; then, per row,
+// out16 = fp16(LayerNorm(x) * ln_w + ln_b) (two-pass mean / variance as layernorm_kernel) or fp16(x) when ln_w is null. One wave per
+// row, the row in registers. HBM: (ks + 1) * 4 N read, 4 N + 2 N written per row.
+#define SKR_MAXV 8      // N <= 64 * 4 * 8 = 2048
+__global__ __launch_bounds__(256) void splitk_reduce_ln_kernel(const float* __restrict__ ws, int ks, const float* __restrict__ bias,
+                                                               float* __restrict__ x, int ldx, const float* __restrict__ ln_w,
+                                                               const float* __restrict__ ln_b, float eps, half_t* __restrict__ out16, int ld16,
+                                                               int M, int N) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const int nv = N >> 2;
+  const size_t Mp = (size_t)((M + 255) & ~255);
+  float4 v[SKR_MAXV];
+  float* xr = x + (size_t)row * ldx;
+#pragma unroll
+  for (int k = 0; k < SKR_MAXV; ++k) {
+    const int i = lane + 64 * k;
+    if (i < nv) v[k] = bias ? reinterpret_cast<const float4*>(bias)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int r = 0; r < ks; ++r) {
+    const float4* pr = reinterpret_cast<const float4*>(ws + ((size_t)r * Mp + row) * N);
+#pragma unroll
+    for (int k = 0; k < SKR_MAXV; ++k) {
+      const int i = lane + 64 * k;
+      if (i < nv) { const float4 q = pr[i]; v[k].x += q.x; v[k].y += q.y; v[k].z += q.z; v[k].w += q.w; }
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < SKR_MAXV; ++k) {
+    const int i = lane + 64 * k;
+    if (i < nv) {
+      const float4 q = reinterpret_cast<const float4*>(xr)[i];
+      v[k].x += q.x; v[k].y += q.y; v[k].z += q.z; v[k].w += q.w;
+      reinterpret_cast<float4*>(xr)[i] = v[k];
+      s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    }
+  }
+  if (!out16) return;
+  float mean = 0.f, rstd = 1.f;
+  if (ln_w) {
+    mean = wave_sum(s) / (float)N;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < SKR_MAXV; ++k) {
+      const int i = lane + 64 * k;
+      if (i < nv) {
+        const float a = v[k].x - mean, c = v[k].y - mean, d = v[k].z - mean, e = v[k].w - mean;
+        q += (a * a + c * c) + (d * d + e * e);
+      }
+    }
+    rstd = 1.0f / sqrtf(wave_sum(q) / (float)N + eps);
+  }
+#pragma unroll
+  for (int k = 0; k < SKR_MAXV; ++k) {
+    const int i = lane + 64 * k;
+    if (i < nv) {
+      float o0 = v[k].x, o1 = v[k].y, o2 = v[k].z, o3 = v[k].w;
+      if (ln_w) {
+        const float4 ww = reinterpret_cast<const float4*>(ln_w)[i], bb = reinterpret_cast<const float4*>(ln_b)[i];
+        o0 = (o0 - mean) * rstd * ww.x + bb.x; o1 = (o1 - mean) * rstd * ww.y + bb.y;
+        o2 = (o2 - mean) * rstd * ww.z + bb.z; o3 = (o3 - mean) * rstd * ww.w + bb.w;
+      }
+      half4_t h = {(half_t)o0, (half_t)o1, (half_t)o2, (half_t)o3};
+      *reinterpret_cast<half4_t*>(out16 + (size_t)row * ld16 + i * 4) = h;
+    }
+  }
+}
+
+// How many K ranges psam_gemm_f16_splitk_ln would use for this shape on this device (0: the shape does not pay - few tiles AND a long K
+// are needed: every range keeps >= 16 K-tiles, the items fill >= 3/4 of the CUs in one round; or the assembly kernel is not loaded).
+extern "C" int psam_gemm_splitk_ranges(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0 || (N % 256) || (K % 64) || N > 64 * 4 * SKR_MAXV) return 0;
+  const int tiles = ((M + 255) / 256) * (N / 256), nkt = K / 64, ncu = eff_cus();
+  if (tiles * 2 > ncu) return 0;
+  int ks = ncu / tiles;
+  if (ks > 8) ks = 8;
+  while (ks >= 2 && nkt / ks < 16) --ks;
+  if (ks < 2 || tiles * ks * 4 < ncu * 3) return 0;
+  return psam_asm_function("psam_gemm_asm_f32_sk") ? ks : 0;
+}
+
+// x[M,N] (fp32, in place) += A[M,K] . W[N,K]^T + bias; out16 (optional, fp16 [M, ld16]) = LayerNorm(x; ln_w, ln_b, eps), or fp16(x) when
+// ln_w is null. ws: caller-owned fp32 scratch of at least ks * Mp * N elements, Mp = M rounded up to a multiple of 256 (ks =
+// psam_gemm_splitk_ranges(M, N, K), which must be >= 2).
+// Deterministic; touches no library-owned state, so it may be captured into a graph.
+extern "C" int psam_gemm_f16_splitk_ln(const void* A, const void* W, const float* bias, float* x, int M, int N, int K, int lda, int ldw,
+                                       int ldx, int ks, float* ws, const float* ln_w, const float* ln_b, float eps, void* out16, int ld16,
+                                       void* stream) {
+  if (ks < 2 || ks > 8 || ks != psam_gemm_splitk_ranges(M, N, K) || !ws || !x || (ldx % 4) || (ln_w && !ln_b) || (out16 && (ld16 % 4)))
+    return PSAM_ERR_ARG;
+  if ((reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(ln_w) |
+       reinterpret_cast<uintptr_t>(ln_b)) & 15 || (reinterpret_cast<uintptr_t>(out16) & 7))
+    return PSAM_ERR_ARG;
+  GemmArgs p;
+  p.A = (const half_t*)A; p.W = (const half_t*)W; p.bias = nullptr; p.out = ws; p.resid = nullptr; p.gamma = nullptr;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldo = N; p.ldr = 0;
+  p.resid_mod = 0; p.out_seg = 0; p.out_seg_stride = 0; p.out_seg_off = 0; p.map_mode = 0; p.head_hd = 0;
+  p.out16 = nullptr; p.ld16 = 0; p.stats = nullptr; p.ln_mr = nullptr; p.ln_s = nullptr; p.wide16 = false; p.ksplit = 1; p.ks_ws = nullptr;
+  if (!asm_eligible(p, EPI_F32, 0) || (unsigned long long)ks * ((M + 255) & ~255) * N * 4 > 0xffffffffull) return PSAM_ERR_ARG;
+  hipFunction_t fn = psam_asm_function("psam_gemm_asm_f32_sk");
+  const AsmTable* t = asm_table_splitk((M + 255) / 256, N / 256, ks);
+  if (!fn || !t) return PSAM_ERR_LAUNCH;
+  AsmGemmArgs a;
+  a.A = A; a.W = W; a.bias = nullptr; a.out = ws; a.resid = nullptr; a.gamma = nullptr; a.tab = t->dev;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldo = N; a.ldr = 0; a.G = t->grid; a.flags = 0; a.pad = ks;
+  a.trace = nullptr; a.out16 = nullptr; a.stats = nullptr; a.ld16 = 0; a.pad2 = 0;
+  size_t sz = 104;
+  void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  hipStream_t s = (hipStream_t)stream;
+  if (hipModuleLaunchKernel(fn, t->grid, 1, 1, 256, 1, 1, 0, s, nullptr, extra) != hipSuccess) {
+    (void)hipGetLastError();
+    return PSAM_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(splitk_reduce_ln_kernel, dim3((M + 3) / 4), dim3(256), 0, s, ws, ks, bias, x, ldx, ln_w, ln_b, eps, (half_t*)out16, ld16, M, N);
+  return psam_launch_status();
+}
+
 // tile choice: 0 = auto; 1 = 128x128x64, four waves, two workgroups per CU (HIP); 11 = 256x256x64 persistent 8-wave kernel (HIP; the
 // folded-LayerNorm, head-major and split-K forms live here); 15 = the assembly kernels of gemm_asm_gen.py (256x256 tiles, four
 // waves, the default large tile); 16 = the half-tile ping-pong assembly kernels of gemm_asm2_gen.py (experimental). The other

@@ -158,6 +158,45 @@ def gemm(a, w, bias=None, out=None, epilogue=EPI_F16, resid=None, gamma=None, re
     return out
 
 
+_SPLITK = {}
+
+
+def gemm_splitk_ranges(M, N, K):
+    """K ranges `gemm_splitk_ln` would use for x[M,N] += a[M,K] w[N,K]^T on the current device, 0 when the shape does not pay (few 256-tiles
+    and a long K are needed: one SAM ViT-H / ViT-L image through mlp.lin2). PSAM_GEMM_SPLITK_ASM=0 switches the path off (A/B)."""
+    if _os.environ.get("PSAM_GEMM_SPLITK_ASM", "1") == "0":
+        return 0
+    key = (M, N, K, torch.cuda.current_device(), DISPATCH_EPOCH)
+    if key not in _SPLITK:
+        _SPLITK[key] = int(_lib.lib().psam_gemm_splitk_ranges(M, N, K))
+    return _SPLITK[key]
+
+
+def splitk_rows(M):
+    """rows of one plane of gemm_splitk_ln's workspace: M rounded up to whole 256-row tiles"""
+    return (M + 255) // 256 * 256
+
+
+def gemm_splitk_ln(a, w, bias, x, ks, ws, ln_w=None, ln_b=None, eps=1e-6, out16=None):
+    """x[M,N] (fp32, in place) += a[M,K] @ w[N,K]^T + bias as `ks` K ranges per 256-tile in one launch of the assembly kernel, then one
+    pass that sums the ranges (fixed order) and writes out16 = LayerNorm(x) (or fp16(x) when ln_w is None). ws: fp32 scratch of at least
+    ks * splitk_rows(M) * N elements owned by the caller (psam_gemm_f16_splitk_ln)."""
+    _req(a, torch.float16, "a"); _req(w, torch.float16, "w"); _req(bias, torch.float32, "bias"); _req(x, torch.float32, "x")
+    _req(ws, torch.float32, "ws"); _req(ln_w, torch.float32, "ln_w"); _req(ln_b, torch.float32, "ln_b"); _req(out16, torch.float16, "out16")
+    M, K = a.shape
+    N = w.shape[0]
+    assert x.shape == (M, N) and w.shape[1] == K and ws.is_contiguous() and ws.numel() >= ks * splitk_rows(M) * N
+    assert out16 is None or (out16.shape[0] >= M and out16.shape[-1] >= N)
+    t0 = GEMM_TIMER.start() if GEMM_TIMER is not None else None
+    st = _lib.lib().psam_gemm_f16_splitk_ln(_ptr(a), _ptr(w), _ptr(bias), _ptr(x), M, N, K, a.stride(0), w.stride(0), x.stride(0), ks,
+                                           _ptr(ws), _ptr(ln_w), _ptr(ln_b), float(eps), _ptr(out16),
+                                           0 if out16 is None else out16.stride(-2), _stream())
+    if t0 is not None:
+        GEMM_TIMER.stop(t0, 2.0 * M * N * K, tag=(M, N, K, EPI_F32, 0))
+    _lib.check(st, "psam_gemm_f16_splitk_ln")
+    return x
+
+
 _CU_COUNT = {}
 
 

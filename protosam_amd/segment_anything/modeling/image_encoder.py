@@ -222,6 +222,12 @@ class ImageEncoderViT(nn.Module):
         # operands. Not a throughput path (3x the matrix work on a kernel tuned for the decoder's shapes, fp32 activations in HBM): it
         # is the "same arithmetic width as the reference" line of bench.py beside the fp16-operand headline, with its own parity figure.
         self.gemm_x3 = os.environ.get("PSAM_ENCODER_X3", "0") != "0"
+        # One image at a time (the reference-shaped call), mlp.lin2 as K ranges of the assembly tile + one reduce pass that also applies the
+        # NEXT block's norm1 (ops.gemm_splitk_ln, round 6; caller-owned workspace: safe inside the captured graph). Measured per block of
+        # ViT-H: 74.6 -> 71.4 us (tools/r06/splitk_probe.py) - 240 workgroups instead of 160 bring every CU under the power cap and the
+        # clock drops from ~2.1 to ~1.7 GHz, so the three-fold shorter K loops buy 1 % of a one-slice call. Opt-in (PSAM_SPLITK_LIN2=1):
+        # it changes the summation order of the one-slice path for that 1 %.
+        self.splitk_lin2 = os.environ.get("PSAM_SPLITK_LIN2", "0") != "0"
 
     def _apply(self, fn, *a, **k):
         self._packed, self._ws = None, {}
@@ -347,7 +353,7 @@ class ImageEncoderViT(nn.Module):
         if B <= 2 and not self.gemm_x3 and ops.graph_wanted(patches, 2 * self.grid * self.grid):
             gc = self.__dict__.setdefault("_graphs", ops.GraphCache("the SAM image encoder forward"))
             key = (tuple(patches.shape), B, str(patches.device), getattr(self, "_weights_epoch", 0), self.fold_ln,
-                   getattr(self, "fold_min_fill", None), ops.dispatch_key(), self.split_fp16,
+                   getattr(self, "fold_min_fill", None), ops.dispatch_key(), self.split_fp16, self.splitk_lin2,
                    None if raw_norm is None else (tuple(raw_norm[0]), tuple(raw_norm[1])))
             out = gc.run(key, patches, lambda t: self._encode_patches(t, B, raw_norm))
             if out is not None:
@@ -382,7 +388,13 @@ class ImageEncoderViT(nn.Module):
             ops.gemm(patches, pk["patch_w"], pk["patch_b"], out=x, epilogue=ops.EPI_F32, resid=pk["pos"], resid_mod=N, **fk)
         if x3:
             self._encode_blocks_x3(pk, ws, B)
-        for blk, bp in zip(self.blocks if not x3 else (), pk["blocks"]):
+        # split-K form of mlp.lin2 (see __init__): only without the fold (one or two images), only where the library says it pays
+        sk = ops.gemm_splitk_ranges(M, D, 4 * D) if (self.splitk_lin2 and not fold and not x3 and not ops.QKV_HEAD_MAJOR) else 0
+        if sk >= 2 and "sk_ws" not in ws:
+            ws["sk_ws"] = torch.empty(sk * ops.splitk_rows(M) * D, dtype=torch.float32, device=x.device)
+        ln1_ready = False                                   # ws["ln"] already holds norm1(x) of the block about to run
+        nblk = len(pk["blocks"])
+        for bi, (blk, bp) in enumerate(zip(self.blocks if not x3 else (), pk["blocks"])):
             if fold:
                 ops.ln_finalize(stats, M, D, LN_EPS, mr=mr)
                 ops.gemm(x16, bp["qkv_wf"], bp["qkv_t"], out=ws["qkv"], epilogue=ops.EPI_F16, ln_mr=mr, ln_s=bp["qkv_s"])
@@ -390,7 +402,8 @@ class ImageEncoderViT(nn.Module):
                 ops.layernorm(x, bp["n1w"], bp["n1b"], LN_EPS, out=ws["ln"])
                 ops.gemm_heads(ws["ln"], bp["qkv_w"], bp["qkv_b"], hd, out=ws["qkv"])   # [3,H,B*N,hd]
             else:
-                ops.layernorm(x, bp["n1w"], bp["n1b"], LN_EPS, out=ws["ln"])
+                if not ln1_ready:
+                    ops.layernorm(x, bp["n1w"], bp["n1b"], LN_EPS, out=ws["ln"])
                 ops.gemm(ws["ln"], bp["qkv_w"], bp["qkv_b"], out=ws["qkv"], epilogue=ops.EPI_F16)
             blk.attn._attend(ws["qkv"], B, g, bp["ws"], bp["rpack"], bp["pad_row"], out=ws["att"], relq=ws["relq"],
                              rel_bufs=lambda: self._rel_buffers(ws, B, H, N))
@@ -401,7 +414,14 @@ class ImageEncoderViT(nn.Module):
             else:
                 ops.layernorm(x, bp["n2w"], bp["n2b"], LN_EPS, out=ws["ln"])
                 ops.gemm(ws["ln"], bp["l1w"], bp["l1b"], out=ws["hid"], epilogue=ops.EPI_GELU_F16)
-            ops.gemm(ws["hid"], bp["l2w"], bp["l2b"], out=x, epilogue=ops.EPI_F32, resid=x, **fk)
+            if sk >= 2:      # x += lin2(hid); ws["ln"] = the next block's norm1(x), or fp16(x) for the neck behind the last block
+                nxt = pk["blocks"][bi + 1] if bi + 1 < nblk else None
+                ops.gemm_splitk_ln(ws["hid"], bp["l2w"], bp["l2b"], x, sk, ws["sk_ws"], nxt["n1w"] if nxt else None,
+                                   nxt["n1b"] if nxt else None, LN_EPS, out16=ws["ln"])
+                ln1_ready = True
+            else:
+                ops.gemm(ws["hid"], bp["l2w"], bp["l2b"], out=x, epilogue=ops.EPI_F32, resid=x, **fk)
+        neck_cast_done = sk >= 2 and nblk > 0 and not x3
         # neck (image_encoder.py:90-106): the residual stream goes through the 1x1-conv GEMM as fp16 (with `fold_ln` the last
         # lin2 epilogue already wrote that copy)
         xh = ws["ln"]
@@ -420,7 +440,7 @@ class ImageEncoderViT(nn.Module):
             ops.gemm(ws["col_lo"], pk["neck2"], None, out=ws["n2"], epilogue=ops.EPI_F32, resid=ws["n2"])
             ops.gemm(ws["col"], pk["neck2_lo"], None, out=ws["n2"], epilogue=ops.EPI_F32, resid=ws["n2"])
         else:
-            if not fold:
+            if not fold and not neck_cast_done:
                 ops.cast_f16(x, xh)
             ops.gemm(xh, pk["neck0"], None, out=ws["n0"], epilogue=ops.EPI_F32)
             ops.layernorm(ws["n0"], pk["neck1w"], pk["neck1b"], LN_EPS, out=ws["n1"])

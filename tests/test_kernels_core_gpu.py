@@ -810,3 +810,58 @@ def test_gemm_f32x3_matches_fp32_accuracy(dev, M, N, K, mode):
     if mode != "tiny":
         assert err < 8 * 2.0 ** -22, (err, err_exact, err_f16)
     assert err < err_f16 / (10 if mode == "tiny" else 100), (err, err_f16)
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 1280, 5120), (4096, 1024, 4096), (3000, 1280, 5120)])
+@pytest.mark.parametrize("with_ln", [True, False])
+def test_gemm_splitk_asm_residual_layernorm(dev, M, N, K, with_ln):
+    """Round 6: x += a w^T + b as K ranges of the assembly tile (psam_gemm_asm_f32_sk: items = (tile, range), partial sums to planes of a
+    caller-owned workspace) + one pass that sums the ranges and applies the LayerNorm that follows in the block stack. Against the fp32
+    arithmetic, against the one-launch GEMM + LayerNorm pass it replaces, run-to-run identical, and identical when replayed from a graph."""
+    from protosam_amd import ops
+    ks = ops.gemm_splitk_ranges(M, N, K)
+    assert ks >= 2, ks
+    a = _rand((M, K), dev, 1.0, 71).half()
+    w = _rand((N, K), dev, 0.02, 72).half()
+    bias = _rand((N,), dev, 0.5, 73)
+    x0 = _rand((M, N), dev, 1.0, 74)
+    lnw, lnb = (1.0 + _rand((N,), dev, 0.1, 75)), _rand((N,), dev, 0.1, 76)
+    ws = torch.empty((ks, ops.splitk_rows(M), N), dtype=torch.float32, device=dev)
+    outs = []
+    for rep in range(2):
+        x = x0.clone()
+        o16 = torch.zeros((M, N), dtype=torch.float16, device=dev)
+        ws.fill_(float("nan"))                                     # every element the reduce pass reads has to be written by the launch
+        ops.gemm_splitk_ln(a, w, bias, x, ks, ws, lnw if with_ln else None, lnb if with_ln else None, 1e-6, out16=o16)
+        outs.append((x, o16))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    x, o16 = outs[0]
+    ref = x0 + a.float() @ w.float().t() + bias
+    torch.testing.assert_close(x, ref, rtol=1e-4, atol=3e-4)
+    ref16 = torch.nn.functional.layer_norm(x, (N,), lnw, lnb, 1e-6) if with_ln else x
+    torch.testing.assert_close(o16.float(), ref16, rtol=2e-3, atol=2e-3)
+    # the path it replaces: one GEMM launch with the residual epilogue, then the LayerNorm pass (same products, another summation order)
+    y = ops.gemm(a, w, bias, out=x0.clone(), epilogue=ops.EPI_F32, resid=x0)
+    torch.testing.assert_close(x, y, rtol=1e-5, atol=2e-5)
+    if with_ln:
+        y16 = ops.layernorm(y, lnw, lnb, 1e-6)
+        assert (o16.float() - y16.float()).abs().max().item() <= 4e-3
+    # graph capture: caller-owned workspace, no library state
+    xg = x0.clone()
+    og = torch.zeros_like(o16)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        ops.gemm_splitk_ln(a, w, bias, xg, ks, ws, lnw if with_ln else None, lnb if with_ln else None, 1e-6, out16=og)
+    xg.copy_(x0)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(xg, x) and torch.equal(og, o16)
+
+
+def test_gemm_splitk_asm_declines_shapes_that_do_not_pay(dev):
+    from protosam_amd import ops
+    assert ops.gemm_splitk_ranges(65536, 1280, 5120) == 0          # the CUs are full already
+    assert ops.gemm_splitk_ranges(4096, 1280, 1280) == 0           # 20 K-tiles: no range of >= 16
+    assert ops.gemm_splitk_ranges(4096, 768, 3072) == 0            # 48 tiles x 48 K-tiles: three ranges of 16 are 144 items, under 3/4 of the CUs
+    assert ops.gemm_splitk_ranges(4096, 1280, 5120) == 3
