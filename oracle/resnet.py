@@ -14,7 +14,6 @@ PINNED against independent code (tests/test_oracle_resnet_cpu.py), in two steps,
      equals the strided network's map (the atrous identity), which ties the shipped `dilate=(False, True, True)` form to step 1.
 torchvision itself (its weights' key names, which `TVDeeplabRes101Encoder` exposes) stays un-run: what is pinned is the architecture.
 """
-import torch
 import torch.nn.functional as F
 
 LAYERS = (3, 4, 23, 3)

@@ -12,7 +12,6 @@ Execution: activations are token-major (NHWC) fp16; every convolution is `psam_g
 none) with eval-mode BatchNorm folded into weights and bias and ReLU / identity-add fused in the epilogue (epilogue 3).
 Channel counts below 128 (stem, layer1 width 64) are zero-padded to 128 for the GEMM's N granularity.
 """
-import math
 
 import torch
 import torch.nn as nn

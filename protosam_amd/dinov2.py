@@ -16,7 +16,6 @@ and all LayerNorm statistics are fp32. The nn.Module tree below only holds param
 """
 import math
 import os
-import sys
 
 import torch
 import torch.nn as nn

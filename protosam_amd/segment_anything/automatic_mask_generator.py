@@ -28,7 +28,7 @@ import torch
 
 from .. import ops
 from .predictor import SamPredictor
-from .utils.amg import (area_from_rle, box_xyxy_to_xywh, build_all_layer_point_grids, generate_crop_boxes,
+from .utils.amg import (box_xyxy_to_xywh, build_all_layer_point_grids, generate_crop_boxes,
                         is_box_near_crop_edge, mask_to_rle, nms_xyxy)
 
 

@@ -8,7 +8,6 @@ route: PIL resize on the host, zero padding after normalisation, crop + resize o
 import numpy as np
 import torch
 
-from .. import ops
 from .utils.transforms import ResizeLongestSide
 
 
