@@ -5,6 +5,7 @@
   python oracle/make_fullsize_goldens.py 400 --wseed 777 --vseed 5 --stride 4
       # the same for another weight draw / another synthetic volume (every 4th slice): fullvolume_cfg4_w777_v5.npz
       # (round 5: "within 1e-3" is held on several draws, not on one - tests/test_fullsize_gpu.py VOLUME_VARIANTS)
+  python oracle/make_fullsize_goldens.py 4400 --stride 4     # round 6: the same gate on heavy-tailed SAM-H weights: fullvolume_cfg4_heavytail.npz
 
 The CPU oracle (pinned against the reference by oracle/validate_against_reference.py) is run ONCE, here in the build
 container, at the configurations' full model depth on seeded synthetic slices; `tests/test_fullsize_gpu.py` runs the HIP
@@ -129,7 +130,8 @@ def prompt_record(taps):
 
 
 def volume_record_name(cfg, wseed=1234, vseed=0):
-    return f"fullvolume_cfg{cfg}.npz" if (wseed, vseed) == (1234, 0) else f"fullvolume_cfg{cfg}_w{wseed}_v{vseed}.npz"
+    base = "fullvolume_cfg4_heavytail" if cfg == 44 else f"fullvolume_cfg{cfg}"      # 44: config 4 with synth.heavy_tail_sam_ weights
+    return f"{base}.npz" if (wseed, vseed) == (1234, 0) else f"{base}_w{wseed}_v{vseed}.npz"
 
 
 def make_whole_volume(cfg, wseed=1234, vseed=0, stride=1):
@@ -143,7 +145,7 @@ def make_whole_volume(cfg, wseed=1234, vseed=0, stride=1):
     from protosam_amd.runner import part_assign, support_set
     from protosam_amd.synth import synth_volume
     sam_type, n, kind, _, _ = volume_config(cfg)
-    enc_sd, sam_sd = _weights(sam_type, 512, seed=wseed)
+    enc_sd, sam_sd = _weights(sam_type, 512, heavy_tail=(cfg == 44), seed=wseed)
     vol, lab = synth_volume(n, 512, seed=vseed, kind=kind)
     svol, slab = synth_volume(n, 512, seed=vseed + 1, kind=kind)
     sup_imgs, sup_masks = support_set(svol, slab)
@@ -182,7 +184,7 @@ def make_whole_volume(cfg, wseed=1234, vseed=0, stride=1):
               f"(total {time.time() - t_all:.0f}s)", flush=True)
         if (z // stride) % 8 == 7 or z == zs[-1]:      # (checkpoint: a long run)
             # (the variants record which slices they hold; the default record keeps its round-4 layout byte for byte)
-            extra = {} if (wseed, vseed, stride) == (1234, 0, 1) else dict(zs=np.array(zs[:zs.index(z) + 1], dtype=np.int32))
+            extra = {} if (wseed, vseed, stride) == (1234, 0, 1) and cfg != 44 else dict(zs=np.array(zs[:zs.index(z) + 1], dtype=np.int32))
             np.savez_compressed(path, **extra, **out)
     print(f"wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)")
 
@@ -234,7 +236,7 @@ if __name__ == "__main__":
         torch.set_num_threads(args.threads)
     which = args.which or [3, 4, 5]
     for c in which:
-        if c in (300, 400):          # every slice of config 3 / 4 (long: ~10 / ~40 minutes on 8 cores)
+        if c in (300, 400, 4400):    # every slice of config 3 / 4 (long: ~10 / ~40 minutes on 8 cores); 4400: config 4, heavy-tailed weights
             make_whole_volume(c // 100, args.wseed, args.vseed, args.stride)
         else:
             make_config5() if c == 5 else make_volume_config(c)

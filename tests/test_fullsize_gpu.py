@@ -175,7 +175,10 @@ def _redecode_with_oracle_prompts(model, vol_d, z, ref_prompts):
 
 # (config, weight seed, volume seed): the round-4 records (every slice, weights 1234, volume 0) and, round 5, two more weight draws and
 # one more volume per configuration (config 3: every slice; config 4: every 4th) - oracle/make_fullsize_goldens.py --wseed / --vseed
-VOLUME_VARIANTS = [(3, 1234, 0), (4, 1234, 0), (3, 777, 0), (3, 4242, 0), (3, 1234, 5), (4, 777, 0), (4, 4242, 0), (4, 1234, 5)]
+# round 6: a fourth weight draw / third volume of config 4 (weights 99, volume 7), and config 4 with HEAVY-TAILED SAM-H weights (44:
+# synth.heavy_tail_sam_ - channel scales over 1.5 decades, massive-activation channels, Student-t projections) over every 4th slice
+VOLUME_VARIANTS = [(3, 1234, 0), (4, 1234, 0), (3, 777, 0), (3, 4242, 0), (3, 1234, 5), (4, 777, 0), (4, 4242, 0), (4, 1234, 5),
+                   (4, 99, 7), (44, 1234, 0)]
 
 
 @pytest.mark.parametrize("cfg,wseed,vseed", VOLUME_VARIANTS)
