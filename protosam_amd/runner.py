@@ -96,7 +96,7 @@ def run_slices(model, vol, sup_imgs, sup_masks, zs, device, out=None, batch=1, m
             st = model.last_stats.get("per_slice", [model.last_stats])
         for k, (pred, scores) in enumerate(res):
             if pred.shape[-1] == S:
-                out[i + k] = pred.to(torch.uint8)
+                out[i + k].copy_(pred)            # ({0., 1.} -> uint8 inside the one copy kernel)
             else:   # empty coarse mask: the reference hands back the all-zero 1024x1024 arg-max map (ProtoSAM.py:612-613)
                 out[i + k].zero_()
             stats[i + k] = st[k].get("n_prompts", 0) if k < len(st) else 0
