@@ -1,5 +1,5 @@
 """The functions of /root/reference/util/utils.py that sit on the hot path, by name, on the device kernels:
-`get_connected_components` (:474-494), `cca` (:496-541), `get_confidence_from_logits` (:429-434), `need_softmax` (:437-441);
+`get_connected_components` (:474-494), `cca` (:496-541), `get_confidence_from_logits` (:429-434), `need_softmax` (:60-61);
 `rotate_tensor_no_crop` / `reverse_tensor` live in protosam_amd/rotate.py and are re-exported here.
 
 `ProtoSAM.forward` never calls these (its component table stays on the device and only ~25 KB travel to the host); they exist
@@ -31,9 +31,9 @@ def get_confidence_from_logits(logits):
 
 
 def need_softmax(tensor, dim=1):
-    """util/utils.py:437-441: True unless the values along `dim` already sum to one and lie in [0, 1]."""
-    return not torch.all(torch.isclose(tensor.sum(dim=dim), torch.ones_like(tensor.sum(dim=dim))) & (tensor >= 0).all(dim=dim)
-                         & (tensor <= 1).all(dim=dim))
+    """util/utils.py:60-61 (the reference's expression, broadcasting included): True unless the values along `dim` already sum to one
+    and none is negative."""
+    return not torch.all(torch.isclose(tensor.sum(dim=dim), torch.ones_like(tensor.sum(dim=dim))) & (tensor >= 0))
 
 
 def get_connected_components(query_pred_original, query_pred_logits, return_conf=False):
